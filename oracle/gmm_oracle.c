@@ -1,0 +1,268 @@
+/*
+ * oracle/gmm_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, float64) of the reference's diagonal-GMM scoring
+ * arithmetic.  It exists so that tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py can CHECK the HIP path; nothing in the product
+ * (speaker-recognition_amd/) may include, link or call it.
+ *
+ * Parity pinning: this restatement is validated against the reference's own
+ * compiled C++ (oracle/_ref/pygmm_ref.so, built from /root/reference/src/gmm
+ * by oracle/Makefile) on the reference's shipped model fixtures; the resulting
+ * known-answer vectors are committed under tests/golden/ (see
+ * tests/golden/make_golden.py) and re-checked by tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * /root/reference/).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* src/gmm/src/gmm.cc:22 */
+static const double SQRT_2_PI = 2.5066282746310002;
+
+/* src/gmm/src/gmm.cc:34-38 -- log with a floor of 1e-15 for non-positive input */
+static double safe_log(double x)
+{
+    if (x <= 0)
+        x = 1e-15;
+    return log(x);
+}
+
+/* The reference DSO is built with -ffast-math, whose start-up object switches
+ * the SSE unit to flush-to-zero / denormals-are-zero (SURVEY.md section 7,
+ * hard part 3).  `ftz` reproduces that: results below DBL_MIN become 0. */
+static double flush(double v, int ftz)
+{
+    if (ftz && fabs(v) < DBL_MIN)
+        return 0.0;
+    return v;
+}
+
+/*
+ * Scalar restatement of remez5_0_log2_sse, src/gmm/src/fastexp.cc:99-212:
+ * clamp to [minlog, maxlog] (:104-105,128-131), a = x*log2e (:134-137),
+ * k = trunc(a - (a<0)) (:140-149), x -= k*C1, x -= k*C2 (:152-161),
+ * degree-5 polynomial in Horner form (:164-192), scale by 2^k built from the
+ * exponent bits (:195-206).
+ */
+static double remez5_exp(double x)
+{
+    const double maxlog = 7.09782712893383996843e2;
+    const double minlog = -7.08396418532264106224e2;
+    const double log2e = 1.4426950408889634073599;
+    const double c1 = 6.93145751953125E-1;
+    const double c2 = 1.42860682030941723212E-6;
+    const double w5 = 1.185268231308989403584147407056378360798378534739e-2;
+    const double w4 = 3.87412011356070379615759057344100690905653320886699e-2;
+    const double w3 = 0.16775408658617866431779970932853611481292418818223;
+    const double w2 = 0.49981934577169208735732248650232562589934399402426;
+    const double w1 = 1.00001092396453942157124178508842412412025643386873;
+    const double w0 = 0.99999989311082729779536722205742989232069120354073;
+
+    if (x > maxlog) x = maxlog;
+    if (x < minlog) x = minlog;
+    double a = x * log2e;
+    if (a < 0) a -= 1.0;
+    int32_t k = (int32_t)a; /* truncation, as _mm_cvttpd_epi32 */
+    double p = (double)k;
+    x -= p * c1;
+    x -= p * c2;
+    a = x * w5 + w4;
+    a = a * x + w3;
+    a = a * x + w2;
+    a = a * x + w1;
+    a = a * x + w0;
+    uint64_t bits = ((uint64_t)(uint32_t)(k + 1023)) << 52;
+    double scale;
+    memcpy(&scale, &bits, sizeof scale);
+    return a * scale;
+}
+
+/* src/gmm/src/gmm.cc:176-202 -- Gaussian::probability_of_fast_exp:
+ * buf[i] = -d*d/(2 s s) (:186-190), vector exp (:191), prod buf[i]/(sqrt(2pi) s) (:192-195). */
+static double gaussian_prob_fastexp(const double *x, const double *mean, const double *sigma,
+                                    int dim, int ftz)
+{
+    double prob = 1.0;
+    for (int i = 0; i < dim; i++) {
+        double s = sigma[i];
+        double d = x[i] - mean[i];
+        double e = remez5_exp(-d * d / (2 * s * s));
+        double p = e / (SQRT_2_PI * s);
+        prob = flush(prob * p, ftz);
+    }
+    return prob;
+}
+
+/* src/gmm/src/gmm.cc:153-174 -- Gaussian::probability_of (libm exp, linear domain). */
+static double gaussian_prob_libm(const double *x, const double *mean, const double *sigma,
+                                 int dim, int ftz)
+{
+    double prob = 1.0;
+    for (int i = 0; i < dim; i++) {
+        double s = sigma[i];
+        double d = x[i] - mean[i];
+        double p = exp(-d * d / (2 * s * s)) / (SQRT_2_PI * s);
+        prob = flush(prob * p, ftz);
+    }
+    return prob;
+}
+
+/* src/gmm/src/gmm.cc:78-99 -- Gaussian::log_probability_of (log domain). */
+static double gaussian_logprob(const double *x, const double *mean, const double *sigma, int dim)
+{
+    double prob = 0;
+    for (int i = 0; i < dim; i++) {
+        double s = sigma[i];
+        double s2 = s * s;
+        double d = x[i] - mean[i];
+        prob += -safe_log(SQRT_2_PI * s) - 1.0 / (2 * s2) * d * d;
+    }
+    return prob;
+}
+
+/*
+ * Per-frame log-likelihoods for one model.
+ *   mode 0: what the C ABI computes -- GMM::log_probability_of_fast_exp,
+ *           src/gmm/src/gmm.cc:237-244 (sum_k w_k * p_k, then safe_log), which is what
+ *           score_batch/score_all reach through threaded_log_probability_of (:533-569).
+ *   mode 1: GMM::log_probability_of, src/gmm/src/gmm.cc:229-235 (libm exp, linear domain).
+ *   mode 2: float64 log-sum-exp over per-mixture log densities (gmm.cc:78-99 for the
+ *           density) -- the formulation the HIP kernel uses; `clamp_compat` applies the
+ *           reference's underflow behaviour (LL < -708.396 -> ln(1e-15)).
+ * Layout: weights[K], mean[K*D], sigma[K*D] (sigma = standard deviations, gmm.hh:24-46),
+ * X[n*D] row-major, out[n].
+ */
+void oracle_gmm_score_batch(const double *weights, const double *mean, const double *sigma,
+                            int K, int D, const double *X, long n, double *out,
+                            int mode, int ftz, int clamp_compat)
+{
+    for (long t = 0; t < n; t++) {
+        const double *x = X + t * (long)D;
+        if (mode == 0 || mode == 1) {
+            double prob = 0;
+            for (int k = 0; k < K; k++) {
+                double p = (mode == 0)
+                    ? gaussian_prob_fastexp(x, mean + (long)k * D, sigma + (long)k * D, D, ftz)
+                    : gaussian_prob_libm(x, mean + (long)k * D, sigma + (long)k * D, D, ftz);
+                prob += flush(weights[k] * p, ftz);
+            }
+            out[t] = safe_log(prob);
+        } else {
+            double m = -INFINITY;
+            double *v = (double *)malloc(sizeof(double) * (size_t)K);
+            for (int k = 0; k < K; k++) {
+                v[k] = safe_log(weights[k]) +
+                       gaussian_logprob(x, mean + (long)k * D, sigma + (long)k * D, D);
+                if (v[k] > m) m = v[k];
+            }
+            double s = 0;
+            for (int k = 0; k < K; k++)
+                s += exp(v[k] - m);
+            double ll = m + log(s);
+            free(v);
+            if (clamp_compat && ll < -7.08396418532264106224e2)
+                ll = log(1e-15);
+            out[t] = ll;
+        }
+    }
+}
+
+/* score_all, src/gmm/src/pygmm.cc:98-102 + gmm.cc:562-569: sequential sum of the
+ * per-frame values in frame order. */
+double oracle_gmm_score_all(const double *weights, const double *mean, const double *sigma,
+                            int K, int D, const double *X, long n, int mode, int ftz,
+                            int clamp_compat)
+{
+    double *buf = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    oracle_gmm_score_batch(weights, mean, sigma, K, D, X, n, buf, mode, ftz, clamp_compat);
+    double prob = 0;
+    for (long t = 0; t < n; t++)
+        prob += buf[t];
+    free(buf);
+    return prob;
+}
+
+/*
+ * One EM iteration, restating GMMTrainerBaseline::iteration, src/gmm/src/gmm.cc:439-531:
+ * responsibilities w_k p_k(x) with the fast exp (:455-469), per-frame normalisation with
+ * MIN_PROB_SUM 1e-15 (:482-498), N_k with min_n_k 1e-6 (:502-513), weights N_k/n then
+ * normalised (:388-394), means (:396-412), variances around the NEW means with the
+ * sqrt(min_covar) floor (:415-437).  With map_relevance > 0 it restates the MAP variant
+ * instead (src/gmm/src/gmmubm.cc:40-81): weights and sigmas untouched, means
+ * alpha*E_k[x] + (1-alpha)*ubm_mean with alpha = N_k/(N_k + relevance).
+ * weights/mean/sigma are updated in place; ubm_mean may be NULL when map_relevance <= 0.
+ * Returns nothing; resp_scratch must hold K*n doubles.
+ */
+void oracle_gmm_em_iteration(double *weights, double *mean, double *sigma, int K, int D,
+                             const double *X, long n, double min_covar, double map_relevance,
+                             const double *ubm_mean, double *resp_scratch, int ftz)
+{
+    double *resp = resp_scratch; /* [k][i] as prob_of_y_given_x, gmm.hh:96 */
+    for (int k = 0; k < K; k++)
+        for (long i = 0; i < n; i++)
+            resp[(long)k * n + i] = weights[k] *
+                gaussian_prob_fastexp(X + i * (long)D, mean + (long)k * D, sigma + (long)k * D, D, ftz);
+    for (long i = 0; i < n; i++) {
+        double sum = 0;
+        for (int k = 0; k < K; k++)
+            sum += resp[(long)k * n + i];
+        if (!(sum > 0))
+            sum = 1e-15;
+        for (int k = 0; k < K; k++)
+            resp[(long)k * n + i] /= sum;
+    }
+    double *Nk = (double *)malloc(sizeof(double) * (size_t)K);
+    for (int k = 0; k < K; k++) {
+        double s = 0;
+        for (long i = 0; i < n; i++)
+            s += resp[(long)k * n + i];
+        if (s == 0)
+            s = 1e-6;
+        Nk[k] = s;
+    }
+    if (map_relevance <= 0) {
+        double wsum = 0;
+        for (int k = 0; k < K; k++) {
+            weights[k] = Nk[k] / (double)n;
+            wsum += weights[k];
+        }
+        for (int k = 0; k < K; k++)
+            weights[k] /= wsum;
+    }
+    double min_sigma = sqrt(min_covar);
+    for (int k = 0; k < K; k++) {
+        double *mu = mean + (long)k * D;
+        for (int d = 0; d < D; d++) {
+            double acc = 0;
+            for (long i = 0; i < n; i++)
+                acc += X[i * (long)D + d] * resp[(long)k * n + i];
+            if (map_relevance > 0) {
+                double alpha = Nk[k] / (Nk[k] + map_relevance);
+                mu[d] = acc * (1.0 / Nk[k] * alpha) + ubm_mean[(long)k * D + d] * (1 - alpha);
+            } else {
+                mu[d] = acc * (1.0 / Nk[k]);
+            }
+        }
+    }
+    if (map_relevance <= 0) {
+        for (int k = 0; k < K; k++) {
+            double *mu = mean + (long)k * D;
+            double *sg = sigma + (long)k * D;
+            for (int d = 0; d < D; d++) {
+                double acc = 0;
+                for (long i = 0; i < n; i++) {
+                    double t = X[i * (long)D + d] - mu[d];
+                    acc += t * t * resp[(long)k * n + i];
+                }
+                double s = sqrt(acc * (1.0 / Nk[k]));
+                sg[d] = s > min_sigma ? s : min_sigma;
+            }
+        }
+    }
+    free(Nk);
+}
