@@ -1,0 +1,162 @@
+/*
+ * include/pygmm_hip.h -- C ABI of lib/pygmm.so (MI355X / gfx950 build).
+ *
+ * Part 1 is a drop-in for the reference's FFI, /root/reference/src/gmm/src/pygmm.hh:11-43:
+ * the same ten symbols, the same signatures and argument meaning, so the reference's ctypes
+ * caller (src/gmm/python/pygmm.py:16 `cdll.LoadLibrary('../lib/pygmm.so')`) binds it
+ * unchanged.  Differences in behaviour, all deliberate:
+ *   - nothing throws across the boundary (reference: `throw "literal"`, gmm.cc:45,59,585);
+ *     legacy entry points report through sr_last_error() and return NULL / NaN / no-op;
+ *   - `concurrency` is accepted and ignored (the HIP grid replaces the thread pool,
+ *     gmm.cc:533-560);
+ *   - score_instance works (the reference aborts on assert(buffer != NULL),
+ *     pygmm.cc:113-117 -> gmm.cc:185).
+ * Part 2 (sr_ prefix) is the contiguous / batched / device-resident interface the hot path
+ * actually wants; the Python mirror of the reference surface calls these.
+ *
+ * Plain C types only; no HIP or C++ types cross this boundary.
+ */
+#ifndef PYGMM_HIP_H
+#define PYGMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GMM GMM; /* opaque; reference: class GMM, src/gmm/src/gmm.hh:130-173 */
+
+/* src/gmm/src/pygmm.hh:12-26 (mirrored by ctypes at src/gmm/python/pygmm.py:18-27) */
+struct Parameter {
+    int nr_instance;
+    int nr_dim;
+    int nr_mixture;
+    double min_covar;
+    double threshold;
+    int nr_iteration;
+    int init_with_kmeans;
+    int concurrency;
+    int verbosity;
+};
+
+/* ---------------- Part 1: legacy symbols (pygmm.hh:28-41) ---------------- */
+
+/* pygmm.hh:28 / pygmm.cc:50-52.  covariance_type must be 1 (COVTYPE_DIAGONAL, gmm.hh:18-22). */
+GMM *new_gmm(int nr_mixture, int covariance_type);
+/* pygmm.hh:29 / pygmm.cc:54-56 -> GMM::load, gmm.cc:664-682 (text format, gmm.cc:101-150). */
+GMM *load(const char *model_file);
+/* pygmm.hh:31 / pygmm.cc:58-61 -> GMM::dump, gmm.cc:655-662 (6 significant digits). */
+void dump(GMM *gmm, const char *model_file);
+/* pygmm.hh:33 / pygmm.cc:63-83 -> GMMTrainerBaseline::train, gmm.cc:581-653. X_in: nr_instance row pointers. */
+void train_model(GMM *gmm, double **X_in, struct Parameter *param);
+/* pygmm.hh:34 / pygmm.cc:85-96 -> MAP means-only adaptation, gmmubm.cc:29-81. */
+void train_model_from_ubm(GMM *gmm, GMM *ubm, double **X_in, struct Parameter *param);
+/* pygmm.hh:36 / pygmm.cc:98-102: sum over frames of the per-frame log-likelihood. */
+double score_all(GMM *gmm, double **X_in, int nr_instance, int nr_dim, int concurrency);
+/* pygmm.hh:37 / pygmm.cc:104-111: per-frame log-likelihoods into caller-owned prob_out[nr_instance]. */
+void score_batch(GMM *gmm, double **X_in, double *prob_out, int nr_instance, int nr_dim, int concurrency);
+/* pygmm.hh:38 / pygmm.cc:113-117. */
+double score_instance(GMM *gmm, double *x_in, int nr_dim);
+/* pygmm.hh:40-41 / pygmm.cc:119-120. */
+int get_dim(GMM *gmm);
+int get_nr_mixtures(GMM *gmm);
+
+/* ---------------- Part 2: extensions ---------------- */
+
+/* Status: 0 = ok, negative = error (text via sr_last_error(), thread-local). */
+const char *sr_last_error(void);
+
+/* Device plumbing. The HIP runtime is initialised lazily on first use (fork-safe for the
+ * multiprocessing callers of src/test/test-nperson.py:135-139). */
+int sr_device_count(void);
+int sr_set_device(int device);
+int sr_get_device(void);
+int sr_device_synchronize(void);
+int sr_device_name(char *buf, int buflen);
+
+/* Model handles beyond the legacy constructors. */
+void sr_free_gmm(GMM *gmm);
+GMM *sr_gmm_from_arrays(int nr_mixture, int nr_dim, const double *weights, const double *mean,
+                        const double *sigma);                       /* sigma = std deviations */
+int sr_gmm_get_params(GMM *gmm, double *weights, double *mean, double *sigma);
+int sr_gmm_dumps(GMM *gmm, char *buf, long buflen, long *needed);     /* text format into memory */
+GMM *sr_gmm_loads(const char *text);
+
+/* Contiguous fp32 scoring of ONE model (frames row-major [n][dim], host memory).
+ * flags: SR_CLAMP_COMPAT reproduces the reference's underflow behaviour
+ * (LL < -708.396 -> ln(1e-15), gmm.cc:34-38 + fastexp.cc:105). */
+#define SR_CLAMP_COMPAT 1
+int sr_score_frames_f32(GMM *gmm, const float *X, long n, int dim, float *ll_out, double *sum_out,
+                        int flags);
+
+/* Speaker set: S models packed once, resident in HBM (replaces the per-speaker ABI loop of
+ * src/testbench/gmmset.py:59-64,95-99). */
+typedef struct SRModelSet SRModelSet;
+SRModelSet *sr_modelset_create(GMM *const *models, int n_models);
+void sr_modelset_free(SRModelSet *set);
+int sr_modelset_size(SRModelSet *set);
+int sr_modelset_dim(SRModelSet *set);
+
+/* Utterance batch resident in HBM: either PCM (int16, concatenated, sample_offsets[U+1]) or
+ * features (fp32 [n][dim], frame_offsets[U+1]). */
+typedef struct SRBatch SRBatch;
+SRBatch *sr_batch_from_pcm(const int16_t *pcm, const int64_t *sample_offsets, int n_utt);
+SRBatch *sr_batch_from_pcm_f32(const float *pcm, const int64_t *sample_offsets, int n_utt);
+SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
+                                const int64_t *frame_offsets, int n_utt);
+void sr_batch_free(SRBatch *b);
+int sr_batch_num_utterances(SRBatch *b);
+int64_t sr_batch_num_rows(SRBatch *b);           /* samples (PCM) or frames (features) */
+int sr_batch_dim(SRBatch *b);                    /* 0 for PCM */
+int sr_batch_offsets(SRBatch *b, int64_t *offsets_out /* [U+1] */);
+int sr_batch_download(SRBatch *b, float *out);   /* features -> host, [rows][dim] */
+
+/* Score every utterance of a feature batch against every model of the set in one fused pass:
+ * sums_out[U][S] = sum_t LL_s(x_t) (double), argmax_out[U] = first maximum (gmmset.py:62-64),
+ * frame_ll_out (optional, may be NULL) = [S][n_frames] fp32 per-frame log-likelihoods. */
+int sr_score_batch_set(SRModelSet *set, SRBatch *features, double *sums_out, int *argmax_out,
+                       float *frame_ll_out, int flags);
+
+/* MFCC extractor (src/feature/MFCC.py:20-41 constants; :49-79 chain; utils.py:24-31 deltas). */
+typedef struct SRMfcc SRMfcc;
+SRMfcc *sr_mfcc_create(double fs, double win_length_ms, double win_shift_ms, int fft_size,
+                       int n_filters, int n_ceps, double pre_emphasis);
+void sr_mfcc_free(SRMfcc *m);
+int sr_mfcc_frame_len(SRMfcc *m);
+int sr_mfcc_frame_shift(SRMfcc *m);
+int64_t sr_mfcc_num_frames(SRMfcc *m, int64_t n_samples);   /* MFCC.py:57; 0 if too short (:56) */
+int sr_mfcc_tables(SRMfcc *m, double *window /*[L]*/, double *melbank /*[n_filters][fft/2+1]*/,
+                   double *dct /*[n_ceps][n_filters]*/);    /* host float64 tables, for tests */
+/* PCM batch -> feature batch (CMVN per utterance, then delta order nd in {0,1,2});
+ * cmvn=0 skips the normalisation (raw cepstra, for tests). Returns a new device batch. */
+SRBatch *sr_mfcc_extract_batch(SRMfcc *m, SRBatch *pcm, int nd, int cmvn);
+
+/* Fused serving step on resident inputs: PCM batch -> MFCC -> CMVN/delta -> scoring -> argmax. */
+int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out,
+                         int *argmax_out, int flags);
+
+/* GPU EM / MAP on contiguous fp32 frames (the engine behind train_model*). Returns the number
+ * of iterations run, negative on error. seed < 0 -> time-based. */
+int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
+                 const struct Parameter *param, long seed);
+
+/* Kernel timing by HIP events on the library's own stream. */
+#define SR_T_SCORE 0
+#define SR_T_MFCC 1
+#define SR_T_CMVN 2
+#define SR_T_FINALIZE 3
+#define SR_T_ESTEP 4
+#define SR_T_COUNT 5
+int sr_profile_enable(int on);
+int sr_profile_reset(void);
+int sr_profile_get(int kind, double *total_ms, long *launches);
+
+/* Tunables (kernel variant selection for A/B runs): key in {"score_frames_per_lane",
+ * "score_model_groups"}; value 0 = automatic. */
+int sr_set_option(const char *key, long value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYGMM_HIP_H */

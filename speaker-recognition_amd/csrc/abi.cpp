@@ -1,0 +1,470 @@
+// abi.cpp -- extern "C" surface of lib/pygmm.so (declared in include/pygmm_hip.h).
+// Part 1 reproduces the reference's ten symbols (src/gmm/src/pygmm.hh:28-41) on top of the
+// HIP path; part 2 is the contiguous / batched interface.  Nothing throws across this file.
+#include "../../include/pygmm_hip.h"
+
+#include "batch.hpp"
+#include "common.hpp"
+#include "gmm_model.hpp"
+#include "mfcc.hpp"
+#include "score.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+
+namespace sr {
+int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
+             long seed);
+}  // namespace sr
+
+using namespace sr;
+
+// ---- guards: park the message, never unwind into C ----
+#define SR_TRY try {
+#define SR_CATCH(ret)                          \
+    }                                          \
+    catch (const std::exception &e) {          \
+        set_error("%s", e.what());             \
+        return ret;                            \
+    }                                          \
+    catch (...) {                              \
+        set_error("unknown C++ exception");    \
+        return ret;                            \
+    }
+#define SR_CATCH_VOID                                          \
+    }                                                          \
+    catch (const std::exception &e) {                          \
+        set_error("%s", e.what());                             \
+        fprintf(stderr, "pygmm.so: %s\n", e.what());           \
+        return;                                                \
+    }                                                          \
+    catch (...) {                                              \
+        set_error("unknown C++ exception");                    \
+        return;                                                \
+    }
+
+static SRModelSet &single_set(GMM *g) {
+    if (!g) fail("null GMM handle");
+    if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
+    if (!g->single || g->single->device != ctx().device) {
+        auto s = std::make_shared<SRModelSet>();
+        s->host = pack_models({g});
+        upload_model_set(*s);
+        g->single = s;
+    }
+    return *g->single;
+}
+
+static std::unique_ptr<SRBatch> feature_batch(const float *X, int64_t n, int dim,
+                                              const int64_t *offsets, int n_utt) {
+    ensure_device();
+    if (n < 0 || dim <= 0 || n_utt < 0) fail("bad batch shape");
+    auto b = std::make_unique<SRBatch>();
+    b->kind = SRBatch::FEATURES;
+    b->n_utt = n_utt;
+    b->dim = dim;
+    b->n_rows = n;
+    b->offsets.assign(offsets, offsets + n_utt + 1);
+    if (b->offsets.front() != 0 || b->offsets.back() != n) fail("offsets must run from 0 to n");
+    for (int u = 0; u < n_utt; u++)
+        if (b->offsets[u + 1] < b->offsets[u]) fail("offsets must be non-decreasing");
+    b->data.upload(X, (size_t)n * dim);
+    b->d_offsets.upload(b->offsets.data(), b->offsets.size());
+    sync_stream();
+    return b;
+}
+
+// double** rows -> contiguous fp32 (the reference deep-copies too: pygmm.cc:16-23)
+static std::vector<float> rows_to_f32(double **X, long n, int dim) {
+    if (n > 0 && !X) fail("null X_in");
+    std::vector<float> out((size_t)n * dim);
+    for (long i = 0; i < n; i++) {
+        const double *r = X[i];
+        for (int j = 0; j < dim; j++) out[(size_t)i * dim + j] = (float)r[j];
+    }
+    return out;
+}
+
+static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out,
+                      int flags) {
+    SRModelSet &set = single_set(g);
+    if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
+    const int64_t off[2] = {0, n};
+    auto b = feature_batch(X, n, dim, off, 1);
+    double sum = 0.0;
+    score_batch_set(set, *b, &sum, nullptr, ll_out, flags);
+    if (sum_out) *sum_out = sum;
+}
+
+extern "C" {
+
+// ======================= Part 1: legacy symbols =======================
+
+GMM *new_gmm(int nr_mixture, int covariance_type) {
+    SR_TRY
+    if (covariance_type != 1) fail("only diagonal matrix supported.");  // gmm.cc:211-215
+    if (nr_mixture <= 0) fail("nr_mixture must be positive");
+    GMM *g = new GMM();
+    g->nr_mixtures = nr_mixture;
+    g->covariance_type = covariance_type;
+    return g;
+    SR_CATCH(nullptr)
+}
+
+GMM *load(const char *model_file) {
+    SR_TRY
+    if (!model_file) fail("null model_file");
+    std::ifstream fin(model_file, std::ios::binary);
+    if (!fin) fail("cannot open model file '%s'", model_file);
+    std::stringstream ss;
+    ss << fin.rdbuf();
+    auto g = std::make_unique<GMM>();
+    gmm_parse_text(ss.str(), *g);
+    return g.release();
+    SR_CATCH(nullptr)
+}
+
+void dump(GMM *gmm, const char *model_file) {
+    SR_TRY
+    if (!gmm || !model_file) fail("null argument to dump");
+    std::ofstream fout(model_file, std::ios::binary);
+    if (!fout) fail("cannot write model file '%s'", model_file);
+    fout << gmm_format_text(*gmm);
+    SR_CATCH_VOID
+}
+
+void train_model(GMM *gmm, double **X_in, struct Parameter *param) {
+    SR_TRY
+    if (!gmm || !param) fail("null argument to train_model");
+    std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
+    if (train_em(*gmm, nullptr, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
+        fail("%s", last_error().c_str());
+    SR_CATCH_VOID
+}
+
+void train_model_from_ubm(GMM *gmm, GMM *ubm, double **X_in, struct Parameter *param) {
+    SR_TRY
+    if (!gmm || !ubm || !param) fail("null argument to train_model_from_ubm");
+    std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
+    if (train_em(*gmm, ubm, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
+        fail("%s", last_error().c_str());
+    SR_CATCH_VOID
+}
+
+double score_all(GMM *gmm, double **X_in, int nr_instance, int nr_dim, int /*concurrency*/) {
+    SR_TRY
+    std::vector<float> X = rows_to_f32(X_in, nr_instance, nr_dim);
+    double sum = 0.0;
+    score_one(gmm, X.data(), nr_instance, nr_dim, nullptr, &sum, SR_CLAMP_COMPAT);
+    return sum;
+    SR_CATCH(std::numeric_limits<double>::quiet_NaN())
+}
+
+void score_batch(GMM *gmm, double **X_in, double *prob_out, int nr_instance, int nr_dim,
+                 int /*concurrency*/) {
+    SR_TRY
+    if (nr_instance > 0 && !prob_out) fail("null prob_out");
+    std::vector<float> X = rows_to_f32(X_in, nr_instance, nr_dim);
+    std::vector<float> ll((size_t)nr_instance);
+    score_one(gmm, X.data(), nr_instance, nr_dim, ll.data(), nullptr, SR_CLAMP_COMPAT);
+    for (int i = 0; i < nr_instance; i++) prob_out[i] = ll[i];
+    SR_CATCH_VOID
+}
+
+double score_instance(GMM *gmm, double *x_in, int nr_dim) {
+    SR_TRY
+    if (!x_in) fail("null x_in");
+    double *rows[1] = {x_in};
+    std::vector<float> X = rows_to_f32(rows, 1, nr_dim);
+    double sum = 0.0;
+    score_one(gmm, X.data(), 1, nr_dim, nullptr, &sum, SR_CLAMP_COMPAT);
+    return sum;
+    SR_CATCH(std::numeric_limits<double>::quiet_NaN())
+}
+
+int get_dim(GMM *gmm) { return gmm ? gmm->dim : 0; }
+int get_nr_mixtures(GMM *gmm) { return gmm ? gmm->nr_mixtures : 0; }
+
+// ======================= Part 2: extensions =======================
+
+const char *sr_last_error(void) { return last_error().c_str(); }
+
+int sr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sr_set_device(int device) {
+    SR_TRY
+    if (ctx().stream) {
+        if (device != ctx().device) fail("device already initialised as %d; set it before first use", ctx().device);
+        return 0;
+    }
+    if (device < 0) fail("negative device index");
+    ctx().device = device;
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_get_device(void) { return ctx().device; }
+
+int sr_device_synchronize(void) {
+    SR_TRY
+    ensure_device();
+    SR_HIP(hipDeviceSynchronize());
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_device_name(char *buf, int buflen) {
+    SR_TRY
+    ensure_device();
+    hipDeviceProp_t prop;
+    SR_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+    SR_CATCH(-1)
+}
+
+void sr_free_gmm(GMM *gmm) { delete gmm; }
+
+GMM *sr_gmm_from_arrays(int K, int D, const double *weights, const double *mean, const double *sigma) {
+    SR_TRY
+    if (K <= 0 || D <= 0 || !weights || !mean || !sigma) fail("bad arguments to sr_gmm_from_arrays");
+    auto g = std::make_unique<GMM>();
+    g->nr_mixtures = K;
+    g->dim = D;
+    g->weights.assign(weights, weights + K);
+    g->mean.assign(mean, mean + (size_t)K * D);
+    g->sigma.assign(sigma, sigma + (size_t)K * D);
+    for (double s : g->sigma)
+        if (!(s > 0)) fail("sigma must be positive");
+    return g.release();
+    SR_CATCH(nullptr)
+}
+
+int sr_gmm_get_params(GMM *g, double *weights, double *mean, double *sigma) {
+    SR_TRY
+    if (!g || !g->trained()) fail("GMM has no parameters");
+    if (weights) std::memcpy(weights, g->weights.data(), sizeof(double) * g->weights.size());
+    if (mean) std::memcpy(mean, g->mean.data(), sizeof(double) * g->mean.size());
+    if (sigma) std::memcpy(sigma, g->sigma.data(), sizeof(double) * g->sigma.size());
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_gmm_dumps(GMM *g, char *buf, long buflen, long *needed) {
+    SR_TRY
+    if (!g) fail("null GMM handle");
+    const std::string s = gmm_format_text(*g);
+    if (needed) *needed = (long)s.size() + 1;
+    if (buf && buflen > (long)s.size()) {
+        std::memcpy(buf, s.c_str(), s.size() + 1);
+        return 0;
+    }
+    return buf ? -2 : 0;
+    SR_CATCH(-1)
+}
+
+GMM *sr_gmm_loads(const char *text) {
+    SR_TRY
+    if (!text) fail("null text");
+    auto g = std::make_unique<GMM>();
+    gmm_parse_text(text, *g);
+    return g.release();
+    SR_CATCH(nullptr)
+}
+
+int sr_score_frames_f32(GMM *gmm, const float *X, long n, int dim, float *ll_out, double *sum_out,
+                        int flags) {
+    SR_TRY
+    if (n > 0 && !X) fail("null X");
+    score_one(gmm, X, n, dim, ll_out, sum_out, flags);
+    return 0;
+    SR_CATCH(-1)
+}
+
+SRModelSet *sr_modelset_create(GMM *const *models, int n_models) {
+    SR_TRY
+    if (!models || n_models <= 0) fail("empty model list");
+    std::vector<const GMM *> v(models, models + n_models);
+    for (auto *m : v)
+        if (!m) fail("null GMM handle in model list");
+    auto s = std::make_unique<SRModelSet>();
+    s->host = pack_models(v);
+    upload_model_set(*s);
+    return s.release();
+    SR_CATCH(nullptr)
+}
+
+void sr_modelset_free(SRModelSet *set) { delete set; }
+int sr_modelset_size(SRModelSet *set) { return set ? set->host.n_models : 0; }
+int sr_modelset_dim(SRModelSet *set) { return set ? set->host.dim : 0; }
+
+static SRBatch *pcm_batch(const void *pcm, bool is_f32, const int64_t *sample_offsets, int n_utt) {
+    ensure_device();
+    if (n_utt < 0 || !sample_offsets) fail("bad PCM batch arguments");
+    auto b = std::make_unique<SRBatch>();
+    b->kind = is_f32 ? SRBatch::PCMF32 : SRBatch::PCM16;
+    b->n_utt = n_utt;
+    b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
+    if (b->offsets.front() != 0) fail("sample_offsets[0] must be 0");
+    for (int u = 0; u < n_utt; u++)
+        if (b->offsets[u + 1] < b->offsets[u]) fail("sample_offsets must be non-decreasing");
+    b->n_rows = b->offsets.back();
+    if (b->n_rows > 0 && !pcm) fail("null PCM pointer");
+    if (is_f32)
+        b->data.upload(static_cast<const float *>(pcm), (size_t)b->n_rows);
+    else
+        b->pcm16.upload(static_cast<const int16_t *>(pcm), (size_t)b->n_rows);
+    b->d_offsets.upload(b->offsets.data(), b->offsets.size());
+    sync_stream();
+    return b.release();
+}
+
+SRBatch *sr_batch_from_pcm(const int16_t *pcm, const int64_t *sample_offsets, int n_utt) {
+    SR_TRY
+    return pcm_batch(pcm, false, sample_offsets, n_utt);
+    SR_CATCH(nullptr)
+}
+
+SRBatch *sr_batch_from_pcm_f32(const float *pcm, const int64_t *sample_offsets, int n_utt) {
+    SR_TRY
+    return pcm_batch(pcm, true, sample_offsets, n_utt);
+    SR_CATCH(nullptr)
+}
+
+SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
+                                const int64_t *frame_offsets, int n_utt) {
+    SR_TRY
+    if (!frame_offsets) fail("null frame_offsets");
+    if (n_frames > 0 && !X) fail("null X");
+    return feature_batch(X, n_frames, dim, frame_offsets, n_utt).release();
+    SR_CATCH(nullptr)
+}
+
+void sr_batch_free(SRBatch *b) { delete b; }
+int sr_batch_num_utterances(SRBatch *b) { return b ? b->n_utt : 0; }
+int64_t sr_batch_num_rows(SRBatch *b) { return b ? b->n_rows : 0; }
+int sr_batch_dim(SRBatch *b) { return (b && b->kind == SRBatch::FEATURES) ? b->dim : 0; }
+
+int sr_batch_offsets(SRBatch *b, int64_t *offsets_out) {
+    SR_TRY
+    if (!b || !offsets_out) fail("null argument");
+    std::memcpy(offsets_out, b->offsets.data(), sizeof(int64_t) * b->offsets.size());
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_batch_download(SRBatch *b, float *out) {
+    SR_TRY
+    if (!b || !out) fail("null argument");
+    if (b->kind != SRBatch::FEATURES) fail("only feature batches can be downloaded");
+    b->data.download(out, (size_t)b->n_rows * b->dim);
+    sync_stream();
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_score_batch_set(SRModelSet *set, SRBatch *features, double *sums_out, int *argmax_out,
+                       float *frame_ll_out, int flags) {
+    SR_TRY
+    if (!set || !features) fail("null argument");
+    score_batch_set(*set, *features, sums_out, argmax_out, frame_ll_out, flags);
+    return 0;
+    SR_CATCH(-1)
+}
+
+SRMfcc *sr_mfcc_create(double fs, double win_length_ms, double win_shift_ms, int fft_size,
+                       int n_filters, int n_ceps, double pre_emphasis) {
+    SR_TRY
+    return new SRMfcc(fs, win_length_ms, win_shift_ms, fft_size, n_filters, n_ceps, pre_emphasis);
+    SR_CATCH(nullptr)
+}
+
+void sr_mfcc_free(SRMfcc *m) { delete m; }
+int sr_mfcc_frame_len(SRMfcc *m) { return m ? m->frame_len : 0; }
+int sr_mfcc_frame_shift(SRMfcc *m) { return m ? m->frame_shift : 0; }
+int64_t sr_mfcc_num_frames(SRMfcc *m, int64_t n_samples) { return m ? mfcc_num_frames(*m, n_samples) : 0; }
+
+int sr_mfcc_tables(SRMfcc *m, double *window, double *melbank, double *dct) {
+    SR_TRY
+    if (!m) fail("null extractor");
+    if (window) std::memcpy(window, m->window.data(), sizeof(double) * m->window.size());
+    if (melbank) std::memcpy(melbank, m->melbank.data(), sizeof(double) * m->melbank.size());
+    if (dct) std::memcpy(dct, m->dct.data(), sizeof(double) * m->dct.size());
+    return 0;
+    SR_CATCH(-1)
+}
+
+SRBatch *sr_mfcc_extract_batch(SRMfcc *m, SRBatch *pcm, int nd, int cmvn) {
+    SR_TRY
+    if (!m || !pcm) fail("null argument");
+    if (!cmvn && nd != 0) fail("raw cepstra (cmvn=0) come without deltas");
+    auto out = std::make_unique<SRBatch>();
+    mfcc_extract_batch(*m, *pcm, nd, cmvn, *out);
+    return out.release();
+    SR_CATCH(nullptr)
+}
+
+int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out,
+                         int *argmax_out, int flags) {
+    SR_TRY
+    if (!m || !set || !pcm) fail("null argument");
+    static SRBatch *feat_ws = new SRBatch();   // reused across steps: the serving loop allocates nothing
+    mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
+    score_batch_set(*set, *feat_ws, sums_out, argmax_out, nullptr, flags);
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
+                 const struct Parameter *param, long seed) {
+    SR_TRY
+    if (!gmm || !X || !param) fail("null argument to sr_train_f32");
+    return train_em(*gmm, ubm_or_null, X, n, dim, *param, seed);
+    SR_CATCH(-1)
+}
+
+int sr_profile_enable(int on) {
+    ctx().profiling = on != 0;
+    return 0;
+}
+
+int sr_profile_reset(void) {
+    SR_TRY
+    profile_reset();
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_profile_get(int kind, double *total_ms, long *launches) {
+    SR_TRY
+    profile_get(kind, total_ms, launches);
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_set_option(const char *key, long value) {
+    SR_TRY
+    if (!key) fail("null key");
+    const std::string k(key);
+    if (k == "score_frames_per_lane") {
+        if (value != 0 && value != 1 && value != 2 && value != 4) fail("frames per lane must be 0/1/2/4");
+        score_options().frames_per_lane = (int)value;
+    } else if (k == "score_model_groups") {
+        score_options().model_groups = (int)value;
+    } else if (k == "score_packed") {
+        score_options().packed = (int)value;
+    } else {
+        fail("unknown option '%s'", key);
+    }
+    return 0;
+    SR_CATCH(-1)
+}
+
+}  // extern "C"

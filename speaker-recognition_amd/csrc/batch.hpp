@@ -1,0 +1,42 @@
+// batch.hpp -- utterance batches resident in HBM (C ABI handle `SRBatch *`) and the tile
+// tables that map workgroups onto (utterance, frame range).
+#pragma once
+
+#include "common.hpp"
+
+#include <memory>
+#include <vector>
+
+namespace sr {
+
+// One scoring workgroup covers `count` (<= 256*F) consecutive frames of ONE utterance, so the
+// per-utterance sums never need a segmented reduction inside the kernel.
+struct TileDesc {
+    int64_t start;  // first frame (global row index)
+    int32_t count;  // valid frames in this tile
+    int32_t utt;
+};
+
+struct TileTable {
+    int frames_per_tile = 0;
+    int n_tiles = 0;
+    DevBuf<TileDesc> d_tiles;
+    DevBuf<int> d_utt_tile_begin;  // [U+1]
+};
+
+}  // namespace sr
+
+struct SRBatch {
+    enum Kind { PCM16 = 0, PCMF32 = 1, FEATURES = 2 };
+    int kind = FEATURES;
+    int n_utt = 0;
+    int dim = 0;                    // features only
+    int64_t n_rows = 0;             // samples or frames
+    std::vector<int64_t> offsets;   // host copy, [U+1]
+    sr::DevBuf<int64_t> d_offsets;
+    sr::DevBuf<int16_t> pcm16;
+    sr::DevBuf<float> data;         // f32 PCM or features [n_rows][dim]
+    std::vector<std::unique_ptr<sr::TileTable>> tile_tables;
+
+    sr::TileTable &tiles_for(int frames_per_tile);
+};

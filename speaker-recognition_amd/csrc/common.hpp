@@ -1,0 +1,94 @@
+// common.hpp -- shared host-side plumbing for lib/pygmm.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace sr {
+
+// ---- errors: nothing may unwind through the C ABI (the reference's `throw "literal"`,
+// gmm.cc:45,59,585, would); entry points catch and park the text here. ----
+std::string &last_error();
+void set_error(const char *fmt, ...);
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+[[noreturn]] void fail(const char *fmt, ...);
+
+#define SR_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            ::sr::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                       __LINE__);                                                      \
+    } while (0)
+
+// ---- per-process device context: one stream, lazily created (fork-safe: nothing touches
+// HIP before the first call that needs the device). ----
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool profiling = false;
+    int n_cu = 256;
+};
+Ctx &ctx();
+void ensure_device();   // throws sr::Error when no usable GPU: the product has no CPU path
+
+// ---- kernel timing with HIP events on OUR stream ----
+enum TimerKind { T_SCORE = 0, T_MFCC = 1, T_CMVN = 2, T_FINALIZE = 3, T_ESTEP = 4, T_COUNT = 5 };
+struct ScopedKernelTimer {
+    explicit ScopedKernelTimer(TimerKind k);
+    ~ScopedKernelTimer();
+    TimerKind kind;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+void profile_collect();          // resolves pending event pairs (synchronises the stream)
+void profile_reset();
+void profile_get(int kind, double *ms, long *launches);
+
+// ---- device buffer ----
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) SR_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void upload(const T *src, size_t count) {
+        ensure(count);
+        if (count) SR_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    }
+    void download(T *dst, size_t count) const {
+        if (count) SR_HIP(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+    }
+};
+
+inline void sync_stream() { SR_HIP(hipStreamSynchronize(ctx().stream)); }
+
+}  // namespace sr

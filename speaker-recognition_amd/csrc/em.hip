@@ -1,0 +1,353 @@
+// em.hip -- EM / MAP training on the GPU: the engine behind train_model and
+// train_model_from_ubm (src/gmm/src/pygmm.cc:63-96).  Restates
+// GMMTrainerBaseline::train / ::iteration (src/gmm/src/gmm.cc:581-653, :439-531),
+// init_gaussians (:306-361, random-frame means; the k-means|| initialiser of kmeansII.cc is
+// replaced by a seeded k-means++ draw on the host -- initialisation is outside the hot path)
+// and the MAP variant GMMUBMTrainerBaseline (src/gmm/src/gmmubm.cc:29-81: means only,
+// relevance 16, weights and sigmas copied from the UBM).
+//
+// E-step on the device in two passes over the resident frames: (1) the scoring kernel gives the
+// per-frame log-likelihood; (2) em_stats_kernel recomputes the per-mixture log densities with
+// the same 2-FMA form, turns them into responsibilities and accumulates, per mixture,
+// N_k, sum g (x-mu_old), sum g (x-mu_old)^2 (centred on the current mean, so the variance
+// update does not cancel).  The M-step is O(K*D) and runs on the host in float64 with the
+// reference's formulas.
+#include "score.hpp"
+
+#include "../../include/pygmm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <random>
+
+namespace sr {
+
+constexpr float EM_MINLOG = -708.396418532264f;   // fastexp.cc:93,105: below this the reference's
+                                                  // linear-domain sum is 0 -> MIN_PROB_SUM path
+constexpr float LOG2E_F = 1.4426950408889634f;
+
+// One workgroup = one tile of 256 frames (lane = frame) walked over ALL mixtures, record by
+// record.  Phase A (lane = frame): log2 densities of the record's 4 mixtures -> responsibilities
+// into LDS.  Phase B (thread = (mixture j, dim d)): sweep the 256 frames of the tile out of LDS.
+// Per-workgroup slabs in global memory take the running sums (only this workgroup touches its
+// slab, in a fixed order -> deterministic); a second kernel adds the slabs in float64.
+template <int DP>
+__global__ __launch_bounds__(256)
+void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
+                     const float4 *__restrict__ params, int n_records,
+                     const float *__restrict__ mean_f32 /* [K_pad][DP] */,
+                     const float *__restrict__ frame_ll /* natural log, no clamp */,
+                     float *__restrict__ slabs /* [grid][K_pad][2*DP+1] */, int n_tiles) {
+    constexpr int REC = 2 * DP + 1;
+    constexpr int XS = DP + 1;                 // padded row stride: conflict-free column sweeps
+    __shared__ float xs[256 * XS];
+    __shared__ float gs[KB][256];
+    __shared__ float4 rec_s[REC];
+    const int tid = threadIdx.x;
+    const int K_pad = n_records * KB;
+    float *slab = slabs + (size_t)blockIdx.x * K_pad * REC;
+    const int j = tid / DP;                    // phase-B role
+    const int d = tid - j * DP;
+    const bool roleB = tid < KB * DP;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t frame = (int64_t)tile * 256 + tid;
+        const bool valid = frame < n_frames;
+        float x[DP];
+        float lse2 = 0.f;
+        bool live = false;
+        {
+            const float *src = X + (valid ? frame : 0) * dim;
+#pragma unroll
+            for (int dd = 0; dd < DP; dd++) {
+                x[dd] = (dd < dim) ? src[dd] : 0.f;
+                xs[tid * XS + dd] = valid ? x[dd] : 0.f;
+            }
+            if (valid) {
+                const float ll = frame_ll[frame];
+                live = ll >= EM_MINLOG;        // underflowed frames carry no responsibility (gmm.cc:482-498)
+                lse2 = ll * LOG2E_F;
+            }
+        }
+        for (int r = 0; r < n_records; r++) {
+            __syncthreads();                   // previous phase B done with gs / rec_s (and xs on r == 0)
+            if (tid < REC) rec_s[tid] = params[(size_t)r * REC + tid];
+            __syncthreads();
+            float acc[KB] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dd = 0; dd < DP; dd++) {
+                const float4 p0 = rec_s[2 * dd];
+                const float4 p1 = rec_s[2 * dd + 1];
+                const float t0 = fmaf(x[dd], p0.x, p0.y);
+                const float t1 = fmaf(x[dd], p0.z, p0.w);
+                const float t2 = fmaf(x[dd], p1.x, p1.y);
+                const float t3 = fmaf(x[dd], p1.z, p1.w);
+                acc[0] = fmaf(t0, t0, acc[0]);
+                acc[1] = fmaf(t1, t1, acc[1]);
+                acc[2] = fmaf(t2, t2, acc[2]);
+                acc[3] = fmaf(t3, t3, acc[3]);
+            }
+            const float4 cc = rec_s[2 * DP];
+            gs[0][tid] = live ? __builtin_amdgcn_exp2f(cc.x - acc[0] - lse2) : 0.f;
+            gs[1][tid] = live ? __builtin_amdgcn_exp2f(cc.y - acc[1] - lse2) : 0.f;
+            gs[2][tid] = live ? __builtin_amdgcn_exp2f(cc.z - acc[2] - lse2) : 0.f;
+            gs[3][tid] = live ? __builtin_amdgcn_exp2f(cc.w - acc[3] - lse2) : 0.f;
+            __syncthreads();
+            if (roleB) {
+                const int k = r * KB + j;
+                const float mu = mean_f32[(size_t)k * DP + d];
+                float sd = 0.f, sdd = 0.f, sn = 0.f;
+                for (int i = 0; i < 256; i++) {
+                    const float gam = gs[j][i];
+                    const float dv = xs[i * XS + d] - mu;
+                    const float gd = gam * dv;
+                    sd += gd;
+                    sdd = fmaf(gd, dv, sdd);
+                    sn += gam;
+                }
+                float *dst = slab + (size_t)k * REC;
+                dst[d] += sd;
+                dst[DP + d] += sdd;
+                if (d == 0) dst[2 * DP] += sn;
+            }
+        }
+        __syncthreads();                       // xs is rewritten by the next tile
+    }
+}
+
+__global__ __launch_bounds__(256)
+void em_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n_elem,
+                      double *__restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_elem) return;
+    double acc = 0.0;
+    for (int s = 0; s < n_slabs; s++) acc += (double)slabs[(size_t)s * n_elem + e];
+    out[e] = acc;
+}
+
+template <int DP>
+static void launch_stats(const float *X, int64_t n, int dim, const float4 *params, int n_records,
+                         const float *mean_f32, const float *frame_ll, float *slabs, int n_tiles,
+                         int grid) {
+    hipLaunchKernelGGL((em_stats_kernel<DP>), dim3(grid), dim3(256), 0, ctx().stream, X, n, dim,
+                       params, n_records, mean_f32, frame_ll, slabs, n_tiles);
+}
+
+static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const float4 *params,
+                           int n_records, const float *mean_f32, const float *frame_ll,
+                           float *slabs, int n_tiles, int grid) {
+#define SR_CASE(V) case V: launch_stats<V>(X, n, dim, params, n_records, mean_f32, frame_ll, slabs, n_tiles, grid); break;
+    switch (DP) {
+        SR_CASE(8) SR_CASE(13) SR_CASE(16) SR_CASE(24) SR_CASE(26) SR_CASE(32) SR_CASE(34)
+        SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64)
+        default: fail("no EM kernel for padded dim %d", DP);
+    }
+#undef SR_CASE
+}
+
+// ---- initialisation (host) ----
+static void init_from_data(GMM &g, const float *X, long n, int dim, const Parameter &param,
+                           std::mt19937_64 &rng) {
+    const int K = g.nr_mixtures;
+    g.dim = dim;
+    // data variance, unbiased, one sigma vector shared by all mixtures (gmm.cc:309-325,352-354)
+    std::vector<double> mean(dim, 0.0), var(dim, 0.0);
+    for (long i = 0; i < n; i++)
+        for (int d = 0; d < dim; d++) mean[d] += X[(size_t)i * dim + d];
+    for (int d = 0; d < dim; d++) mean[d] /= (double)n;
+    for (long i = 0; i < n; i++)
+        for (int d = 0; d < dim; d++) {
+            const double v = X[(size_t)i * dim + d] - mean[d];
+            var[d] += v * v;
+        }
+    g.sigma.assign((size_t)K * dim, 0.0);
+    for (int k = 0; k < K; k++)
+        for (int d = 0; d < dim; d++) g.sigma[(size_t)k * dim + d] = std::sqrt(var[d] / (double)(n - 1));
+    for (double s : g.sigma)
+        if (!(s > 0)) fail("training data has zero variance in some dimension");
+    g.mean.assign((size_t)K * dim, 0.0);
+    std::vector<long> pick(K);
+    if (param.init_with_kmeans > 0) {
+        // seeded k-means++ draw (D^2 sampling) on at most 20000 frames
+        const long m = std::min<long>(n, 20000);
+        std::vector<long> cand(m);
+        for (long i = 0; i < m; i++) cand[i] = (long)((double)i * n / m);
+        std::vector<double> d2(m, 1e300);
+        std::uniform_int_distribution<long> first(0, m - 1);
+        pick[0] = cand[first(rng)];
+        for (int k = 1; k <= K; k++) {
+            const float *c = X + (size_t)pick[k - 1] * dim;
+            double total = 0;
+            for (long i = 0; i < m; i++) {
+                const float *x = X + (size_t)cand[i] * dim;
+                double s = 0;
+                for (int d = 0; d < dim; d++) {
+                    const double v = (x[d] - c[d]) / g.sigma[d];
+                    s += v * v;
+                }
+                d2[i] = std::min(d2[i], s);
+                total += d2[i];
+            }
+            if (k == K) break;
+            std::uniform_real_distribution<double> u(0.0, total);
+            double r = u(rng), run = 0;
+            long chosen = m - 1;
+            for (long i = 0; i < m; i++) {
+                run += d2[i];
+                if (run >= r) { chosen = i; break; }
+            }
+            pick[k] = cand[chosen];
+        }
+    } else {
+        std::uniform_int_distribution<long> any(0, n - 1);   // gmm.cc:346-349
+        for (int k = 0; k < K; k++) pick[k] = any(rng);
+    }
+    for (int k = 0; k < K; k++)
+        for (int d = 0; d < dim; d++) g.mean[(size_t)k * dim + d] = X[(size_t)pick[k] * dim + d];
+    g.weights.assign(K, 1.0 / K);                            // gmm.cc:356-360
+    g.single.reset();
+}
+
+struct EmWorkspace {
+    DevBuf<float> slabs, mean_f32;
+    DevBuf<double> stats;
+};
+static EmWorkspace &ews() {
+    static EmWorkspace *w = new EmWorkspace();
+    return *w;
+}
+
+int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
+             long seed) {
+    ensure_device();
+    if (n <= 0) fail("X.size() == 0");                       // gmm.cc:582-586
+    if (dim <= 0) fail("bad dimension %d", dim);
+    std::mt19937_64 rng(seed >= 0 ? (uint64_t)seed : std::random_device{}());
+    if (param.verbosity >= 1)
+        printf("nr_instance: %ld nr_dim: %d nr_mixture: %d min_covar: %f threshold: %f nr_iteration: %d "
+               "init_with_kmeans: %d\n", n, dim, gmm.nr_mixtures, param.min_covar, param.threshold,
+               param.nr_iteration, param.init_with_kmeans);
+    if (ubm) {
+        if (!ubm->trained()) fail("UBM has no parameters");
+        if (ubm->dim != dim) fail("UBM dim %d != data dim %d", ubm->dim, dim);
+        gmm.nr_mixtures = ubm->nr_mixtures;                  // gmm_replace_with, gmmubm.cc:29-38
+        gmm.dim = ubm->dim;
+        gmm.weights = ubm->weights;
+        gmm.mean = ubm->mean;
+        gmm.sigma = ubm->sigma;
+        gmm.single.reset();
+    } else if (param.init_with_kmeans < 0 && gmm.trained() && gmm.dim == dim) {
+        // extension: warm start from the handle's current parameters (no re-initialisation)
+    } else {
+        if (gmm.nr_mixtures <= 0) fail("GMM has no mixture count");
+        if (n < 2) fail("need at least 2 frames to initialise the variances");
+        init_from_data(gmm, X, n, dim, param, rng);
+    }
+    const int K = gmm.nr_mixtures;
+    const double relevance = 16.0;                           // gmm.hh:118-120
+    const double min_sigma = std::sqrt(param.min_covar);
+
+    // frames resident on the device for the whole fit
+    SRBatch feat;
+    feat.kind = SRBatch::FEATURES;
+    feat.n_utt = 1;
+    feat.dim = dim;
+    feat.n_rows = n;
+    feat.offsets = {0, (int64_t)n};
+    feat.data.upload(X, (size_t)n * dim);
+    feat.d_offsets.upload(feat.offsets.data(), feat.offsets.size());
+    sync_stream();
+
+    const int n_tiles = (int)((n + 255) / 256);
+    const int grid = std::min(n_tiles, ctx().n_cu * 4);
+    auto &w = ews();
+
+    double last_ll = -std::numeric_limits<double>::max();
+    int it = 0;
+    for (; it < param.nr_iteration; it++) {
+        // ---- E-step ----
+        SRModelSet set;
+        set.host = pack_models({&gmm});
+        upload_model_set(set);
+        const int DP = set.host.dp;
+        const int n_records = (K + KB - 1) / KB;
+        const int K_pad = n_records * KB;
+        const int REC = 2 * DP + 1;
+        const ScoreResult sres = score_device(set, feat, true, 0);
+        std::vector<float> mean_f32((size_t)K_pad * DP, 0.f);
+        for (int k = 0; k < K; k++)
+            for (int d = 0; d < dim; d++) mean_f32[(size_t)k * DP + d] = (float)gmm.mean[(size_t)k * dim + d];
+        w.mean_f32.upload(mean_f32.data(), mean_f32.size());
+        const size_t n_elem = (size_t)K_pad * REC;
+        w.slabs.ensure((size_t)grid * n_elem);
+        w.stats.ensure(n_elem);
+        SR_HIP(hipMemsetAsync(w.slabs.p, 0, (size_t)grid * n_elem * sizeof(float), ctx().stream));
+        {
+            ScopedKernelTimer t(T_ESTEP);
+            dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p),
+                           n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
+        }
+        SR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(em_reduce_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0,
+                           ctx().stream, w.slabs.p, grid, (int)n_elem, w.stats.p);
+        SR_HIP(hipGetLastError());
+        std::vector<double> stats(n_elem);
+        w.stats.download(stats.data(), n_elem);
+        sync_stream();
+
+        // ---- M-step (float64, host; O(K*D)) ----
+        std::vector<double> Nk(K);
+        for (int k = 0; k < K; k++) {
+            double v = stats[(size_t)k * REC + 2 * DP];
+            if (v == 0) v = 1e-6;                            // min_n_k, gmm.cc:502-509
+            Nk[k] = v;
+        }
+        if (!ubm) {                                          // update_weights, gmm.cc:388-394
+            double wsum = 0;
+            for (int k = 0; k < K; k++) {
+                gmm.weights[k] = Nk[k] / (double)n;
+                wsum += gmm.weights[k];
+            }
+            for (int k = 0; k < K; k++) gmm.weights[k] /= wsum;
+        }
+        for (int k = 0; k < K; k++) {
+            for (int d = 0; d < dim; d++) {
+                const double sd = stats[(size_t)k * REC + d];
+                const double sdd = stats[(size_t)k * REC + DP + d];
+                const double mu_old = gmm.mean[(size_t)k * dim + d];
+                const double shift = sd / Nk[k];             // E_k[x] - mu_old
+                if (ubm) {                                   // update_means, gmmubm.cc:53-74
+                    const double alpha = Nk[k] / (Nk[k] + relevance);
+                    gmm.mean[(size_t)k * dim + d] =
+                        alpha * (mu_old + shift) + (1 - alpha) * ubm->mean[(size_t)k * dim + d];
+                } else {                                     // gmm.cc:396-412, :415-437
+                    gmm.mean[(size_t)k * dim + d] = mu_old + shift;
+                    // sum g (x - mu_new)^2 = sdd - 2 shift sd + shift^2 N = sdd - N shift^2
+                    double var = sdd / Nk[k] - shift * shift;
+                    if (var < 0) var = 0;
+                    gmm.sigma[(size_t)k * dim + d] = std::max(min_sigma, std::sqrt(var));
+                }
+            }
+        }
+        gmm.single.reset();
+
+        if (it % 2 == 0) continue;                           // gmm.cc:622-623
+        // total log-likelihood under the updated model (gmm.cc:631-641), reference clamp on
+        SRModelSet set2;
+        set2.host = pack_models({&gmm});
+        upload_model_set(set2);
+        double ll = 0.0;
+        score_batch_set(set2, feat, &ll, nullptr, nullptr, SR_CLAMP_COMPAT);
+        if (param.verbosity >= 1) printf("iter %d: ll %lf\n", it, ll);
+        const double ll_diff = ll - last_ll;
+        if (std::fabs(ll_diff) / std::fabs(ll) < param.threshold && ll_diff < param.threshold) {
+            it++;
+            break;                                           // gmm.cc:643-650
+        }
+        last_ll = ll;
+    }
+    return it;
+}
+
+}  // namespace sr

@@ -1,0 +1,157 @@
+// gmm_model.cpp -- text model format + parameter packing (host, float64 -> fp32 tables).
+#include "gmm_model.hpp"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace sr {
+
+namespace {
+
+struct Tok {
+    const char *p;
+    const char *end;
+    void skip() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool more() {
+        skip();
+        return p < end;
+    }
+    double num(const char *what) {
+        skip();
+        if (p >= end) fail("model text truncated while reading %s", what);
+        char *q = nullptr;
+        double v = std::strtod(p, &q);
+        if (q == p) fail("model text: cannot parse %s near '%.16s'", what, p);
+        p = q;
+        return v;
+    }
+};
+
+}  // namespace
+
+// Token-stream parse with the semantics of `in >> x` (gmm.cc:664-682, :125-150).
+void gmm_parse_text(const std::string &text, GMM &out) {
+    Tok t{text.data(), text.data() + text.size()};
+    double kd = t.num("nr_mixtures");
+    int K = (int)kd;
+    if (K <= 0 || K > (1 << 20)) fail("model text: bad mixture count %g", kd);
+    std::vector<double> w(K);
+    for (auto &v : w) v = t.num("weight");
+    std::vector<double> mean, sigma;
+    int dim = 0;
+    for (int k = 0; k < K; k++) {
+        int d = (int)t.num("dim");
+        int cov = (int)t.num("covariance_type");
+        if (cov != 1) fail("model text: only diagonal covariance (type 1) exists, got %d", cov);
+        if (d <= 0) fail("model text: bad dim %d", d);
+        if (k == 0) {
+            dim = d;
+            mean.resize((size_t)K * dim);
+            sigma.resize((size_t)K * dim);
+        } else if (d != dim) {
+            fail("model text: mixture %d has dim %d, expected %d", k, d, dim);
+        }
+        for (int i = 0; i < dim; i++) mean[(size_t)k * dim + i] = t.num("mean");
+        for (int i = 0; i < dim; i++) sigma[(size_t)k * dim + i] = t.num("sigma");
+    }
+    out.nr_mixtures = K;
+    out.covariance_type = 1;
+    out.dim = dim;
+    out.weights = std::move(w);
+    out.mean = std::move(mean);
+    out.sigma = std::move(sigma);
+    out.single.reset();
+}
+
+static void put(std::string &s, double v) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%g ", v);  // `out << v << ' '` at default precision
+    s += buf;
+}
+
+std::string gmm_format_text(const GMM &g) {
+    std::string s;
+    s.reserve((size_t)g.nr_mixtures * (g.dim * 2 + 2) * 12 + 64);
+    s += std::to_string(g.nr_mixtures) + "\n";
+    for (double w : g.weights) put(s, w);
+    s += "\n";
+    for (int k = 0; k < g.nr_mixtures; k++) {
+        s += std::to_string(g.dim) + " " + std::to_string(g.covariance_type) + "\n";
+        for (int i = 0; i < g.dim; i++) put(s, g.mean[(size_t)k * g.dim + i]);
+        s += "\n";
+        for (int i = 0; i < g.dim; i++) put(s, g.sigma[(size_t)k * g.dim + i]);
+        s += "\n";
+    }
+    return s;
+}
+
+static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64};
+
+int pick_padded_dim(int dim) {
+    for (int d : kDims)
+        if (d >= dim) return d;
+    fail("feature dim %d > 64 is not instantiated in this build", dim);
+}
+
+PackedModels pack_models(const std::vector<const GMM *> &models) {
+    if (models.empty()) fail("empty model set");
+    PackedModels pm;
+    pm.n_models = (int)models.size();
+    pm.dim = models[0]->dim;
+    pm.dp = pick_padded_dim(pm.dim);
+    const int DP = pm.dp;
+    const size_t rec_f4 = (size_t)2 * DP + 1;
+    const double LOG2E = 1.4426950408889634073599;
+    const double SQRT_2_PI = 2.5066282746310002;  // gmm.cc:22
+    pm.model_chunk_begin.push_back(0);
+    for (int s = 0; s < pm.n_models; s++) {
+        const GMM &g = *models[s];
+        if (!g.trained()) fail("model %d of the set is untrained/empty", s);
+        if (g.dim != pm.dim) fail("model %d has dim %d, set has %d", s, g.dim, pm.dim);
+        const int K = g.nr_mixtures;
+        const int n_rec = (K + KB - 1) / KB;
+        const size_t base_f4 = pm.params.size() / 4;
+        pm.params.resize(pm.params.size() + (size_t)n_rec * rec_f4 * 4, 0.0f);
+        for (int r = 0; r < n_rec; r++) {
+            float *rec = pm.params.data() + (base_f4 + (size_t)r * rec_f4) * 4;
+            for (int j = 0; j < KB; j++) {
+                const int k = r * KB + j;
+                float *cslot = rec + (size_t)2 * DP * 4 + j;
+                if (k >= K) {
+                    *cslot = NEG_BIG;
+                    continue;
+                }
+                // c = log2e * (ln w - sum ln(sqrt(2pi) sigma)); ln of a non-positive weight is
+                // treated as -inf -> NEG_BIG (the reference's linear-domain sum just adds 0).
+                double c = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                for (int d = 0; d < pm.dim; d++) {
+                    const double sg = g.sigma[(size_t)k * pm.dim + d];
+                    const double mu = g.mean[(size_t)k * pm.dim + d];
+                    const double sc = std::sqrt(LOG2E * 0.5) / sg;
+                    // record layout: dim d -> two float4: {s0,m0,s1,m1} {s2,m2,s3,m3}
+                    float *pair = rec + (size_t)d * 8 + (size_t)j * 2;
+                    pair[0] = (float)sc;
+                    pair[1] = (float)(-mu * sc);
+                    c -= std::log(SQRT_2_PI * sg);
+                }
+                c *= LOG2E;
+                *cslot = (std::isfinite(c) && c > (double)NEG_BIG) ? (float)c : NEG_BIG;
+            }
+        }
+        for (int r0 = 0; r0 < n_rec; r0 += CB) {
+            ChunkDesc cd;
+            cd.offset_f4 = (uint32_t)(base_f4 + (size_t)r0 * rec_f4);
+            cd.n_records = std::min(CB, n_rec - r0);
+            cd.model_done = (r0 + CB >= n_rec) ? s : -1;
+            cd.pad = 0;
+            pm.chunks.push_back(cd);
+        }
+        pm.model_chunk_begin.push_back((int)pm.chunks.size());
+    }
+    return pm;
+}
+
+}  // namespace sr

@@ -1,0 +1,73 @@
+// gmm_model.hpp -- host-side model objects behind the C ABI handles, the reference's text
+// model format, and the packing of mixture parameters into the layout the scoring kernel
+// streams through LDS.
+#pragma once
+
+#include "common.hpp"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+struct SRModelSet;
+
+// The handle type of the C ABI (`GMM *`).  Reference: class GMM, src/gmm/src/gmm.hh:130-173;
+// per-Gaussian mean/sigma (sigma = STANDARD DEVIATIONS) as gmm.hh:24-46.
+struct GMM {
+    int nr_mixtures = 0;
+    int covariance_type = 1;  // COVTYPE_DIAGONAL, gmm.hh:18-22
+    int dim = 0;
+    std::vector<double> weights;  // [K]
+    std::vector<double> mean;     // [K*D]
+    std::vector<double> sigma;    // [K*D]
+    std::shared_ptr<SRModelSet> single;  // lazily packed one-model set (invalidated by training)
+    bool trained() const { return dim > 0 && (int)weights.size() == nr_mixtures; }
+};
+
+namespace sr {
+
+// ---- text format: GMM::load gmm.cc:664-682 / Gaussian::load :125-150; GMM::dump :655-662 /
+// Gaussian::dump :101-123 (default ostream precision = "%g", 6 significant digits) ----
+void gmm_parse_text(const std::string &text, GMM &out);
+std::string gmm_format_text(const GMM &g);
+
+// ---- packed parameters ----
+// A record holds KB=4 mixtures for all (padded) dims: for d in [0,DP): float4 pair
+//   {s0,m0,s1,m1}, {s2,m2,s3,m3}      with s = sqrt(log2(e)/2)/sigma, m = -mean*s
+// followed by one float4 {c0,c1,c2,c3}, c = log2(e) * (ln w - sum_d ln(sqrt(2 pi) sigma_d)),
+// so that  log2-density_k(x) = c_k - sum_d (x_d*s_kd + m_kd)^2     (2 FMAs per (d,k)).
+// Padded mixtures carry c = -1e30 (contribute 2^-inf = 0); padded dims carry s = m = 0.
+// Record size = (2*DP+1) float4.  A chunk = up to CB consecutive records of ONE model and is
+// what a workgroup copies into LDS at a time.
+constexpr int KB = 4;
+constexpr int CB = 8;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct ChunkDesc {
+    uint32_t offset_f4;  // float4 index of the chunk's first record in the params buffer
+    int32_t n_records;   // 1..CB
+    int32_t model_done;  // model index when this chunk is the last of its model, else -1
+    int32_t pad;
+};
+
+int pick_padded_dim(int dim);  // smallest instantiated kernel dim >= dim; throws if > 64
+
+struct PackedModels {
+    int n_models = 0;
+    int dim = 0;  // actual feature dim
+    int dp = 0;   // padded dim the kernels are instantiated for
+    std::vector<float> params;      // float4-granular
+    std::vector<ChunkDesc> chunks;  // all models, in model order
+    std::vector<int> model_chunk_begin;  // [S+1]
+};
+PackedModels pack_models(const std::vector<const GMM *> &models);
+
+}  // namespace sr
+
+// Device-resident speaker set (C ABI handle `SRModelSet *`).
+struct SRModelSet {
+    sr::PackedModels host;
+    sr::DevBuf<float> d_params;
+    sr::DevBuf<sr::ChunkDesc> d_chunks;
+    int device = -1;
+};

@@ -1,0 +1,442 @@
+// gmm_score.hip -- diagonal-GMM log-likelihood scoring on gfx950 (CDNA4), the hot loop of
+// the path.  Replaces Gaussian::probability_of_fast_exp (src/gmm/src/gmm.cc:176-202),
+// GMM::log_probability_of_fast_exp (:237-244) and threaded_log_probability_of (:533-569), and
+// -- by looping all S speaker models over a resident frame tile -- the per-speaker ABI loop
+// of GMMSet.predict_one (src/testbench/gmmset.py:59-64, 95-99).
+//
+// Formulation:  LL(x) = ln2 * log2sum_k 2^(c_k - sum_d (x_d s_kd + m_kd)^2)
+// with the tables of gmm_model.hpp; fp32, online max; optional reference-compat clamp.
+//
+// Mapping: a workgroup (256 threads = 4 wave64) owns one tile of 256*F frames of one
+// utterance; every lane keeps F frames (F*D floats) in VGPRs for the whole kernel, so X is
+// read from HBM exactly once.  Mixture parameters stream through LDS in chunks (double
+// buffered, prefetched through registers); all lanes read the same LDS address (broadcast),
+// two ds_read_b128 feed 8*F FMAs.  The log-sum-exp is online per lane, in the log2 domain
+// (v_exp_f32 / v_log_f32 are base-2).  No MFMA: the 2-FMA distance form is not a contraction.
+#include "score.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace sr {
+
+struct ScoreArgs {
+    const float *X;            // [n_frames][dim] row-major fp32
+    const TileDesc *tiles;
+    const float4 *params;
+    const ChunkDesc *chunks;
+    const int *group_chunk_begin;  // [G+1]
+    double *partial;           // [n_tiles][S][4]  per-wave partial sums
+    float *frame_ll;           // [S][n_frames] or nullptr
+    int64_t n_frames;
+    int dim;
+    int n_models;
+    int clamp;
+};
+
+constexpr float LN2_F = 0.69314718055994530942f;
+constexpr float MINLOG_F = -708.396418532264f;     // fastexp.cc:93,105
+constexpr float LN_1E_15_F = -34.538776394910684f;  // safe_log floor, gmm.cc:34-38
+
+__host__ __device__ constexpr int score_waves_per_eu(int dp, int f) {
+    return (dp * f + 44 <= 128) ? 4 : (dp * f + 44 <= 168) ? 3 : 2;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Lane-private arithmetic on either one frame (float) or a packed pair of frames (v2f ->
+// v_pk_fma_f32, the mixture constants broadcast to both halves through op_sel).
+template <bool PK> struct Lanes;
+template <> struct Lanes<false> {
+    using T = float;
+    static constexpr int W = 1;
+    static __device__ __forceinline__ T zero() { return 0.0f; }
+    static __device__ __forceinline__ T fma_bcast(T x, float s, float m) { return fmaf(x, s, m); }
+    static __device__ __forceinline__ T fma_sq(T t, T acc) { return fmaf(t, t, acc); }
+    static __device__ __forceinline__ float get(T v, int) { return v; }
+    static __device__ __forceinline__ void set(T &v, int, float s) { v = s; }
+};
+template <> struct Lanes<true> {
+    using T = v2f;
+    static constexpr int W = 2;
+    static __device__ __forceinline__ T zero() { return (v2f){0.0f, 0.0f}; }
+    static __device__ __forceinline__ T fma_bcast(T x, float s, float m) {
+        return __builtin_elementwise_fma(x, (v2f){s, s}, (v2f){m, m});
+    }
+    static __device__ __forceinline__ T fma_sq(T t, T acc) { return __builtin_elementwise_fma(t, t, acc); }
+    static __device__ __forceinline__ float get(T v, int e) { return e ? v.y : v.x; }
+    static __device__ __forceinline__ void set(T &v, int e, float s) { if (e) v.y = s; else v.x = s; }
+};
+
+template <int DP, int F, bool PK>
+__global__ __launch_bounds__(256, score_waves_per_eu(DP, F))
+void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ tiles,
+                      const float4 *__restrict__ params, const ChunkDesc *__restrict__ chunks,
+                      const int *__restrict__ group_chunk_begin, double *__restrict__ partial,
+                      float *__restrict__ frame_ll, int64_t n_frames, int dim, int n_models,
+                      int clamp) {
+    using L = Lanes<PK>;
+    using XT = typename L::T;
+    constexpr int W = L::W;
+    constexpr int NV = F / W;                // lane-private vectors per dim
+    static_assert(F % W == 0, "packed variant needs an even number of frames per lane");
+    constexpr int REC = 2 * DP + 1;          // float4 per record
+    constexpr int CHUNK_F4 = CB * REC;       // float4 per LDS buffer
+    constexpr int PF = (CHUNK_F4 + 255) / 256;
+    // Two separately named LDS objects (not one [2][..] array): the buffer a ds_read touches
+    // is then statically distinct from the one an in-flight LDS-DMA writes, which lets hipcc
+    // keep the DMA outstanding across the compute instead of draining vmcnt(0) first.
+    __shared__ float4 lds_a[CHUNK_F4];
+    __shared__ float4 lds_b[CHUNK_F4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileDesc tile = tiles[blockIdx.x];
+    const int g = blockIdx.y;
+    const int chunk_begin = group_chunk_begin[g];
+    const int chunk_end = group_chunk_begin[g + 1];
+
+    // LDS-DMA (global_load_lds_dwordx4): LDS destination = wave-uniform base + lane*16, so a
+    // chunk (a linear run of float4) lands as a linear image; no VGPR round trip.
+    auto stage = [&](float4 *dst, const ChunkDesc cd) {
+        const float4 *src = params + cd.offset_f4;
+        const int n4 = cd.n_records * REC;
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int base = (i * 4 + wave) * 64;
+            if (base + lane < n4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + base + lane),
+                    (__attribute__((address_space(3))) void *)(dst + base), 16, 0, 0);
+        }
+    };
+    stage(lds_a, chunks[chunk_begin]);   // in flight while the frames are fetched
+
+    // ---- resident frames: frame f of this lane = tile.start + f*256 + tid ----
+    XT x[NV][DP];
+    bool valid[F];
+    int64_t row[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        const int local = f * 256 + tid;
+        valid[f] = local < tile.count;
+        row[f] = tile.start + (valid[f] ? local : 0);
+        const float *src = X + row[f] * dim;
+        if (dim == DP) {
+#pragma unroll
+            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, src[d]);
+        } else {
+#pragma unroll
+            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, (d < dim) ? src[d] : 0.0f);
+        }
+    }
+
+    float m[F], ssum[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        m[f] = NEG_BIG;
+        ssum[f] = 0.0f;
+    }
+    __syncthreads();   // drains the LDS-DMA of chunk 0 (hipcc emits vmcnt(0) before the barrier)
+
+    // One chunk: stage the next one into `other`, run all records of `cur`, close the model
+    // if the chunk is its last, then barrier (next chunk landed; everyone is done with `cur`).
+    auto do_chunk = [&](const float4 *cur, float4 *other, int c) {
+        const ChunkDesc cd = chunks[c];
+        if (c + 1 < chunk_end) stage(other, chunks[c + 1]);
+
+        for (int r = 0; r < cd.n_records; r++) {
+            const float4 *rec = cur + r * REC;
+            XT acc[NV][KB];
+#pragma unroll
+            for (int h = 0; h < NV; h++)
+#pragma unroll
+                for (int j = 0; j < KB; j++) acc[h][j] = L::zero();
+#pragma unroll
+            for (int d = 0; d < DP; d++) {
+                const float4 p0 = rec[2 * d];
+                const float4 p1 = rec[2 * d + 1];
+#pragma unroll
+                for (int h = 0; h < NV; h++) {
+                    const XT xv = x[h][d];
+                    const XT t0 = L::fma_bcast(xv, p0.x, p0.y);
+                    const XT t1 = L::fma_bcast(xv, p0.z, p0.w);
+                    const XT t2 = L::fma_bcast(xv, p1.x, p1.y);
+                    const XT t3 = L::fma_bcast(xv, p1.z, p1.w);
+                    acc[h][0] = L::fma_sq(t0, acc[h][0]);
+                    acc[h][1] = L::fma_sq(t1, acc[h][1]);
+                    acc[h][2] = L::fma_sq(t2, acc[h][2]);
+                    acc[h][3] = L::fma_sq(t3, acc[h][3]);
+                }
+            }
+            const float4 cc = rec[2 * DP];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const float v0 = cc.x - L::get(acc[f / W][0], f % W);
+                const float v1 = cc.y - L::get(acc[f / W][1], f % W);
+                const float v2 = cc.z - L::get(acc[f / W][2], f % W);
+                const float v3 = cc.w - L::get(acc[f / W][3], f % W);
+                const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                const float mn = fmaxf(m[f], mx);
+                const float e = __builtin_amdgcn_exp2f(v0 - mn) + __builtin_amdgcn_exp2f(v1 - mn) +
+                                __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
+                ssum[f] = fmaf(ssum[f], __builtin_amdgcn_exp2f(m[f] - mn), e);
+                m[f] = mn;
+            }
+        }
+
+        if (cd.model_done >= 0) {   // wave-uniform: close the model, start the next one
+            const int s = cd.model_done;
+            double mine = 0.0;
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                float ll = LN2_F * (m[f] + log2f(ssum[f]));
+                if (clamp && ll < MINLOG_F) ll = LN_1E_15_F;
+                if (valid[f]) {
+                    mine += (double)ll;
+                    if (frame_ll) frame_ll[(int64_t)s * n_frames + row[f]] = ll;
+                }
+                m[f] = NEG_BIG;
+                ssum[f] = 0.0f;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+            if (lane == 0) partial[((int64_t)blockIdx.x * n_models + s) * 4 + wave] = mine;
+        }
+        __syncthreads();
+    };
+
+    for (int c = chunk_begin; c < chunk_end; c += 2) {
+        do_chunk(lds_a, lds_b, c);
+        if (c + 1 < chunk_end) do_chunk(lds_b, lds_a, c + 1);
+    }
+}
+
+// Per utterance: add the tile/wave partials in a fixed order (deterministic), then the
+// reference's argmax -- first maximum wins (gmmset.py:62-64, `max(enumerate(scores), key=...)`).
+__global__ __launch_bounds__(256)
+void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n_models,
+                         double *sums, int *argmax) {
+    const int u = blockIdx.x;
+    const int tb = utt_tile_begin[u], te = utt_tile_begin[u + 1];
+    double best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int s = threadIdx.x; s < n_models; s += 256) {
+        double acc = 0.0;
+        for (int t = tb; t < te; t++) {
+            const double *p = partial + ((int64_t)t * n_models + s) * 4;
+            acc += p[0];
+            acc += p[1];
+            acc += p[2];
+            acc += p[3];
+        }
+        sums[(int64_t)u * n_models + s] = acc;
+        if (acc > best) {
+            best = acc;
+            best_i = s;
+        }
+    }
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    sv[threadIdx.x] = best;
+    si[threadIdx.x] = best_i;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) {
+            const double ov = sv[threadIdx.x + w];
+            const int oi = si[threadIdx.x + w];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) argmax[u] = (te > tb && si[0] != 0x7fffffff) ? si[0] : -1;
+}
+
+// ---------------- host side ----------------
+
+ScoreOptions &score_options() {
+    static ScoreOptions o;
+    return o;
+}
+
+struct ScoreWorkspace {
+    DevBuf<double> partial;
+    DevBuf<double> sums;
+    DevBuf<int> argmax;
+    DevBuf<int> group_chunk_begin;
+    DevBuf<float> frame_ll;
+};
+static ScoreWorkspace &ws() {
+    static ScoreWorkspace *w = new ScoreWorkspace();   // leaked on purpose: no hipFree at exit
+    return *w;
+}
+
+template <int DP, int F, bool PK>
+static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
+    dim3 grid((unsigned)n_tiles, (unsigned)n_groups);
+    hipLaunchKernelGGL((gmm_score_kernel<DP, F, PK>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
+                       a.params, a.chunks, a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames,
+                       a.dim, a.n_models, a.clamp);
+}
+
+template <int DP>
+static void dispatch_f(const ScoreArgs &a, int F, bool pk, int n_tiles, int n_groups) {
+    if (F == 1) return launch_score<DP, 1, false>(a, n_tiles, n_groups);
+    if (F == 2) return pk ? launch_score<DP, 2, true>(a, n_tiles, n_groups)
+                          : launch_score<DP, 2, false>(a, n_tiles, n_groups);
+    if constexpr (DP <= 40) {
+        if (F == 4) return pk ? launch_score<DP, 4, true>(a, n_tiles, n_groups)
+                              : launch_score<DP, 4, false>(a, n_tiles, n_groups);
+    }
+    fail("frames_per_lane=%d not instantiated for dim %d", F, DP);
+}
+
+static void dispatch(const ScoreArgs &a, int DP, int F, bool pk, int n_tiles, int n_groups) {
+    switch (DP) {
+        case 8: dispatch_f<8>(a, F, pk, n_tiles, n_groups); break;
+        case 13: dispatch_f<13>(a, F, pk, n_tiles, n_groups); break;
+        case 16: dispatch_f<16>(a, F, pk, n_tiles, n_groups); break;
+        case 24: dispatch_f<24>(a, F, pk, n_tiles, n_groups); break;
+        case 26: dispatch_f<26>(a, F, pk, n_tiles, n_groups); break;
+        case 32: dispatch_f<32>(a, F, pk, n_tiles, n_groups); break;
+        case 34: dispatch_f<34>(a, F, pk, n_tiles, n_groups); break;
+        case 39: dispatch_f<39>(a, F, pk, n_tiles, n_groups); break;
+        case 40: dispatch_f<40>(a, F, pk, n_tiles, n_groups); break;
+        case 48: dispatch_f<48>(a, F, pk, n_tiles, n_groups); break;
+        case 56: dispatch_f<56>(a, F, pk, n_tiles, n_groups); break;
+        case 64: dispatch_f<64>(a, F, pk, n_tiles, n_groups); break;
+        default: fail("no scoring kernel for padded dim %d", DP);
+    }
+}
+
+static int auto_frames_per_lane(const SRBatch &b, int dp) {
+    const int fmax = dp <= 40 ? 4 : 2;
+    if (b.n_utt == 0) return 1;
+    const double mean_len = (double)b.n_rows / b.n_utt;
+    // pick the largest F whose tiles are mostly full
+    for (int f = fmax; f > 1; f >>= 1) {
+        const double tile = 256.0 * f;
+        const double tiles = std::ceil(mean_len / tile);
+        if (mean_len / (tiles * tile) >= 0.80) return f;
+    }
+    return 1;
+}
+
+void upload_model_set(SRModelSet &s) {
+    ensure_device();
+    s.d_params.upload(s.host.params.data(), s.host.params.size());
+    s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
+    sync_stream();
+    s.device = ctx().device;
+}
+
+ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags) {
+    ensure_device();
+    if (feat.kind != SRBatch::FEATURES) fail("scoring needs a feature batch");
+    if (feat.dim != set.host.dim)
+        fail("feature dim %d != model dim %d", feat.dim, set.host.dim);
+    const int S = set.host.n_models;
+    const int DP = set.host.dp;
+    int F = score_options().frames_per_lane ? score_options().frames_per_lane
+                                            : auto_frames_per_lane(feat, DP);
+    if (DP > 40 && F > 2) F = 2;
+    TileTable &tt = feat.tiles_for(256 * F);
+    const int U = feat.n_utt;
+
+    auto &w = ws();
+    w.sums.ensure((size_t)std::max(1, U) * S);
+    w.argmax.ensure((size_t)std::max(1, U));
+    if (tt.n_tiles > 0) {
+        // model groups: enough workgroups to fill the chip several times over
+        int G = score_options().model_groups;
+        if (G <= 0) {
+            const int target = ctx().n_cu * 2 * 6;
+            G = (target + tt.n_tiles - 1) / tt.n_tiles;
+        }
+        G = std::max(1, std::min(G, S));
+        std::vector<int> gcb(G + 1);
+        for (int g = 0; g <= G; g++) {
+            const int model = (int)(((int64_t)g * S) / G);
+            gcb[g] = set.host.model_chunk_begin[model];
+        }
+        w.group_chunk_begin.upload(gcb.data(), gcb.size());
+        w.partial.ensure((size_t)tt.n_tiles * S * 4);
+        if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
+
+        ScoreArgs a;
+        a.X = feat.data.p;
+        a.tiles = tt.d_tiles.p;
+        a.params = reinterpret_cast<const float4 *>(set.d_params.p);
+        a.chunks = set.d_chunks.p;
+        a.group_chunk_begin = w.group_chunk_begin.p;
+        a.partial = w.partial.p;
+        a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+        a.n_frames = feat.n_rows;
+        a.dim = feat.dim;
+        a.n_models = S;
+        a.clamp = (flags & 1) ? 1 : 0;
+        {
+            ScopedKernelTimer t(T_SCORE);
+            dispatch(a, DP, F, score_options().packed != 0 && F >= 2, tt.n_tiles, G);
+        }
+        SR_HIP(hipGetLastError());
+        sync_stream();  // gcb (host vector) must outlive its async upload
+    }
+    if (U > 0) {
+        ScopedKernelTimer t(T_FINALIZE);
+        hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
+                           w.partial.p, tt.d_utt_tile_begin.p, S, w.sums.p, w.argmax.p);
+    }
+    SR_HIP(hipGetLastError());
+    ScoreResult r;
+    r.d_sums = w.sums.p;
+    r.d_argmax = w.argmax.p;
+    r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? w.frame_ll.p : nullptr;
+    return r;
+}
+
+void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
+                     float *frame_ll_out, int flags) {
+    const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags);
+    const size_t U = (size_t)feat.n_utt, S = (size_t)set.host.n_models;
+    if (sums_out && U)
+        SR_HIP(hipMemcpyAsync(sums_out, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+    if (argmax_out && U)
+        SR_HIP(hipMemcpyAsync(argmax_out, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    if (frame_ll_out && r.d_frame_ll)
+        SR_HIP(hipMemcpyAsync(frame_ll_out, r.d_frame_ll, S * (size_t)feat.n_rows * sizeof(float),
+                              hipMemcpyDeviceToHost, ctx().stream));
+    sync_stream();
+}
+
+}  // namespace sr
+
+sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {
+    for (auto &t : tile_tables)
+        if (t->frames_per_tile == frames_per_tile) return *t;
+    auto tt = std::make_unique<sr::TileTable>();
+    tt->frames_per_tile = frames_per_tile;
+    std::vector<sr::TileDesc> tiles;
+    std::vector<int> begin(n_utt + 1, 0);
+    for (int u = 0; u < n_utt; u++) {
+        begin[u] = (int)tiles.size();
+        for (int64_t s = offsets[u]; s < offsets[u + 1]; s += frames_per_tile) {
+            sr::TileDesc td;
+            td.start = s;
+            td.count = (int32_t)std::min<int64_t>(frames_per_tile, offsets[u + 1] - s);
+            td.utt = u;
+            tiles.push_back(td);
+        }
+    }
+    begin[n_utt] = (int)tiles.size();
+    tt->n_tiles = (int)tiles.size();
+    tt->d_tiles.upload(tiles.data(), tiles.size());
+    tt->d_utt_tile_begin.upload(begin.data(), begin.size());
+    sr::sync_stream();
+    tile_tables.push_back(std::move(tt));
+    return *tile_tables.back();
+}

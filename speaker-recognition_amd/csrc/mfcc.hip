@@ -1,0 +1,456 @@
+// mfcc.hip -- the reference's own MFCC chain on gfx950: framing, Hamming window,
+// pre-emphasis on the WINDOWED frame, zero-padded real FFT, power spectrum, melfb.m-style
+// filterbank, ln, DCT-II (c0 dropped), per-utterance CMVN, first-difference deltas.
+// Restates src/feature/MFCC.py:14-16 (window), :20-41 (constants), :49-79 (chain),
+// :81-105 (filterbank), :107-113 (DCT) and src/feature/utils.py:24-31 (deltas).
+//
+// Mapping: one wave64 per frame (4 frames per 256-thread workgroup in flight); the N/2-point
+// complex Stockham FFT (radix 4, one trailing radix-2 pass when log2 is odd) ping-pongs
+// between two LDS slabs private to the wave; twiddles live in LDS; the filterbank is a
+// sparse row sweep with a wave64 shuffle reduction per band; constants are fp32 copies of
+// float64 tables built on the host exactly as the reference builds them.
+#include "batch.hpp"
+#include "mfcc.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace sr {
+
+// ---------------- host: tables (float64, as the reference) ----------------
+
+static std::vector<double> hamming(int n) {  // MFCC.py:14-16
+    std::vector<double> w(n);
+    for (int i = 0; i < n; i++) w[i] = 0.54 - 0.46 * std::cos(2 * M_PI / n * (i + 0.5));
+    return w;
+}
+
+static std::vector<double> dct_rows(int n_bands, int n_ceps) {  // MFCC.py:107-113 + :36-37
+    std::vector<double> d((size_t)n_ceps * n_bands);
+    for (int y = 1; y <= n_ceps; y++)
+        for (int x = 0; x < n_bands; x++)
+            d[(size_t)(y - 1) * n_bands + x] =
+                std::sqrt(2.0 / n_bands) * std::cos(M_PI * (2 * x + 1) * y / (2.0 * n_bands));
+    return d;  // row 0 (the one divided by sqrt 2) is c0, which the reference drops
+}
+
+static std::vector<double> mel_bank(double fs, int fft_size, int n_bands) {  // MFCC.py:81-105
+    const double f0 = 700.0 / fs;
+    const int fn2 = fft_size / 2;
+    const double lr = std::log(1 + 0.5 / f0) / (n_bands + 1);
+    auto bl = [&](int i) { return fft_size * f0 * (std::exp(i * lr) - 1); };
+    const int b1 = (int)std::floor(bl(0)) + 1;
+    const int b2 = (int)std::ceil(bl(1));
+    const int b3 = (int)std::floor(bl(n_bands));
+    const int b4 = std::min(fn2, (int)std::ceil(bl(n_bands + 1))) - 1;
+    const int n = b4 - b1 + 1;
+    std::vector<double> fp(n), pm(n);
+    for (int i = 0; i < n; i++) {
+        const double pf = std::log(1 + (double)(b1 + i) / f0 / fft_size) / lr;
+        fp[i] = std::floor(pf);
+        pm[i] = pf - fp[i];
+    }
+    std::vector<double> M((size_t)n_bands * (fn2 + 1), 0.0);
+    auto at = [&](int r, int c) -> double & {
+        if (r < 0 || r >= n_bands || c < 0 || c > fn2) fail("mel filterbank index out of range");
+        return M[(size_t)r * (fn2 + 1) + c];
+    };
+    for (int c = b2 - 1; c < b4; c++) at((int)fp[c] - 1, c + 1) += 2 * (1 - pm[c]);
+    for (int c = 0; c < b3; c++) at((int)fp[c], c + 1) += 2 * pm[c];
+    return M;
+}
+
+}  // namespace sr
+
+SRMfcc::SRMfcc(double fs_, double win_length_ms, double win_shift_ms, int fft_size_,
+               int n_filters_, int n_ceps_, double pre_emph_) {
+    using namespace sr;
+    fs = fs_;
+    fft_size = fft_size_;
+    n_filters = n_filters_;
+    n_ceps = n_ceps_;
+    pre_emph = pre_emph_;
+    frame_len = (int)(win_length_ms / 1000.0 * fs);    // MFCC.py:28
+    frame_shift = (int)(win_shift_ms / 1000.0 * fs);   // MFCC.py:29
+    if (fft_size < 32 || fft_size > 4096 || (fft_size & (fft_size - 1)))
+        fail("FFT_SIZE must be a power of two in [32, 4096], got %d", fft_size);
+    if (frame_len <= 0 || frame_shift <= 0) fail("empty frame (len %d shift %d)", frame_len, frame_shift);
+    if (frame_len > fft_size) fail("frame of %d samples does not fit FFT_SIZE %d", frame_len, fft_size);
+    if (n_filters < 2 || n_filters > 64) fail("n_filters must be in [2, 64], got %d", n_filters);
+    if (n_ceps < 1 || n_ceps >= n_filters) fail("n_ceps must be in [1, n_filters), got %d", n_ceps);
+    window = hamming(frame_len);
+    melbank = mel_bank(fs, fft_size, n_filters);
+    dct = dct_rows(n_filters, n_ceps);
+}
+
+namespace sr {
+
+struct MfccDev {
+    const float *window;      // [L]
+    const float2 *twiddle;    // [NFFT/2]  W_NFFT^k
+    const int *mel_row;       // [n_filters+1]
+    const int *mel_col;       // [nnz]
+    const float *mel_val;     // [nnz]
+    const float *mel_floor;   // [n_filters]  ln(1e-100 * row sum): the reference's floored silence
+    const float *dct;         // [n_ceps][n_filters]
+    int frame_len, frame_shift, fft_size, n_filters, n_ceps;
+    float pre_emph;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// W_NFFT^i for i in [0, NFFT): the table stores the first half, the second is its negative.
+__device__ __forceinline__ float2 tw(const float2 *t, int i, int nc) {
+    float2 w = t[i & (nc - 1)];
+    if (i & nc) w = make_float2(-w.x, -w.y);
+    return w;
+}
+
+template <typename PcmT>
+__global__ __launch_bounds__(256)
+void mfcc_frames_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
+                        const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
+                        MfccDev p, float *__restrict__ raw /* [n_frames][n_ceps] */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nc = p.fft_size >> 1;           // complex FFT length
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2 *buf_a = s_tw + nc + (size_t)wave * 2 * nc;
+    float2 *buf_b = buf_a + nc;
+    float *s_lm = reinterpret_cast<float *>(s_tw + nc + (size_t)4 * 2 * nc) + wave * 64;
+
+    for (int i = threadIdx.x; i < nc; i += 256) s_tw[i] = p.twiddle[i];
+    __syncthreads();
+
+    const int64_t frames_per_iter = (int64_t)gridDim.x * 4;
+    const int64_t iters = (n_frames + frames_per_iter - 1) / frames_per_iter;
+    for (int64_t it = 0; it < iters; it++) {
+        const int64_t frame = (it * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool active = frame < n_frames;   // wave-uniform
+
+        // ---- frame -> (utterance, local index): binary search in frame_off ----
+        int64_t base = 0;
+        if (active) {
+            int lo = 0, hi = n_utt;               // frame_off[lo] <= frame < frame_off[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (frame_off[mid] <= frame) lo = mid; else hi = mid;
+            }
+            base = sample_off[lo] + (frame - frame_off[lo]) * p.frame_shift;
+        }
+
+        // ---- window, then pre-emphasis on the windowed samples (MFCC.py:61-64); pack the
+        // zero-padded real frame as z[n] = y[2n] + i y[2n+1] ----
+        if (active) {
+            const int L = p.frame_len;
+            for (int n = lane; n < nc; n += 64) {
+                float re = 0.f, im = 0.f;
+                const int i0 = 2 * n;
+                if (i0 < L) {
+                    const float c0 = (float)pcm[base + i0] * p.window[i0];
+                    const float pm1 = i0 > 0 ? (float)pcm[base + i0 - 1] * p.window[i0 - 1] : 0.f;
+                    re = i0 > 0 ? c0 - pm1 * p.pre_emph : c0;
+                    if (i0 + 1 < L) {
+                        const float c1 = (float)pcm[base + i0 + 1] * p.window[i0 + 1];
+                        im = c1 - c0 * p.pre_emph;
+                    }
+                }
+                buf_a[n] = make_float2(re, im);
+            }
+        }
+        __syncthreads();
+
+        // ---- Stockham autosort FFT of length nc ----
+        float2 *in = buf_a, *out = buf_b;
+        int ns = 1;
+        for (; ns * 4 <= nc; ns *= 4) {
+            if (active) {
+                const int T = nc >> 2;
+                const int tstep = p.fft_size / (4 * ns) ;   // W_nc^(k*nc/(4ns)) = W_NFFT^(k*NFFT/(4ns))
+                for (int j = lane; j < T; j += 64) {
+                    const int k = j & (ns - 1);
+                    const int q = k * tstep;
+                    const float2 v0 = in[j];
+                    const float2 v1 = cmul(in[j + T], tw(s_tw, q, nc));
+                    const float2 v2 = cmul(in[j + 2 * T], tw(s_tw, 2 * q, nc));
+                    const float2 v3 = cmul(in[j + 3 * T], tw(s_tw, 3 * q, nc));
+                    const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+                    const float2 a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+                    const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+                    const float2 a3 = make_float2(v1.y - v3.y, v3.x - v1.x);   // (v1-v3)*(-i)
+                    const int j0 = ((j - k) << 2) + k;
+                    out[j0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+                    out[j0 + ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+                    out[j0 + 2 * ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+                    out[j0 + 3 * ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+                }
+            }
+            __syncthreads();
+            float2 *t = in; in = out; out = t;
+        }
+        if (ns < nc) {   // one radix-2 pass (ns == nc/2)
+            if (active) {
+                const int T = nc >> 1;
+                for (int j = lane; j < T; j += 64) {
+                    const float2 v0 = in[j];
+                    const float2 v1 = cmul(in[j + T], tw(s_tw, 2 * j, nc));   // W_nc^j
+                    out[j] = make_float2(v0.x + v1.x, v0.y + v1.y);
+                    out[j + T] = make_float2(v0.x - v1.x, v0.y - v1.y);
+                }
+            }
+            __syncthreads();
+            float2 *t = in; in = out; out = t;
+        }
+
+        // ---- real-FFT untangle + power spectrum (MFCC.py:66), bins 0..nc into `out` as floats ----
+        float *pw = reinterpret_cast<float *>(out);
+        if (active) {
+            for (int k = lane; k <= nc; k += 64) {
+                const float2 zk = in[k & (nc - 1)];
+                const float2 zr = in[(nc - k) & (nc - 1)];
+                const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
+                const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
+                const float2 w = tw(s_tw, k, nc);
+                const float2 xo = cmul(w, o);
+                const float xr = e.x + xo.x, xi = e.y + xo.y;
+                pw[k] = xr * xr + xi * xi;
+            }
+        }
+        __syncthreads();
+
+        // ---- mel filterbank (sparse rows, wave shuffle reduction) + ln (MFCC.py:67-69) ----
+        if (active) {
+            float mine = 0.f;
+            for (int b = 0; b < p.n_filters; b++) {
+                float acc = 0.f;
+                const int e1 = p.mel_row[b + 1];
+                for (int e = p.mel_row[b] + lane; e < e1; e += 64) acc = fmaf(p.mel_val[e], pw[p.mel_col[e]], acc);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+                if (lane == b) mine = acc > 0.f ? logf(acc) : p.mel_floor[b];
+            }
+            s_lm[lane] = mine;
+        }
+        __syncthreads();
+
+        // ---- DCT-II rows 1..n_ceps ----
+        if (active && lane < p.n_ceps) {
+            float acc = 0.f;
+            const float *drow = p.dct + lane * p.n_filters;
+            for (int b = 0; b < p.n_filters; b++) acc = fmaf(drow[b], s_lm[b], acc);
+            raw[frame * p.n_ceps + lane] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// Per-utterance CMVN (mean, population std, no epsilon -- MFCC.py:74-77) and causal
+// first-difference deltas AFTER the normalisation (utils.py:24-31).  Statistics in float64.
+__global__ __launch_bounds__(256)
+void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict__ raw_off,
+                       const int64_t *__restrict__ out_off, int n_ceps, int nd, int cmvn,
+                       float *__restrict__ out) {
+    const int u = blockIdx.x;
+    const int64_t r0 = raw_off[u];
+    const int64_t T = raw_off[u + 1] - r0;
+    const int64_t o0 = out_off[u];
+    const int64_t To = out_off[u + 1] - o0;
+    __shared__ double red[256];
+    __shared__ double s_mean[64], s_inv[64];
+    const int tid = threadIdx.x;
+    for (int c = 0; c < n_ceps; c++) {
+        double mean = 0.0, inv = 1.0;
+        if (cmvn && T > 1) {
+            double acc = 0.0;
+            for (int64_t t = tid; t < T; t += 256) acc += (double)raw[(r0 + t) * n_ceps + c];
+            red[tid] = acc;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) red[tid] += red[tid + w];
+                __syncthreads();
+            }
+            mean = red[0] / (double)T;
+            __syncthreads();
+            acc = 0.0;
+            for (int64_t t = tid; t < T; t += 256) {
+                const double dv = (double)raw[(r0 + t) * n_ceps + c] - mean;
+                acc += dv * dv;
+            }
+            red[tid] = acc;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) red[tid] += red[tid + w];
+                __syncthreads();
+            }
+            inv = 1.0 / sqrt(red[0] / (double)T);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            s_mean[c] = mean;
+            s_inv[c] = inv;
+        }
+    }
+    __syncthreads();
+    const int dim_out = n_ceps * (nd + 1);
+    for (int64_t t = tid; t < To; t += 256) {
+        const int64_t tr = t + nd;   // row of the normalised features this output row ends on
+        float *dst = out + (o0 + t) * dim_out;
+        for (int c = 0; c < n_ceps; c++) {
+            const double z0 = ((double)raw[(r0 + tr) * n_ceps + c] - s_mean[c]) * s_inv[c];
+            dst[c] = (float)z0;
+            if (nd >= 1) {
+                const double z1 = ((double)raw[(r0 + tr - 1) * n_ceps + c] - s_mean[c]) * s_inv[c];
+                dst[n_ceps + c] = (float)(z0 - z1);
+                if (nd >= 2) {
+                    const double z2 = ((double)raw[(r0 + tr - 2) * n_ceps + c] - s_mean[c]) * s_inv[c];
+                    dst[2 * n_ceps + c] = (float)((z0 - z1) - (z1 - z2));
+                }
+            }
+        }
+    }
+}
+
+// ---------------- host: device tables + launch ----------------
+
+struct MfccDeviceTables {
+    DevBuf<float> window, mel_val, mel_floor, dct;
+    DevBuf<float2> twiddle;
+    DevBuf<int> mel_row, mel_col;
+    int device = -1;
+};
+
+static MfccDev upload_tables(SRMfcc &m) {
+    if (!m.dev) {
+        auto t = std::make_shared<MfccDeviceTables>();
+        const int L = m.frame_len, NF = m.fft_size, nc = NF / 2, B = m.n_filters, C = m.n_ceps;
+        std::vector<float> w(L), dctf((size_t)C * B), val, floor_ln(B);
+        std::vector<float2> twd(nc);
+        std::vector<int> row(B + 1, 0), col;
+        for (int i = 0; i < L; i++) w[i] = (float)m.window[i];
+        for (size_t i = 0; i < dctf.size(); i++) dctf[i] = (float)m.dct[i];
+        for (int k = 0; k < nc; k++) {
+            const double ang = -2.0 * M_PI * k / NF;
+            twd[k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        }
+        for (int b = 0; b < B; b++) {
+            double rs = 0.0;
+            for (int c = 0; c <= nc; c++) {
+                const double v = m.melbank[(size_t)b * (nc + 1) + c];
+                if (v != 0.0) {
+                    col.push_back(c);
+                    val.push_back((float)v);
+                    rs += v;
+                }
+            }
+            row[b + 1] = (int)col.size();
+            floor_ln[b] = (float)std::log(1e-100 * rs);   // POWER_SPECTRUM_FLOOR, MFCC.py:8,67
+        }
+        if (col.empty()) fail("empty mel filterbank");
+        t->window.upload(w.data(), w.size());
+        t->dct.upload(dctf.data(), dctf.size());
+        t->twiddle.upload(twd.data(), twd.size());
+        t->mel_row.upload(row.data(), row.size());
+        t->mel_col.upload(col.data(), col.size());
+        t->mel_val.upload(val.data(), val.size());
+        t->mel_floor.upload(floor_ln.data(), floor_ln.size());
+        sync_stream();
+        m.dev = t;
+    }
+    auto &t = *std::static_pointer_cast<MfccDeviceTables>(m.dev);
+    MfccDev d;
+    d.window = t.window.p;
+    d.twiddle = t.twiddle.p;
+    d.mel_row = t.mel_row.p;
+    d.mel_col = t.mel_col.p;
+    d.mel_val = t.mel_val.p;
+    d.mel_floor = t.mel_floor.p;
+    d.dct = t.dct.p;
+    d.frame_len = m.frame_len;
+    d.frame_shift = m.frame_shift;
+    d.fft_size = m.fft_size;
+    d.n_filters = m.n_filters;
+    d.n_ceps = m.n_ceps;
+    d.pre_emph = (float)m.pre_emph;
+    return d;
+}
+
+int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples) {
+    if (n_samples <= 5 * (int64_t)m.frame_len) return 0;           // MFCC.py:56 (assert there)
+    return (n_samples - m.frame_len) / m.frame_shift + 1;          // MFCC.py:57
+}
+
+struct MfccWorkspace {
+    DevBuf<float> raw;
+    DevBuf<int64_t> raw_off;
+};
+static MfccWorkspace &mws() {
+    static MfccWorkspace *w = new MfccWorkspace();   // leaked on purpose: no hipFree at exit
+    return *w;
+}
+
+// PCM batch -> feature batch.  `out` is reused when it is large enough (serving loop).
+void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out) {
+    ensure_device();
+    if (pcm.kind != SRBatch::PCM16 && pcm.kind != SRBatch::PCMF32) fail("MFCC needs a PCM batch");
+    if (nd < 0 || nd > 2) fail("delta order must be 0, 1 or 2");
+    const MfccDev dev = upload_tables(m);
+    const int U = pcm.n_utt;
+    std::vector<int64_t> raw_off(U + 1, 0), out_off(U + 1, 0);
+    for (int u = 0; u < U; u++) {
+        const int64_t T = mfcc_num_frames(m, pcm.offsets[u + 1] - pcm.offsets[u]);
+        raw_off[u + 1] = raw_off[u] + T;
+        out_off[u + 1] = out_off[u] + std::max<int64_t>(0, T - nd);
+    }
+    const int64_t NF = raw_off[U];
+    auto &w = mws();
+    w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
+    w.raw_off.upload(raw_off.data(), raw_off.size());
+
+    const bool same_shape = out.kind == SRBatch::FEATURES && out.offsets == out_off &&
+                            out.dim == m.n_ceps * (nd + 1);
+    out.kind = SRBatch::FEATURES;
+    out.n_utt = U;
+    out.dim = m.n_ceps * (nd + 1);
+    out.n_rows = out_off[U];
+    out.data.ensure((size_t)std::max<int64_t>(1, out.n_rows) * out.dim);
+    if (!same_shape) {
+        out.offsets = out_off;
+        out.tile_tables.clear();
+        out.d_offsets.upload(out.offsets.data(), out.offsets.size());
+    }
+
+    if (NF > 0) {
+        const int nc = m.fft_size / 2;
+        const size_t lds = (size_t)nc * sizeof(float2) * (1 + 4 * 2) + 4 * 64 * sizeof(float);
+        const int64_t blocks_needed = (NF + 3) / 4;
+        const int blocks_per_cu = std::max<int>(1, (int)(160 * 1024 / lds));
+        const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx().n_cu * std::min(blocks_per_cu, 8));
+        ScopedKernelTimer t(T_MFCC);
+        if (pcm.kind == SRBatch::PCM16) {
+            auto kern = mfcc_frames_kernel<int16_t>;
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.pcm16.p,
+                               pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+        } else {
+            auto kern = mfcc_frames_kernel<float>;
+            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.data.p,
+                               pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+        }
+        SR_HIP(hipGetLastError());
+    }
+    if (U > 0 && out.n_rows > 0) {
+        ScopedKernelTimer t(T_CMVN);
+        hipLaunchKernelGGL(cmvn_delta_kernel, dim3(U), dim3(256), 0, ctx().stream, w.raw.p,
+                           w.raw_off.p, out.d_offsets.p, m.n_ceps, nd, cmvn, out.data.p);
+        SR_HIP(hipGetLastError());
+    }
+    sync_stream();   // raw_off / out_off host vectors feed async uploads
+}
+
+}  // namespace sr

@@ -1,0 +1,27 @@
+// mfcc.hpp -- MFCC extractor object behind the C ABI handle `SRMfcc *`.
+#pragma once
+
+#include "common.hpp"
+
+#include <memory>
+#include <vector>
+
+struct SRBatch;
+
+// Constants of one extractor, as MFCCExtractor.__init__ builds them
+// (src/feature/MFCC.py:20-41): float64 on the host, fp32 copies on the device.
+struct SRMfcc {
+    double fs = 0, pre_emph = 0;
+    int fft_size = 0, n_filters = 0, n_ceps = 0, frame_len = 0, frame_shift = 0;
+    std::vector<double> window;    // [frame_len]
+    std::vector<double> melbank;   // [n_filters][fft_size/2+1]
+    std::vector<double> dct;       // [n_ceps][n_filters]  (DCT-II rows 1..n_ceps)
+    std::shared_ptr<void> dev;     // device tables, created on first use
+    SRMfcc(double fs, double win_length_ms, double win_shift_ms, int fft_size, int n_filters,
+           int n_ceps, double pre_emph);
+};
+
+namespace sr {
+int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples);
+void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out);
+}  // namespace sr

@@ -1,0 +1,98 @@
+"""Model facade -- mirrors the reference's ``src/gui/interface.py`` (ModelInterface :26-109):
+enroll / train / predict / dump / load with the same meaning.  The speaker set is the
+device-backed ``GMMSetPyGMM`` (the reference's C++ back-end, interface.py:19-23,63-75, is the
+drop-in boundary of this repo; its scikit-learn default is third-party code).
+
+Extensions (all keyword-only, defaults = the reference's behaviour): ``gmm_order``,
+``feature_kwargs`` (forwarded to ``feature.MFCC.extract``), ``diff``/``nd`` (append deltas),
+``gmm_kwargs`` (forwarded to ``pygmm.GMM``), ``ubm`` (MAP-adapt speakers from a UBM).
+VAD (``init_noise`` / ``filter``; third-party pyssp LTSD in the reference) is out of scope.
+"""
+from __future__ import annotations
+
+import pickle
+import sys
+import time
+import traceback as tb
+from collections import defaultdict
+
+import numpy as np
+
+from .feature import mix_feature
+from .gmmset import GMMSetPyGMM as GMMSet
+from .pygmm import GMM
+
+
+class ModelInterface(object):
+
+    UBM_MODEL_FILE = None
+
+    def __init__(self, *, gmm_order=32, feature_kwargs=None, diff=False, nd=1, gmm_kwargs=None,
+                 verbose=True):
+        self.features = defaultdict(list)
+        self.gmm_order = gmm_order
+        self.feature_kwargs = dict(feature_kwargs or {})
+        self.diff, self.nd = diff, nd
+        self.gmm_kwargs = dict(gmm_kwargs or {})
+        self.verbose = verbose
+        self.gmmset = GMMSet(gmm_order=gmm_order, **self.gmm_kwargs)
+
+    def init_noise(self, fs, signal):
+        raise NotImplementedError("VAD (filters/ltsd.py -> third-party pyssp) is outside the "
+                                  "MFCC + GMM hot path this package implements")
+
+    def filter(self, fs, signal):
+        raise NotImplementedError("VAD (filters/VAD.py) is outside the MFCC + GMM hot path")
+
+    def _features(self, fs, signal):
+        return mix_feature((fs, signal), diff=self.diff, nd=self.nd, **self.feature_kwargs)
+
+    def enroll(self, name, fs, signal):
+        """add the signal to this person's training dataset"""
+        feat = self._features(fs, signal)
+        self.features[name].extend(feat)
+
+    def _get_gmm_set(self):
+        import os
+        if self.UBM_MODEL_FILE and os.path.isfile(self.UBM_MODEL_FILE):
+            return GMMSet(ubm=GMM.load(self.UBM_MODEL_FILE), **self.gmm_kwargs)
+        return GMMSet(gmm_order=self.gmm_order, **self.gmm_kwargs)
+
+    def train(self):
+        self.gmmset = self._get_gmm_set()
+        start = time.time()
+        if self.verbose:
+            print("Start training...")
+        for name, feats in self.features.items():
+            self.gmmset.fit_new(np.asarray(feats), name)
+        if self.verbose:
+            print(time.time() - start, " seconds")
+
+    def predict(self, fs, signal):
+        """return a label (name)"""
+        try:
+            feat = self._features(fs, signal)
+        except Exception:
+            print(tb.format_exc(), file=sys.stderr)
+            return None
+        return self.gmmset.predict_one(feat)
+
+    def predict_many(self, items):
+        """Extension: [(fs, signal), ...] -> labels, every utterance scored in one batch."""
+        feats = [self._features(fs, sig) for fs, sig in items]
+        return self.gmmset.predict(feats)
+
+    def dump(self, fname):
+        """ dump all models to file"""
+        self.gmmset.before_pickle()
+        with open(fname, "wb") as f:
+            pickle.dump(self, f, -1)
+        self.gmmset.after_pickle()
+
+    @staticmethod
+    def load(fname):
+        """ load from a dumped model file"""
+        with open(fname, "rb") as f:
+            R = pickle.load(f)
+            R.gmmset.after_pickle()
+            return R

@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library builds for gfx950, loads, exports every symbol the header declares,
+its host-side logic (text format, MFCC tables, frame counts) matches the oracle, and every
+compute entry point fails LOUDLY when no GPU is present (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import mfcc_oracle as mo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pygmm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_symbols_exported(built_lib):
+    from speaker_recognition_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 45
+    for legacy in _lib.LEGACY_SYMBOLS:        # src/gmm/src/pygmm.hh:28-41
+        assert legacy in names
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "lib/pygmm.so does not export %s" % n
+    assert set(_lib.LEGACY_SYMBOLS + _lib.EXT_SYMBOLS) == set(names)
+
+
+def test_parameter_struct_layout():
+    from speaker_recognition_amd._lib import Parameter
+    assert C.sizeof(Parameter) == 48
+    assert Parameter.min_covar.offset == 16 and Parameter.nr_iteration.offset == 32
+
+
+def test_text_format_host_side(built_lib, oracle_built, gmm_golden, tmp_path):
+    from speaker_recognition_amd.pygmm import GMM
+    go, g = oracle_built, gmm_golden
+    p = go.GMMParams(g["syn16x13_w"], g["syn16x13_mean"], g["syn16x13_sigma"])
+    text = go.format_model_text(p)
+    f = tmp_path / "m.model"
+    f.write_text(text)
+    m = GMM.load(str(f))
+    assert m.get_dim() == 13 and m.get_nr_mixtures() == 16
+    w, mu, sg = m.params()
+    assert np.array_equal(w, p.weights) and np.array_equal(mu, p.mean) and np.array_equal(sg, p.sigma)
+    assert m.dumps() == text                      # byte-identical to GMM::dump (gmm.cc:655-662)
+    out = tmp_path / "o.model"
+    m.dump(str(out))
+    assert out.read_text() == text
+    m2 = GMM.loads(text)
+    assert m2.get_nr_mixtures() == 16
+    with pytest.raises(Exception):
+        GMM.load(str(tmp_path / "missing.model"))
+    with pytest.raises(Exception):
+        GMM.loads("3\n0.5 0.5\n")                 # truncated
+
+
+def test_new_gmm_rejects_non_diagonal(built_lib):
+    L = built_lib
+    assert not L.new_gmm(4, 2)                    # gmm.cc:211-215 throws; here: NULL + message
+    assert b"diagonal" in L.sr_last_error()
+    h = L.new_gmm(4, 1)
+    assert h and L.get_nr_mixtures(h) == 4 and L.get_dim(h) == 0
+    L.sr_free_gmm(h)
+
+
+def test_mfcc_tables_match_oracle(built_lib):
+    from speaker_recognition_amd.core import MfccExtractor
+    for fs, kw in ((16000, {}), (8000, {}), (16000, dict(win_length_ms=25, win_shift_ms=10, FFT_SIZE=512, n_filters=40)),
+                   (8000, dict(win_length_ms=25, win_shift_ms=10, FFT_SIZE=256, n_filters=24, n_ceps=12))):
+        ex = MfccExtractor(fs, **kw)
+        ref = mo.get_mfcc_extractor(fs, **kw)
+        assert (ex.FRAME_LEN, ex.FRAME_SHIFT) == (ref.FRAME_LEN, ref.FRAME_SHIFT)
+        win, M, D = ex.tables()
+        assert np.allclose(win, ref.window, rtol=0, atol=1e-15)
+        assert np.array_equal(M != 0, ref.M != 0)
+        assert np.allclose(M, ref.M, rtol=0, atol=1e-12)
+        assert np.allclose(D, ref.D, rtol=0, atol=1e-14)
+        for n in (0, 5 * ref.FRAME_LEN, 5 * ref.FRAME_LEN + 1, 16000, 480000):
+            want = ref.n_frames(n) if n > 5 * ref.FRAME_LEN else 0
+            assert ex.num_frames(n) == want
+
+
+def test_bad_mfcc_parameters_rejected(built_lib):
+    from speaker_recognition_amd._lib import SRError
+    from speaker_recognition_amd.core import MfccExtractor
+    with pytest.raises(SRError):
+        MfccExtractor(16000, FFT_SIZE=1000)
+    with pytest.raises(SRError):
+        MfccExtractor(16000, win_length_ms=200)   # frame longer than the FFT
+
+
+def test_compute_fails_loudly_without_gpu(built_lib, oracle_built, gmm_golden):
+    """No silent CPU path: with no HIP device every compute call raises."""
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.pygmm import GMM
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    g = gmm_golden
+    m = GMM.from_arrays(g["syn5x3_w"], g["syn5x3_mean"], g["syn5x3_sigma"])
+    with pytest.raises(_lib.SRError, match="no HIP device"):
+        m.score(g["syn5x3_X"])
+    with pytest.raises(_lib.SRError):
+        m.fit(g["syn5x3_X"])
+    # legacy symbol: NaN + parked message instead of an exception across the ABI
+    X = np.ascontiguousarray(g["syn5x3_X"])
+    rows = (C.POINTER(C.c_double) * len(X))(*[C.cast(X[i].ctypes.data, C.POINTER(C.c_double)) for i in range(len(X))])
+    v = built_lib.score_all(m.gmm, rows, len(X), X.shape[1], 1)
+    assert np.isnan(v) and b"no HIP device" in built_lib.sr_last_error()

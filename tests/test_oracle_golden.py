@@ -1,0 +1,97 @@
+"""CPU: pins the oracle (oracle/) against the known-answer vectors generated from the
+reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import mfcc_oracle as mo
+
+
+def _params(go, g, c):
+    return go.GMMParams(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"])
+
+
+def test_gmm_oracle_matches_reference_dso(oracle_built, gmm_golden):
+    go, g = oracle_built, gmm_golden
+    for c in g["cases"]:
+        p = _params(go, g, c)
+        ll = go.score_batch(p, g[c + "_X"], go.MODE_FASTEXP)
+        # scalar restatement of the SSE2 polynomial vs the -ffast-math DSO: rounding-order only
+        assert np.max(np.abs(ll - g[c + "_ll"])) < 1e-12, c
+        assert abs(np.sum(ll) - float(g[c + "_sum"])) < 1e-9 * max(1, abs(float(g[c + "_sum"])))
+
+
+def test_gmm_oracle_modes_agree_and_clamp(oracle_built, gmm_golden):
+    go, g = oracle_built, gmm_golden
+    for c in g["cases"]:
+        p = _params(go, g, c)
+        ref = g[c + "_ll"]
+        lse = go.score_batch(p, g[c + "_X"], go.MODE_LOGSUMEXP)
+        libm = go.score_batch(p, g[c + "_X"], go.MODE_LIBM)
+        # remez5 error of the reference's fast exp: <= ~2e-6 absolute
+        assert np.max(np.abs(lse - ref)) < 3e-6, c
+        assert np.max(np.abs(libm - ref)) < 3e-6, c
+        # the two outlier frames underflow -> safe_log floor ln(1e-15) (gmm.cc:34-38)
+        assert np.all(ref[-2:] == go.LN_1E_15) and np.all(lse[-2:] == go.LN_1E_15)
+        true_ll = go.score_batch(p, g[c + "_X"], go.MODE_LOGSUMEXP, clamp_compat=False)
+        assert np.all(true_ll[-2:] < go.MINLOG)
+
+
+def test_model_text_roundtrip(oracle_built, gmm_golden):
+    go, g = oracle_built, gmm_golden
+    p = _params(go, g, "syn16x13")
+    q = go.parse_model_text(go.format_model_text(p))
+    assert q.K == 16 and q.D == 13
+    # synthetic models were generated through the 6-significant-digit format already
+    assert np.array_equal(q.weights, p.weights) and np.array_equal(q.mean, p.mean)
+    assert np.array_equal(q.sigma, p.sigma)
+
+
+def test_em_iteration_increases_likelihood(oracle_built, gmm_golden):
+    go, g = oracle_built, gmm_golden
+    p = _params(go, g, "syn5x3")
+    rng = np.random.default_rng(0)
+    k = rng.choice(p.K, 400, p=p.weights / p.weights.sum())
+    X = p.mean[k] + p.sigma[k] * rng.standard_normal((400, p.D))
+    start = go.GMMParams(np.full(p.K, 1.0 / p.K), p.mean + 0.3, np.ones_like(p.sigma))
+    l0 = go.score_all(start, X, go.MODE_LOGSUMEXP)
+    nxt = go.em_iteration(start, X)
+    l1 = go.score_all(nxt, X, go.MODE_LOGSUMEXP)
+    assert l1 > l0
+    assert abs(nxt.weights.sum() - 1) < 1e-12 and np.all(nxt.sigma >= np.sqrt(1e-3))
+    m = go.em_iteration(start, X, map_relevance=16.0, ubm=start)
+    assert np.array_equal(m.weights, start.weights) and np.array_equal(m.sigma, start.sigma)
+    assert not np.array_equal(m.mean, start.mean)
+
+
+def test_mfcc_oracle_matches_reference(mfcc_golden):
+    m = mfcc_golden
+    assert np.allclose(mo.hamming(4), m["hamming4"], rtol=0, atol=1e-15)
+    assert np.allclose(mo.hamming(4), [0.2147, 0.8653, 0.8653, 0.2147], atol=5e-5)
+    for c in m["cases"]:
+        kw = eval(str(m[c + "_kw"]))
+        fs, pcm = int(m[c + "_fs"]), m[c + "_pcm"]
+        ex = mo.get_mfcc_extractor(fs, **kw)
+        assert np.max(np.abs(ex.raw_cepstra(pcm.astype(float)) - m[c + "_raw"])) < 1e-9, c
+        assert np.max(np.abs(mo.extract(fs, pcm, **kw) - m[c + "_feat"])) < 1e-9, c
+        assert np.max(np.abs(mo.extract(fs, pcm, diff=True, **kw) - m[c + "_d1"])) < 1e-9, c
+        assert np.max(np.abs(mo.extract((fs, pcm), diff=True, nd=2, **kw) - m[c + "_d2"])) < 1e-9, c
+        T = m[c + "_feat"].shape[0]
+        assert m[c + "_d1"].shape == (T - 1, 2 * m[c + "_feat"].shape[1])
+        assert m[c + "_d2"].shape == (T - 2, 3 * m[c + "_feat"].shape[1])
+
+
+def test_mfcc_constants(mfcc_golden):
+    m = mfcc_golden
+    ex = mo.get_mfcc_extractor(16000)
+    assert ex.FRAME_LEN == 512 and ex.FRAME_SHIFT == 256
+    assert np.array_equal(ex.window, m["default16k_window"])
+    assert np.allclose(ex.D, m["default16k_D"], rtol=0, atol=1e-15)
+    r, c = np.nonzero(ex.M)
+    assert np.array_equal(r, m["default16k_M_nnz_rows"]) and np.array_equal(c, m["default16k_M_nnz_cols"])
+    assert len(r) == 1989 and c.min() == 1 and c.max() == 1023
+    assert np.allclose(ex.M[r, c], m["default16k_M_vals"], rtol=0, atol=1e-13)
+
+
+def test_signal_too_short_asserts():
+    with pytest.raises(AssertionError):
+        mo.extract(16000, np.zeros(5 * 512, dtype=np.int16))          # MFCC.py:56
