@@ -152,8 +152,9 @@ int sr_profile_enable(int on);
 int sr_profile_reset(void);
 int sr_profile_get(int kind, double *total_ms, long *launches);
 
-/* Tunables (kernel variant selection for A/B runs): key in {"score_frames_per_lane",
- * "score_model_groups"}; value 0 = automatic. */
+/* Tunables (kernel variant selection for A/B runs); value 0 = automatic:
+ *   "score_frames_per_lane" 1|2|4, "score_model_groups" n, "score_packed" -1 (scalar FMA) | 1 (packed),
+ *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel). */
 int sr_set_option(const char *key, long value);
 
 #ifdef __cplusplus

@@ -32,7 +32,7 @@ def main():
     feats = Batch.from_features(utts)
     n = feats.n_rows
     flops = float(n) * S * K * (4 * D + 6)
-    variants = [(F, pk, G) for F, pk in ((4, 0), (4, 1), (2, 0), (2, 1), (1, 0)) for G in (0, 1, 4)]
+    variants = [(F, pk, G) for F, pk in ((4, -1), (4, 1), (2, -1), (2, 1), (1, 0)) for G in (0, 4)]
     if D > 40:
         variants = [(F, pk, G) for F, pk, G in variants if F <= 2]
     ref = None

@@ -460,6 +460,8 @@ int sr_set_option(const char *key, long value) {
         score_options().model_groups = (int)value;
     } else if (k == "score_packed") {
         score_options().packed = (int)value;
+    } else if (k == "mfcc_generic") {
+        mfcc_set_force_generic(value != 0);
     } else {
         fail("unknown option '%s'", key);
     }

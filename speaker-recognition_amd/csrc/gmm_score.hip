@@ -381,7 +381,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         a.clamp = (flags & 1) ? 1 : 0;
         {
             ScopedKernelTimer t(T_SCORE);
-            dispatch(a, DP, F, score_options().packed != 0 && F >= 2, tt.n_tiles, G);
+            dispatch(a, DP, F, score_options().packed >= 0 && F >= 2, tt.n_tiles, G);
         }
         SR_HIP(hipGetLastError());
         sync_stream();  // gcb (host vector) must outlive its async upload

@@ -97,6 +97,8 @@ struct MfccDev {
     float pre_emph;
 };
 
+bool mfcc_force_generic();
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -247,6 +249,206 @@ void mfcc_frames_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fast path for FFT_SIZE 2048 (the reference's default, MFCC.py:116): the 1024-point complex
+// FFT of the packed frame is done by ONE wave with 16 points per lane in registers --
+//   n = 64 n1 + lane : 16-point DFT over n1 in registers (pruned: a frame of <= 512 samples
+//   fills only n1 < 4), twiddle W_1024^(lane k1), LDS transpose, radix-4 over a (n2 = 16a+b),
+//   twiddle W_64^(bc), LDS transpose, 16-point DFT over b in registers  ->  Z[k1 + 16c + 64d]
+// i.e. three register passes and two LDS exchanges instead of five LDS passes; the waves of a
+// workgroup never synchronise with each other (wave-local LDS slab, wavefront-scope fences).
+// Mel rows are contiguous column runs (melfb.m structure), lane = band; DCT lane = coefficient.
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+// y_r = sum_p x_p (-i)^(p r)
+__device__ __forceinline__ void radix4(float2 a, float2 b, float2 c, float2 d, float2 &y0, float2 &y1,
+                                       float2 &y2, float2 &y3) {
+    const float2 s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = mul_mi(csub(b, d));
+    y0 = cadd(s0, s2);
+    y1 = cadd(s1, s3);
+    y2 = csub(s0, s2);
+    y3 = csub(s1, s3);
+}
+
+// In-register 16-point forward DFT, natural order in and out (4x4 Cooley-Tukey).
+// NZ = number of leading nonzero inputs the caller guarantees (4 or 16).
+template <int NZ>
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, H = 0.70710678118654752440f;
+    float2 u[4][4];   // u[q][r]
+    if constexpr (NZ <= 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) u[q][r] = v[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) radix4(v[q], v[4 + q], v[8 + q], v[12 + q], u[q][0], u[q][1], u[q][2], u[q][3]);
+    }
+    // twiddles W_16^(q r)
+    u[1][1] = cmul(u[1][1], make_float2(C1, -S1));
+    u[1][2] = cmul(u[1][2], make_float2(H, -H));
+    u[1][3] = cmul(u[1][3], make_float2(S1, -C1));
+    u[2][1] = cmul(u[2][1], make_float2(H, -H));
+    u[2][2] = mul_mi(u[2][2]);
+    u[2][3] = cmul(u[2][3], make_float2(-H, -H));
+    u[3][1] = cmul(u[3][1], make_float2(S1, -C1));
+    u[3][2] = cmul(u[3][2], make_float2(-H, -H));
+    u[3][3] = cmul(u[3][3], make_float2(-C1, S1));
+#pragma unroll
+    for (int r = 0; r < 4; r++) radix4(u[0][r], u[1][r], u[2][r], u[3][r], v[r], v[r + 4], v[r + 8], v[r + 12]);
+}
+
+struct MelRuns {
+    const int *col0;       // [n_filters] first column of the row's nonzero run
+    const int *cnt;        // [n_filters] run length
+    const int *row_start;  // [n_filters+1] offset of the run in mel_val
+    int nnz;
+    int max_cnt;
+};
+
+constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
+
+template <typename PcmT, int NZ1>
+__global__ __launch_bounds__(256)
+void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
+                                const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
+                                MfccDev p, MelRuns mr, float *__restrict__ raw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = 1024;
+    float *s_melval = reinterpret_cast<float *>(smem);
+    const int nnz_pad = (mr.nnz + 3) & ~3;
+    float *s_dct = s_melval + nnz_pad;
+    const int dct_pad = (p.n_ceps * p.n_filters + 3) & ~3;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2 *slab = reinterpret_cast<float2 *>(s_dct + dct_pad) + (size_t)wave * WAVE_SLAB_C;
+    float *pbuf = reinterpret_cast<float *>(slab);          // power spectrum, 1025 floats
+    float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
+
+    for (int i = threadIdx.x; i < mr.nnz; i += 256) s_melval[i] = p.mel_val[i];
+    for (int i = threadIdx.x; i < p.n_ceps * p.n_filters; i += 256) s_dct[i] = p.dct[i];
+    __syncthreads();
+
+    // ---- per-lane constants ----
+    float2 wk[16];        // W_1024^(lane*k1)
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(p.twiddle, (2 * lane * k1) & 2047, NC);
+    const int bb = lane & 15, gg = lane >> 4;
+    float2 w64[4];        // W_64^(b*c)
+#pragma unroll
+    for (int c = 0; c < 4; c++) w64[c] = tw(p.twiddle, (32 * bb * c) & 2047, NC);
+    const bool has_band = lane < p.n_filters;
+    const int m_c0 = has_band ? mr.col0[lane] : 0;
+    const int m_cnt = has_band ? mr.cnt[lane] : 0;
+    const int m_rs = has_band ? mr.row_start[lane] : 0;
+    const float m_floor = has_band ? p.mel_floor[lane] : 0.f;
+    const int L = p.frame_len;
+
+    const int64_t frames_per_iter = (int64_t)gridDim.x * 4;
+    for (int64_t frame = (int64_t)blockIdx.x * 4 + wave; frame < n_frames; frame += frames_per_iter) {
+        // frame -> (utterance, local index)
+        int lo = 0, hi = n_utt;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (frame_off[mid] <= frame) lo = mid; else hi = mid;
+        }
+        const int64_t base = sample_off[lo] + (frame - frame_off[lo]) * p.frame_shift;
+
+        // ---- window, pre-emphasis on the windowed samples, pack z[n] = y[2n] + i y[2n+1] ----
+        float2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) {
+            v[n1] = make_float2(0.f, 0.f);
+            if (n1 < NZ1) {
+                const int i0 = 2 * (64 * n1 + lane);
+                if (i0 < L) {
+                    const float c0 = (float)pcm[base + i0] * p.window[i0];
+                    const float pm1 = i0 > 0 ? (float)pcm[base + i0 - 1] * p.window[i0 - 1] : 0.f;
+                    float im = 0.f;
+                    if (i0 + 1 < L) im = (float)pcm[base + i0 + 1] * p.window[i0 + 1] - c0 * p.pre_emph;
+                    v[n1] = make_float2(c0 - pm1 * p.pre_emph, im);
+                }
+            }
+        }
+        // ---- pass 1: 16-point DFT over n1, twiddle, exchange ----
+        dft16<(NZ1 <= 4 ? 4 : 16)>(v);
+#pragma unroll
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], wk[k1]);
+        wave_sync();      // previous frame's readers are done with the slab
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++) slab[k1 * 68 + lane] = v[k1];
+        wave_sync();
+        // ---- pass 2: radix-4 over a for (k1 = 4g+i, b), twiddle W_64^(bc), exchange ----
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float2 *rowp = slab + (4 * gg + i) * 68 + bb;
+            radix4(rowp[0], rowp[16], rowp[32], rowp[48], v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            v[4 * i + 1] = cmul(v[4 * i + 1], w64[1]);
+            v[4 * i + 2] = cmul(v[4 * i + 2], w64[2]);
+            v[4 * i + 3] = cmul(v[4 * i + 3], w64[3]);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) slab[((4 * gg + i) + 16 * c) * 17 + bb] = v[4 * i + c];
+        wave_sync();
+        // ---- pass 3: lane l = k1 + 16c holds C[k1][b][c], b = 0..15 -> Z[l + 64 d] ----
+#pragma unroll
+        for (int b = 0; b < 16; b++) v[b] = slab[lane * 17 + b];
+        dft16<16>(v);
+        wave_sync();
+#pragma unroll
+        for (int d = 0; d < 16; d++) slab[lane + 64 * d] = v[d];
+        wave_sync();
+        // ---- real-FFT untangle + power spectrum (MFCC.py:66): bins lane + 64 j, and bin 1024 ----
+        float pw[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int k = lane + 64 * j;
+            const float2 zk = slab[k];
+            const float2 zr = slab[(NC - k) & (NC - 1)];
+            const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
+            const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
+            const float2 xo = cmul(p.twiddle[k], o);
+            const float xr = e.x + xo.x, xi = e.y + xo.y;
+            pw[j] = xr * xr + xi * xi;
+        }
+        const float2 z0 = slab[0];
+        const float nyq = (z0.x - z0.y) * (z0.x - z0.y);       // X[1024] = Re Z0 - Im Z0
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) pbuf[lane + 64 * j] = pw[j];
+        if (lane == 0) pbuf[NC] = nyq;
+        wave_sync();
+        // ---- mel filterbank: lane = band, contiguous run of columns; ln (MFCC.py:67-69) ----
+        float acc = 0.f;
+        for (int i = 0; i < mr.max_cnt; i++)
+            if (i < m_cnt) acc = fmaf(s_melval[m_rs + i], pbuf[m_c0 + i], acc);
+        const float lm = acc > 0.f ? logf(acc) : m_floor;
+        wave_sync();
+        s_lm[lane] = lm;
+        wave_sync();
+        // ---- DCT-II rows 1..n_ceps: lane = coefficient ----
+        if (lane < p.n_ceps) {
+            float o = 0.f;
+            const float *drow = s_dct + lane * p.n_filters;
+            for (int b = 0; b < p.n_filters; b++) o = fmaf(drow[b], s_lm[b], o);
+            raw[frame * p.n_ceps + lane] = o;
+        }
+    }
+}
+
 // Per-utterance CMVN (mean, population std, no epsilon -- MFCC.py:74-77) and causal
 // first-difference deltas AFTER the normalisation (utils.py:24-31).  Statistics in float64.
 __global__ __launch_bounds__(256)
@@ -261,51 +463,59 @@ void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict_
     __shared__ double red[256];
     __shared__ double s_mean[64], s_inv[64];
     const int tid = threadIdx.x;
-    for (int c = 0; c < n_ceps; c++) {
-        double mean = 0.0, inv = 1.0;
-        if (cmvn && T > 1) {
-            double acc = 0.0;
-            for (int64_t t = tid; t < T; t += 256) acc += (double)raw[(r0 + t) * n_ceps + c];
-            red[tid] = acc;
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (tid < w) red[tid] += red[tid + w];
-                __syncthreads();
-            }
-            mean = red[0] / (double)T;
-            __syncthreads();
-            acc = 0.0;
-            for (int64_t t = tid; t < T; t += 256) {
-                const double dv = (double)raw[(r0 + t) * n_ceps + c] - mean;
-                acc += dv * dv;
-            }
-            red[tid] = acc;
-            __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (tid < w) red[tid] += red[tid + w];
-                __syncthreads();
-            }
-            inv = 1.0 / sqrt(red[0] / (double)T);
-            __syncthreads();
-        }
-        if (tid == 0) {
-            s_mean[c] = mean;
-            s_inv[c] = inv;
-        }
+    // thread = (stripe of frames, coefficient): consecutive threads read consecutive floats
+    const int cp = n_ceps <= 16 ? 16 : n_ceps <= 32 ? 32 : 64;
+    const int n_stripes = 256 / cp;
+    const int c = tid & (cp - 1);
+    const int stripe = tid / cp;
+    const bool live = c < n_ceps;
+    if (tid < 64) {
+        s_mean[tid] = 0.0;
+        s_inv[tid] = 1.0;
     }
     __syncthreads();
+    if (cmvn && T > 1) {
+        double acc = 0.0;
+        if (live)
+            for (int64_t t = stripe; t < T; t += n_stripes) acc += (double)raw[(r0 + t) * n_ceps + c];
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < cp) {
+            double tot = 0.0;
+            for (int s = 0; s < n_stripes; s++) tot += red[s * cp + tid];
+            s_mean[tid] = tot / (double)T;
+        }
+        __syncthreads();
+        acc = 0.0;
+        if (live) {
+            const double mu = s_mean[c];
+            for (int64_t t = stripe; t < T; t += n_stripes) {
+                const double dv = (double)raw[(r0 + t) * n_ceps + c] - mu;
+                acc += dv * dv;
+            }
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (tid < cp) {
+            double tot = 0.0;
+            for (int s = 0; s < n_stripes; s++) tot += red[s * cp + tid];
+            s_inv[tid] = 1.0 / sqrt(tot / (double)T);      // no epsilon, as the reference
+        }
+        __syncthreads();
+    }
     const int dim_out = n_ceps * (nd + 1);
-    for (int64_t t = tid; t < To; t += 256) {
-        const int64_t tr = t + nd;   // row of the normalised features this output row ends on
-        float *dst = out + (o0 + t) * dim_out;
-        for (int c = 0; c < n_ceps; c++) {
-            const double z0 = ((double)raw[(r0 + tr) * n_ceps + c] - s_mean[c]) * s_inv[c];
+    if (live) {
+        const double mu = s_mean[c], inv = s_inv[c];
+        for (int64_t t = stripe; t < To; t += n_stripes) {
+            const int64_t tr = t + nd;   // row of the normalised features this output row ends on
+            float *dst = out + (o0 + t) * dim_out;
+            const double z0 = ((double)raw[(r0 + tr) * n_ceps + c] - mu) * inv;
             dst[c] = (float)z0;
             if (nd >= 1) {
-                const double z1 = ((double)raw[(r0 + tr - 1) * n_ceps + c] - s_mean[c]) * s_inv[c];
+                const double z1 = ((double)raw[(r0 + tr - 1) * n_ceps + c] - mu) * inv;
                 dst[n_ceps + c] = (float)(z0 - z1);
                 if (nd >= 2) {
-                    const double z2 = ((double)raw[(r0 + tr - 2) * n_ceps + c] - s_mean[c]) * s_inv[c];
+                    const double z2 = ((double)raw[(r0 + tr - 2) * n_ceps + c] - mu) * inv;
                     dst[2 * n_ceps + c] = (float)((z0 - z1) - (z1 - z2));
                 }
             }
@@ -318,8 +528,10 @@ void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict_
 struct MfccDeviceTables {
     DevBuf<float> window, mel_val, mel_floor, dct;
     DevBuf<float2> twiddle;
-    DevBuf<int> mel_row, mel_col;
+    DevBuf<int> mel_row, mel_col, mel_col0, mel_cnt;
     int device = -1;
+    int nnz = 0, max_cnt = 0;
+    bool runs_contiguous = true;
 };
 
 static MfccDev upload_tables(SRMfcc &m) {
@@ -328,7 +540,7 @@ static MfccDev upload_tables(SRMfcc &m) {
         const int L = m.frame_len, NF = m.fft_size, nc = NF / 2, B = m.n_filters, C = m.n_ceps;
         std::vector<float> w(L), dctf((size_t)C * B), val, floor_ln(B);
         std::vector<float2> twd(nc);
-        std::vector<int> row(B + 1, 0), col;
+        std::vector<int> row(B + 1, 0), col, col0(B, 0), cnt(B, 0);
         for (int i = 0; i < L; i++) w[i] = (float)m.window[i];
         for (size_t i = 0; i < dctf.size(); i++) dctf[i] = (float)m.dct[i];
         for (int k = 0; k < nc; k++) {
@@ -346,6 +558,10 @@ static MfccDev upload_tables(SRMfcc &m) {
                 }
             }
             row[b + 1] = (int)col.size();
+            cnt[b] = row[b + 1] - row[b];
+            col0[b] = cnt[b] ? col[row[b]] : 0;
+            if (cnt[b] && col[row[b + 1] - 1] - col0[b] + 1 != cnt[b]) t->runs_contiguous = false;
+            t->max_cnt = std::max(t->max_cnt, cnt[b]);
             floor_ln[b] = (float)std::log(1e-100 * rs);   // POWER_SPECTRUM_FLOOR, MFCC.py:8,67
         }
         if (col.empty()) fail("empty mel filterbank");
@@ -356,6 +572,9 @@ static MfccDev upload_tables(SRMfcc &m) {
         t->mel_col.upload(col.data(), col.size());
         t->mel_val.upload(val.data(), val.size());
         t->mel_floor.upload(floor_ln.data(), floor_ln.size());
+        t->mel_col0.upload(col0.data(), col0.size());
+        t->mel_cnt.upload(cnt.data(), cnt.size());
+        t->nnz = (int)col.size();
         sync_stream();
         m.dev = t;
     }
@@ -381,6 +600,13 @@ int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples) {
     if (n_samples <= 5 * (int64_t)m.frame_len) return 0;           // MFCC.py:56 (assert there)
     return (n_samples - m.frame_len) / m.frame_shift + 1;          // MFCC.py:57
 }
+
+static bool &mfcc_force_generic_flag() {
+    static bool f = false;
+    return f;
+}
+bool mfcc_force_generic() { return mfcc_force_generic_flag(); }
+void mfcc_set_force_generic(bool on) { mfcc_force_generic_flag() = on; }
 
 struct MfccWorkspace {
     DevBuf<float> raw;
@@ -423,24 +649,55 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     }
 
     if (NF > 0) {
-        const int nc = m.fft_size / 2;
-        const size_t lds = (size_t)nc * sizeof(float2) * (1 + 4 * 2) + 4 * 64 * sizeof(float);
-        const int64_t blocks_needed = (NF + 3) / 4;
-        const int blocks_per_cu = std::max<int>(1, (int)(160 * 1024 / lds));
-        const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx().n_cu * std::min(blocks_per_cu, 8));
+        auto &tabs = *std::static_pointer_cast<MfccDeviceTables>(m.dev);
+        const bool fast = m.fft_size == 2048 && tabs.runs_contiguous && !mfcc_force_generic();
         ScopedKernelTimer t(T_MFCC);
-        if (pcm.kind == SRBatch::PCM16) {
-            auto kern = mfcc_frames_kernel<int16_t>;
-            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.pcm16.p,
-                               pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+        if (fast) {
+            MelRuns mr;
+            mr.col0 = tabs.mel_col0.p;
+            mr.cnt = tabs.mel_cnt.p;
+            mr.row_start = tabs.mel_row.p;
+            mr.nnz = tabs.nnz;
+            mr.max_cnt = tabs.max_cnt;
+            const size_t lds = (size_t)(((tabs.nnz + 3) & ~3) + ((m.n_ceps * m.n_filters + 3) & ~3)) * sizeof(float) +
+                               (size_t)4 * WAVE_SLAB_C * sizeof(float2);
+            const int64_t blocks_needed = (NF + 3) / 4;
+            const int blocks_per_cu = std::max<int>(1, std::min<int>(8, (int)(160 * 1024 / lds)));
+            const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx().n_cu * blocks_per_cu);
+            const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
+#define SR_LAUNCH_FAST(PT, NZ, PCMPTR)                                                              \
+    do {                                                                                             \
+        auto kern = mfcc_frames_fft2048_kernel<PT, NZ>;                                              \
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, PCMPTR, pcm.d_offsets.p,  \
+                           w.raw_off.p, U, NF, dev, mr, w.raw.p);                                    \
+    } while (0)
+            if (pcm.kind == SRBatch::PCM16) {
+                if (nz1 <= 4) SR_LAUNCH_FAST(int16_t, 4, pcm.pcm16.p); else SR_LAUNCH_FAST(int16_t, 16, pcm.pcm16.p);
+            } else {
+                if (nz1 <= 4) SR_LAUNCH_FAST(float, 4, pcm.data.p); else SR_LAUNCH_FAST(float, 16, pcm.data.p);
+            }
+#undef SR_LAUNCH_FAST
         } else {
-            auto kern = mfcc_frames_kernel<float>;
-            SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.data.p,
-                               pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+            const int nc = m.fft_size / 2;
+            const size_t lds = (size_t)nc * sizeof(float2) * (1 + 4 * 2) + 4 * 64 * sizeof(float);
+            const int64_t blocks_needed = (NF + 3) / 4;
+            const int blocks_per_cu = std::max<int>(1, (int)(160 * 1024 / lds));
+            const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx().n_cu * std::min(blocks_per_cu, 8));
+            if (pcm.kind == SRBatch::PCM16) {
+                auto kern = mfcc_frames_kernel<int16_t>;
+                SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.pcm16.p,
+                                   pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+            } else {
+                auto kern = mfcc_frames_kernel<float>;
+                SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.data.p,
+                                   pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+            }
         }
         SR_HIP(hipGetLastError());
     }

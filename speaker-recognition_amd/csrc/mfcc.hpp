@@ -24,4 +24,5 @@ struct SRMfcc {
 namespace sr {
 int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples);
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out);
+void mfcc_set_force_generic(bool on);   // A/B: route FFT_SIZE 2048 through the generic LDS kernel
 }  // namespace sr

@@ -9,7 +9,7 @@ namespace sr {
 struct ScoreOptions {
     int frames_per_lane = 0;   // 0 = auto; 1, 2 or 4 frames resident per lane
     int model_groups = 0;      // 0 = auto; workgroups per frame tile along the model axis
-    int packed = 0;            // 1 = v_pk_fma_f32 variant (two frames per VGPR pair)
+    int packed = 0;            // -1 = scalar v_fma_f32; 0 (auto) / 1 = v_pk_fma_f32, two frames per VGPR pair
 };
 ScoreOptions &score_options();
 

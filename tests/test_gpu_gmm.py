@@ -21,7 +21,7 @@ def _gmm(g, c):
 def _reset_options(built_lib):
     from speaker_recognition_amd import _lib
     yield
-    for k in ("score_frames_per_lane", "score_model_groups", "score_packed"):
+    for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "mfcc_generic"):
         _lib.set_option(k, 0)
 
 
@@ -33,7 +33,7 @@ def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
     for c in g["cases"]:
         m = _gmm(g, c)
         ref = g[c + "_ll"]
-        for F, pk in ((0, 0), (1, 0), (2, 0), (4, 0), (2, 1), (4, 1)):
+        for F, pk in ((0, 0), (1, 0), (2, -1), (4, -1), (2, 1), (4, 1)):
             _lib.set_option("score_frames_per_lane", F)
             _lib.set_option("score_packed", pk)
             ll = m.score(g[c + "_X"])
@@ -88,7 +88,7 @@ def test_speaker_set_ragged_batch_vs_oracle(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X.astype(np.float64)) for m in models])
     off = np.concatenate([[0], np.cumsum(lens)])
     want_sums = np.array([[want[s, off[u]:off[u + 1]].sum() for s in range(S)] for u in range(len(lens))])
-    for F, pk, G in ((0, 0, 0), (1, 0, 1), (2, 0, 3), (4, 0, 7), (4, 1, 2), (2, 1, 0)):
+    for F, pk, G in ((0, 0, 0), (1, 0, 1), (2, -1, 3), (4, -1, 7), (4, 1, 2), (2, 1, 0)):
         _lib.set_option("score_frames_per_lane", F)
         _lib.set_option("score_packed", pk)
         _lib.set_option("score_model_groups", G)

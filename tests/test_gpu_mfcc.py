@@ -7,9 +7,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden):
+@pytest.mark.parametrize("generic", [0, 1])
+def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden, generic):
+    """generic=0: register-resident FFT-2048 kernel where it applies; generic=1: LDS-pass kernel."""
+    from speaker_recognition_amd import _lib
     from speaker_recognition_amd.core import Batch, MfccExtractor
     from speaker_recognition_amd.feature import MFCC
+    _lib.set_option("mfcc_generic", generic)
     m = mfcc_golden
     for c in m["cases"]:
         kw = eval(str(m[c + "_kw"]))
@@ -27,6 +31,7 @@ def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden):
         d2 = MFCC.extract(fs, pcm, diff=True, nd=2, **kw)
         assert d1.shape == m[c + "_d1"].shape and d2.shape == m[c + "_d2"].shape
         assert np.max(np.abs(d1 - m[c + "_d1"])) < 1e-3 and np.max(np.abs(d2 - m[c + "_d2"])) < 2e-3
+    _lib.set_option("mfcc_generic", 0)
 
 
 def test_ragged_batch_vs_oracle(built_lib):
