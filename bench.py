@@ -156,11 +156,12 @@ def main():
                    "frames_per_gpu": n_frames, "speakers": N_MODELS, "mixtures": N_MIX, "dim": DIM,
                    "sharding": "utterances/%d ranks, models replicated, no collective" % world},
         "roofline": {
-            "kernel": "gmm_score_kernel<39,F>",
+            "kernel": "gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32; auto-selected engine)",
             "bound": "mfma",
-            "note": "fp32 FMA-issue bound on the vector ALU (no MFMA used): the fp32 vector peak and the "
-                    "dense fp32 MFMA peak are the same 157.3 TFLOP/s; arithmetic intensity "
-                    "S*K*(4D+6)/(4D) = %.0f flop/B, so HBM cannot be the bound" % (flops_per_launch / bytes_per_launch),
+            "note": "compute-bound: arithmetic intensity S*K*(4D+6)/(4D) = %.0f flop/B vs machine balance ~20, so "
+                    "HBM cannot be the bound; peak = dense fp32 MFMA = fp32 vector peak = 157.3 TFLOP/s; flops are "
+                    "the algorithmic S*K*(4D+6) per frame (the kernel issues 2*32*(2D+2) per 32 mixtures, 1.3%% more)"
+                    % (flops_per_launch / bytes_per_launch),
             "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved_tf / FP32_PEAK_TFLOPS,
             "traffic": traffic,

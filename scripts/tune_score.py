@@ -32,16 +32,19 @@ def main():
     feats = Batch.from_features(utts)
     n = feats.n_rows
     flops = float(n) * S * K * (4 * D + 6)
-    variants = [(F, pk, G) for F, pk in ((4, -1), (4, 1), (2, -1), (2, 1), (1, 0)) for G in (0, 4)]
+    # (frames per lane | -FT for the matrix-core engine, packed, groups)
+    variants = [(4, 1, 0), (4, -1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0), (-2, 0, 1), (-3, 0, 0), (-4, 0, 0)]
     if D > 40:
-        variants = [(F, pk, G) for F, pk, G in variants if F <= 2]
+        variants = [v for v in variants if v[0] <= 2 and v[0] >= -3]
     ref = None
     res = {v: [] for v in variants}
     _lib.profile_enable(True)
     for r in range(rounds + 1):
         for v in variants:
             F, pk, G = v
-            _lib.set_option("score_frames_per_lane", F)
+            _lib.set_option("score_engine", 2 if F < 0 else 1)
+            _lib.set_option("score_mfma_ft", -F if F < 0 else 0)
+            _lib.set_option("score_frames_per_lane", F if F > 0 else 0)
             _lib.set_option("score_packed", pk)
             _lib.set_option("score_model_groups", G)
             _lib.profile_reset()

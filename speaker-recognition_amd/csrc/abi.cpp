@@ -52,6 +52,7 @@ static SRModelSet &single_set(GMM *g) {
     if (!g->single || g->single->device != ctx().device) {
         auto s = std::make_shared<SRModelSet>();
         s->host = pack_models({g});
+        s->mfma = pack_models_mfma({g}, s->host.dp);
         upload_model_set(*s);
         g->single = s;
     }
@@ -296,6 +297,7 @@ SRModelSet *sr_modelset_create(GMM *const *models, int n_models) {
         if (!m) fail("null GMM handle in model list");
     auto s = std::make_unique<SRModelSet>();
     s->host = pack_models(v);
+    s->mfma = pack_models_mfma(v, s->host.dp);
     upload_model_set(*s);
     return s.release();
     SR_CATCH(nullptr)
@@ -460,6 +462,12 @@ int sr_set_option(const char *key, long value) {
         score_options().model_groups = (int)value;
     } else if (k == "score_packed") {
         score_options().packed = (int)value;
+    } else if (k == "score_engine") {
+        if (value < 0 || value > 2) fail("score_engine must be 0 (auto), 1 (vector ALU) or 2 (matrix cores)");
+        score_options().engine = (int)value;
+    } else if (k == "score_mfma_ft") {
+        if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");
+        score_options().mfma_ft = (int)value;
     } else if (k == "mfcc_generic") {
         mfcc_set_force_generic(value != 0);
     } else {

@@ -74,7 +74,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                       const float4 *__restrict__ params, const ChunkDesc *__restrict__ chunks,
                       const int *__restrict__ group_chunk_begin, double *__restrict__ partial,
                       float *__restrict__ frame_ll, int64_t n_frames, int dim, int n_models,
-                      int clamp) {
+                      int clamp, int n_groups, int n_tiles) {
     using L = Lanes<PK>;
     using XT = typename L::T;
     constexpr int W = L::W;
@@ -92,8 +92,15 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileDesc tile = tiles[blockIdx.x];
-    const int g = blockIdx.y;
+    // XCD-aware 1-D grid: workgroup b runs on XCD b % 8 (observed dispatch order, speed only), so
+    // the G workgroups that share a frame tile are given ids 8 apart: same XCD, same L2, adjacent
+    // in dispatch order -> the tile's rows leave HBM / the fabric once instead of G times.
+    const int tile_lo = blockIdx.x & 7;
+    const int q = blockIdx.x >> 3;
+    const int g = q % n_groups;
+    const int tile_id = (q / n_groups) * 8 + tile_lo;
+    if (tile_id >= n_tiles) return;              // padding workgroups (whole workgroup, before any barrier)
+    const TileDesc tile = tiles[tile_id];
     const int chunk_begin = group_chunk_begin[g];
     const int chunk_end = group_chunk_begin[g + 1];
 
@@ -202,7 +209,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-            if (lane == 0) partial[((int64_t)blockIdx.x * n_models + s) * 4 + wave] = mine;
+            if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
         __syncthreads();
     };
@@ -277,10 +284,10 @@ static ScoreWorkspace &ws() {
 
 template <int DP, int F, bool PK>
 static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
-    dim3 grid((unsigned)n_tiles, (unsigned)n_groups);
+    dim3 grid((unsigned)((int64_t)n_groups * ((n_tiles + 7) / 8) * 8));   // 1-D, XCD-aware order
     hipLaunchKernelGGL((gmm_score_kernel<DP, F, PK>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        a.params, a.chunks, a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames,
-                       a.dim, a.n_models, a.clamp);
+                       a.dim, a.n_models, a.clamp, n_groups, n_tiles);
 }
 
 template <int DP>
@@ -334,6 +341,16 @@ void upload_model_set(SRModelSet &s) {
     s.device = ctx().device;
 }
 
+// The expanded-form (matrix-core) layout is packed lazily: only sets that take that engine pay.
+static void ensure_mfma_layout(SRModelSet &s, const std::vector<const GMM *> *models) {
+    (void)models;
+    if (s.d_mfma_params.p) return;
+    s.d_mfma_params.upload(s.mfma.params.data(), s.mfma.params.size());
+    s.d_mfma_chunks.upload(s.mfma.chunks.data(), s.mfma.chunks.size());
+    s.d_center.upload(s.mfma.center.data(), s.mfma.center.size());
+    sync_stream();
+}
+
 ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags) {
     ensure_device();
     if (feat.kind != SRBatch::FEATURES) fail("scoring needs a feature batch");
@@ -341,10 +358,22 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         fail("feature dim %d != model dim %d", feat.dim, set.host.dim);
     const int S = set.host.n_models;
     const int DP = set.host.dp;
-    int F = score_options().frames_per_lane ? score_options().frames_per_lane
-                                            : auto_frames_per_lane(feat, DP);
+    const ScoreOptions &opt = score_options();
+    // engine choice (see score.hpp): the matrix-core kernel when its layout exists, is well
+    // conditioned and not mostly padding; the vector-ALU kernel otherwise or when forced
+    const bool mfma_ok = !set.mfma.params.empty();
+    bool use_mfma = false;
+    if (opt.engine == 2) {
+        if (!mfma_ok) fail("matrix-core engine requested but the set has no expanded-form layout");
+        use_mfma = true;
+    } else if (opt.engine == 0) {
+        use_mfma = mfma_ok && set.mfma.amp <= MFMA_MAX_AMP && set.mfma.pad_waste <= MFMA_MAX_PAD_WASTE;
+    }
+    int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
-    TileTable &tt = feat.tiles_for(256 * F);
+    int FT = opt.mfma_ft ? opt.mfma_ft : 2;
+    if (DP > 40 && FT > 3) FT = 3;
+    TileTable &tt = feat.tiles_for(use_mfma ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
@@ -352,36 +381,56 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     w.argmax.ensure((size_t)std::max(1, U));
     if (tt.n_tiles > 0) {
         // model groups: enough workgroups to fill the chip several times over
-        int G = score_options().model_groups;
+        int G = opt.model_groups;
         if (G <= 0) {
             const int target = ctx().n_cu * 2 * 6;
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
         G = std::max(1, std::min(G, S));
+        const std::vector<int> &mcb = use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
         std::vector<int> gcb(G + 1);
         for (int g = 0; g <= G; g++) {
             const int model = (int)(((int64_t)g * S) / G);
-            gcb[g] = set.host.model_chunk_begin[model];
+            gcb[g] = mcb[model];
         }
         w.group_chunk_begin.upload(gcb.data(), gcb.size());
         w.partial.ensure((size_t)tt.n_tiles * S * 4);
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
-        ScoreArgs a;
-        a.X = feat.data.p;
-        a.tiles = tt.d_tiles.p;
-        a.params = reinterpret_cast<const float4 *>(set.d_params.p);
-        a.chunks = set.d_chunks.p;
-        a.group_chunk_begin = w.group_chunk_begin.p;
-        a.partial = w.partial.p;
-        a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
-        a.n_frames = feat.n_rows;
-        a.dim = feat.dim;
-        a.n_models = S;
-        a.clamp = (flags & 1) ? 1 : 0;
-        {
+        if (use_mfma) {
+            ensure_mfma_layout(set, nullptr);
+            MfmaLaunch a;
+            a.X = feat.data.p;
+            a.tiles = tt.d_tiles.p;
+            a.params = reinterpret_cast<const float4 *>(set.d_mfma_params.p);
+            a.chunks = set.d_mfma_chunks.p;
+            a.group_chunk_begin = w.group_chunk_begin.p;
+            a.center = set.d_center.p;
+            a.partial = w.partial.p;
+            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.n_frames = feat.n_rows;
+            a.dim = feat.dim;
+            a.n_models = S;
+            a.clamp = (flags & 1) ? 1 : 0;
+            a.n_groups = G;
+            a.n_tiles = tt.n_tiles;
             ScopedKernelTimer t(T_SCORE);
-            dispatch(a, DP, F, score_options().packed >= 0 && F >= 2, tt.n_tiles, G);
+            launch_score_mfma(a, DP, FT);
+        } else {
+            ScoreArgs a;
+            a.X = feat.data.p;
+            a.tiles = tt.d_tiles.p;
+            a.params = reinterpret_cast<const float4 *>(set.d_params.p);
+            a.chunks = set.d_chunks.p;
+            a.group_chunk_begin = w.group_chunk_begin.p;
+            a.partial = w.partial.p;
+            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.n_frames = feat.n_rows;
+            a.dim = feat.dim;
+            a.n_models = S;
+            a.clamp = (flags & 1) ? 1 : 0;
+            ScopedKernelTimer t(T_SCORE);
+            dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
         }
         SR_HIP(hipGetLastError());
         sync_stream();  // gcb (host vector) must outlive its async upload

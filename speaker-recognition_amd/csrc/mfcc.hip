@@ -313,19 +313,24 @@ struct MelRuns {
     const int *cnt;        // [n_filters] run length
     const int *row_start;  // [n_filters+1] offset of the run in mel_val
     int nnz;
-    int max_cnt;
+    int pass_iters[4];     // per pass of 16 bands: ceil(max run length / 4)
 };
 
 constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
 
+// One wave = one contiguous range of frames (binary search for the utterance once, then walk);
+// per-lane constants (window taps, pass-1/2 twiddles) live in registers, the untangle twiddles
+// and the mel / DCT tables in LDS; the next frame's samples are prefetched while the current
+// frame is transformed.
 template <typename PcmT, int NZ1>
 __global__ __launch_bounds__(256)
 void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
                                 const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
-                                MfccDev p, MelRuns mr, float *__restrict__ raw) {
+                                int64_t frames_per_wave, MfccDev p, MelRuns mr, float *__restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NC = 1024;
-    float *s_melval = reinterpret_cast<float *>(smem);
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_2048^k, k < 1024
+    float *s_melval = reinterpret_cast<float *>(s_tw + NC);
     const int nnz_pad = (mr.nnz + 3) & ~3;
     float *s_dct = s_melval + nnz_pad;
     const int dct_pad = (p.n_ceps * p.n_filters + 3) & ~3;
@@ -335,6 +340,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float *pbuf = reinterpret_cast<float *>(slab);          // power spectrum, 1025 floats
     float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
 
+    for (int i = threadIdx.x; i < NC; i += 256) s_tw[i] = p.twiddle[i];
     for (int i = threadIdx.x; i < mr.nnz; i += 256) s_melval[i] = p.mel_val[i];
     for (int i = threadIdx.x; i < p.n_ceps * p.n_filters; i += 256) s_dct[i] = p.dct[i];
     __syncthreads();
@@ -342,43 +348,83 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     // ---- per-lane constants ----
     float2 wk[16];        // W_1024^(lane*k1)
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(p.twiddle, (2 * lane * k1) & 2047, NC);
+    for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(s_tw, (2 * lane * k1) & 2047, NC);
     const int bb = lane & 15, gg = lane >> 4;
     float2 w64[4];        // W_64^(b*c)
 #pragma unroll
-    for (int c = 0; c < 4; c++) w64[c] = tw(p.twiddle, (32 * bb * c) & 2047, NC);
-    const bool has_band = lane < p.n_filters;
-    const int m_c0 = has_band ? mr.col0[lane] : 0;
-    const int m_cnt = has_band ? mr.cnt[lane] : 0;
-    const int m_rs = has_band ? mr.row_start[lane] : 0;
-    const float m_floor = has_band ? p.mel_floor[lane] : 0.f;
+    for (int c = 0; c < 4; c++) w64[c] = tw(s_tw, (32 * bb * c) & 2047, NC);
     const int L = p.frame_len;
+    // window taps of this lane's samples: y[i0] = w0 x[i0] - wm x[i0-1], y[i0+1] = w1 x[i0+1] - w0p x[i0]
+    float win_m[NZ1], win_0[NZ1], win_1[NZ1], win_0p[NZ1];
+#pragma unroll
+    for (int n1 = 0; n1 < NZ1; n1++) {
+        const int i0 = 2 * (64 * n1 + lane);
+        win_0[n1] = i0 < L ? p.window[i0] : 0.f;
+        win_m[n1] = (i0 > 0 && i0 < L) ? p.window[i0 - 1] * p.pre_emph : 0.f;
+        win_1[n1] = i0 + 1 < L ? p.window[i0 + 1] : 0.f;
+        win_0p[n1] = i0 + 1 < L ? win_0[n1] * p.pre_emph : 0.f;
+    }
+    // mel: 4 lanes per band, 16 bands per pass
+    const int m_part = lane & 3, m_bl = lane >> 2;
+    int m_c0[4], m_cnt[4], m_rs[4];
+    float m_floor[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ps++) {
+        const int band = 16 * ps + m_bl;
+        const bool ok = band < p.n_filters;
+        m_c0[ps] = ok ? mr.col0[band] : 0;
+        m_cnt[ps] = ok ? mr.cnt[band] : 0;
+        m_rs[ps] = ok ? mr.row_start[band] : 0;
+        m_floor[ps] = ok ? p.mel_floor[band] : 0.f;
+    }
 
-    const int64_t frames_per_iter = (int64_t)gridDim.x * 4;
-    for (int64_t frame = (int64_t)blockIdx.x * 4 + wave; frame < n_frames; frame += frames_per_iter) {
-        // frame -> (utterance, local index)
-        int lo = 0, hi = n_utt;
+    const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t f_begin = gwave * frames_per_wave;
+    const int64_t f_end = f_begin + frames_per_wave < n_frames ? f_begin + frames_per_wave : n_frames;
+    if (f_begin >= f_end) return;      // whole wave idle (no workgroup barrier below this point)
+
+    int utt = 0;
+    {
+        int lo = 0, hi = n_utt;        // frame_off[lo] <= f_begin < frame_off[hi]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (frame_off[mid] <= frame) lo = mid; else hi = mid;
+            if (frame_off[mid] <= f_begin) lo = mid; else hi = mid;
         }
-        const int64_t base = sample_off[lo] + (frame - frame_off[lo]) * p.frame_shift;
+        utt = lo;
+    }
+    int64_t utt_f0 = frame_off[utt], utt_f1 = frame_off[utt + 1], utt_s0 = sample_off[utt];
 
-        // ---- window, pre-emphasis on the windowed samples, pack z[n] = y[2n] + i y[2n+1] ----
+    // sample fetch for one frame: three taps per row (previous, even, odd sample)
+    auto fetch = [&](int64_t base, float (&xm)[NZ1], float (&x0)[NZ1], float (&x1)[NZ1]) {
+#pragma unroll
+        for (int n1 = 0; n1 < NZ1; n1++) {
+            const int i0 = 2 * (64 * n1 + lane);
+            x0[n1] = i0 < L ? (float)pcm[base + i0] : 0.f;
+            xm[n1] = (i0 > 0 && i0 < L) ? (float)pcm[base + i0 - 1] : 0.f;
+            x1[n1] = i0 + 1 < L ? (float)pcm[base + i0 + 1] : 0.f;
+        }
+    };
+    float cm[NZ1], c0[NZ1], c1[NZ1];
+    fetch(utt_s0 + (f_begin - utt_f0) * p.frame_shift, cm, c0, c1);
+
+    for (int64_t frame = f_begin; frame < f_end; frame++) {
+        // ---- window + pre-emphasis on the windowed samples (MFCC.py:61-64), packed z = y[2n] + i y[2n+1] ----
         float2 v[16];
 #pragma unroll
-        for (int n1 = 0; n1 < 16; n1++) {
-            v[n1] = make_float2(0.f, 0.f);
-            if (n1 < NZ1) {
-                const int i0 = 2 * (64 * n1 + lane);
-                if (i0 < L) {
-                    const float c0 = (float)pcm[base + i0] * p.window[i0];
-                    const float pm1 = i0 > 0 ? (float)pcm[base + i0 - 1] * p.window[i0 - 1] : 0.f;
-                    float im = 0.f;
-                    if (i0 + 1 < L) im = (float)pcm[base + i0 + 1] * p.window[i0 + 1] - c0 * p.pre_emph;
-                    v[n1] = make_float2(c0 - pm1 * p.pre_emph, im);
-                }
+        for (int n1 = 0; n1 < 16; n1++) v[n1] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int n1 = 0; n1 < NZ1; n1++)
+            v[n1] = make_float2(win_0[n1] * c0[n1] - win_m[n1] * cm[n1], win_1[n1] * c1[n1] - win_0p[n1] * c0[n1]);
+        // ---- prefetch the next frame's samples (in flight during the transform) ----
+        if (frame + 1 < f_end) {
+            int64_t nf = frame + 1;
+            while (nf >= utt_f1) {     // utterances with zero frames are skipped
+                utt++;
+                utt_f0 = utt_f1;
+                utt_f1 = frame_off[utt + 1];
+                utt_s0 = sample_off[utt];
             }
+            fetch(utt_s0 + (nf - utt_f0) * p.frame_shift, cm, c0, c1);
         }
         // ---- pass 1: 16-point DFT over n1, twiddle, exchange ----
         dft16<(NZ1 <= 4 ? 4 : 16)>(v);
@@ -420,7 +466,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             const float2 zr = slab[(NC - k) & (NC - 1)];
             const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
             const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
-            const float2 xo = cmul(p.twiddle[k], o);
+            const float2 xo = cmul(s_tw[k], o);
             const float xr = e.x + xo.x, xi = e.y + xo.y;
             pw[j] = xr * xr + xi * xi;
         }
@@ -431,20 +477,60 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         for (int j = 0; j < 16; j++) pbuf[lane + 64 * j] = pw[j];
         if (lane == 0) pbuf[NC] = nyq;
         wave_sync();
-        // ---- mel filterbank: lane = band, contiguous run of columns; ln (MFCC.py:67-69) ----
-        float acc = 0.f;
-        for (int i = 0; i < mr.max_cnt; i++)
-            if (i < m_cnt) acc = fmaf(s_melval[m_rs + i], pbuf[m_c0 + i], acc);
-        const float lm = acc > 0.f ? logf(acc) : m_floor;
+        // ---- mel filterbank (MFCC.py:67-69): 4 lanes sweep one band's column run, 16 bands per pass ----
+        float lm[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            // unconditional (clamped) loads so that a whole batch of LDS reads is in flight at once
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const int last = m_cnt[ps] > 0 ? m_cnt[ps] - 1 : 0;
+            const float *mv = s_melval + m_rs[ps];
+            const float *pp = pbuf + m_c0[ps];
+            for (int it = 0; it < mr.pass_iters[ps]; it += 4) {
+                const int i0 = 4 * it + m_part, i1 = i0 + 4, i2 = i0 + 8, i3 = i0 + 12;
+                const int j0 = i0 < last ? i0 : last, j1 = i1 < last ? i1 : last;
+                const int j2 = i2 < last ? i2 : last, j3 = i3 < last ? i3 : last;
+                const float w0 = mv[j0], w1 = mv[j1], w2 = mv[j2], w3 = mv[j3];
+                const float x0 = pp[j0], x1 = pp[j1], x2 = pp[j2], x3 = pp[j3];
+                a0 = fmaf(i0 < m_cnt[ps] ? w0 : 0.f, x0, a0);
+                a1 = fmaf(i1 < m_cnt[ps] ? w1 : 0.f, x1, a1);
+                a2 = fmaf(i2 < m_cnt[ps] ? w2 : 0.f, x2, a2);
+                a3 = fmaf(i3 < m_cnt[ps] ? w3 : 0.f, x3, a3);
+            }
+            float acc = (a0 + a1) + (a2 + a3);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            lm[ps] = acc > 0.f ? logf(acc) : m_floor[ps];
+        }
         wave_sync();
-        s_lm[lane] = lm;
+        if (m_part == 0) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ps++) s_lm[16 * ps + m_bl] = lm[ps];
+        }
         wave_sync();
-        // ---- DCT-II rows 1..n_ceps: lane = coefficient ----
-        if (lane < p.n_ceps) {
+        // ---- DCT-II rows 1..n_ceps: 4 lanes per coefficient ----
+        {
+            const int cidx = lane >> 2;
             float o = 0.f;
-            const float *drow = s_dct + lane * p.n_filters;
-            for (int b = 0; b < p.n_filters; b++) o = fmaf(drow[b], s_lm[b], o);
-            raw[frame * p.n_ceps + lane] = o;
+            if (cidx < p.n_ceps) {
+                const float *drow = s_dct + cidx * p.n_filters;
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                const int nb = p.n_filters, lastb = nb - 1;
+                for (int b = m_part; b < nb; b += 16) {
+                    const int b1 = b + 4, b2 = b + 8, b3 = b + 12;
+                    const int c1 = b1 < lastb ? b1 : lastb, c2 = b2 < lastb ? b2 : lastb, c3 = b3 < lastb ? b3 : lastb;
+                    const float d0 = drow[b], d1 = drow[c1], d2 = drow[c2], d3 = drow[c3];
+                    const float l0 = s_lm[b], l1 = s_lm[c1], l2 = s_lm[c2], l3 = s_lm[c3];
+                    o0 = fmaf(d0, l0, o0);
+                    o1 = fmaf(b1 < nb ? d1 : 0.f, l1, o1);
+                    o2 = fmaf(b2 < nb ? d2 : 0.f, l2, o2);
+                    o3 = fmaf(b3 < nb ? d3 : 0.f, l3, o3);
+                }
+                o = (o0 + o1) + (o2 + o3);
+            }
+            o += __shfl_xor(o, 1, 64);
+            o += __shfl_xor(o, 2, 64);
+            if (m_part == 0 && cidx < p.n_ceps) raw[frame * p.n_ceps + cidx] = o;
         }
     }
 }
@@ -531,6 +617,7 @@ struct MfccDeviceTables {
     DevBuf<int> mel_row, mel_col, mel_col0, mel_cnt;
     int device = -1;
     int nnz = 0, max_cnt = 0;
+    int pass_iters[4] = {0, 0, 0, 0};
     bool runs_contiguous = true;
 };
 
@@ -562,6 +649,7 @@ static MfccDev upload_tables(SRMfcc &m) {
             col0[b] = cnt[b] ? col[row[b]] : 0;
             if (cnt[b] && col[row[b + 1] - 1] - col0[b] + 1 != cnt[b]) t->runs_contiguous = false;
             t->max_cnt = std::max(t->max_cnt, cnt[b]);
+            t->pass_iters[b / 16] = std::max(t->pass_iters[b / 16], (cnt[b] + 3) / 4);
             floor_ln[b] = (float)std::log(1e-100 * rs);   // POWER_SPECTRUM_FLOOR, MFCC.py:8,67
         }
         if (col.empty()) fail("empty mel filterbank");
@@ -658,12 +746,16 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
             mr.cnt = tabs.mel_cnt.p;
             mr.row_start = tabs.mel_row.p;
             mr.nnz = tabs.nnz;
-            mr.max_cnt = tabs.max_cnt;
-            const size_t lds = (size_t)(((tabs.nnz + 3) & ~3) + ((m.n_ceps * m.n_filters + 3) & ~3)) * sizeof(float) +
+            for (int ps = 0; ps < 4; ps++) mr.pass_iters[ps] = tabs.pass_iters[ps];
+            const size_t lds = (size_t)1024 * sizeof(float2) +
+                               (size_t)(((tabs.nnz + 3) & ~3) + ((m.n_ceps * m.n_filters + 3) & ~3)) * sizeof(float) +
                                (size_t)4 * WAVE_SLAB_C * sizeof(float2);
-            const int64_t blocks_needed = (NF + 3) / 4;
-            const int blocks_per_cu = std::max<int>(1, std::min<int>(8, (int)(160 * 1024 / lds)));
-            const int grid = (int)std::min<int64_t>(blocks_needed, (int64_t)ctx().n_cu * blocks_per_cu);
+            // one contiguous frame range per wave; enough waves to fill the chip a few times over
+            const int blocks_per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
+            const int64_t max_waves = (int64_t)ctx().n_cu * blocks_per_cu * 4 * 4;
+            const int64_t frames_per_wave = std::max<int64_t>(8, (NF + max_waves - 1) / max_waves);
+            const int64_t n_waves = (NF + frames_per_wave - 1) / frames_per_wave;
+            const int grid = (int)((n_waves + 3) / 4);
             const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
 #define SR_LAUNCH_FAST(PT, NZ, PCMPTR)                                                              \
     do {                                                                                             \
@@ -671,7 +763,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, PCMPTR, pcm.d_offsets.p,  \
-                           w.raw_off.p, U, NF, dev, mr, w.raw.p);                                    \
+                           w.raw_off.p, U, NF, frames_per_wave, dev, mr, w.raw.p);                   \
     } while (0)
             if (pcm.kind == SRBatch::PCM16) {
                 if (nz1 <= 4) SR_LAUNCH_FAST(int16_t, 4, pcm.pcm16.p); else SR_LAUNCH_FAST(int16_t, 16, pcm.pcm16.p);

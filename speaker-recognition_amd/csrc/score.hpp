@@ -10,7 +10,28 @@ struct ScoreOptions {
     int frames_per_lane = 0;   // 0 = auto; 1, 2 or 4 frames resident per lane
     int model_groups = 0;      // 0 = auto; workgroups per frame tile along the model axis
     int packed = 0;            // -1 = scalar v_fma_f32; 0 (auto) / 1 = v_pk_fma_f32, two frames per VGPR pair
+    int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel
+    int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernel (0 = auto)
 };
+
+// The matrix-core engine is used when the expanded form is well conditioned in fp32 and the
+// 32-mixture tiles are not mostly padding.
+constexpr double MFMA_MAX_AMP = 2000.0;      // max_k sum_d (mu'_d/sigma_d)^2
+constexpr double MFMA_MAX_PAD_WASTE = 0.25;
+
+struct MfmaLaunch {
+    const float *X;
+    const TileDesc *tiles;
+    const float4 *params;
+    const ChunkDesc *chunks;
+    const int *group_chunk_begin;
+    const float *center;
+    double *partial;
+    float *frame_ll;
+    int64_t n_frames;
+    int dim, n_models, clamp, n_groups, n_tiles;
+};
+void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
 ScoreOptions &score_options();
 
 // Device-resident results of the last scoring call (valid until the next one).

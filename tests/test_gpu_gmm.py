@@ -21,7 +21,7 @@ def _gmm(g, c):
 def _reset_options(built_lib):
     from speaker_recognition_amd import _lib
     yield
-    for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "mfcc_generic"):
+    for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic"):
         _lib.set_option(k, 0)
 
 
@@ -33,11 +33,14 @@ def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
     for c in g["cases"]:
         m = _gmm(g, c)
         ref = g[c + "_ll"]
-        for F, pk in ((0, 0), (1, 0), (2, -1), (4, -1), (2, 1), (4, 1)):
+        for F, pk, eng, ft in ((0, 0, 1, 0), (1, 0, 1, 0), (2, -1, 1, 0), (4, -1, 1, 0), (2, 1, 1, 0), (4, 1, 1, 0),
+                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 0, 0)):
             _lib.set_option("score_frames_per_lane", F)
             _lib.set_option("score_packed", pk)
+            _lib.set_option("score_engine", eng)      # 1: vector-ALU kernel, 2: matrix-core kernel, 0: auto
+            _lib.set_option("score_mfma_ft", ft)
             ll = m.score(g[c + "_X"])
-            assert ll_close(ll, ref) < TOL, (c, F, pk, ll_close(ll, ref))
+            assert ll_close(ll, ref) < TOL, (c, F, pk, eng, ft, ll_close(ll, ref))
             # the two outlier frames hit the reference's underflow clamp exactly (gmm.cc:34-38)
             assert np.all(ll[-2:] == np.float32(np.log(1e-15)))
             s = m.score_all(g[c + "_X"])
@@ -88,18 +91,20 @@ def test_speaker_set_ragged_batch_vs_oracle(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X.astype(np.float64)) for m in models])
     off = np.concatenate([[0], np.cumsum(lens)])
     want_sums = np.array([[want[s, off[u]:off[u + 1]].sum() for s in range(S)] for u in range(len(lens))])
-    for F, pk, G in ((0, 0, 0), (1, 0, 1), (2, -1, 3), (4, -1, 7), (4, 1, 2), (2, 1, 0)):
+    for F, pk, G, eng in ((0, 0, 0, 1), (1, 0, 1, 1), (2, -1, 3, 1), (4, -1, 7, 1), (4, 1, 2, 1), (2, 1, 0, 1),
+                          (0, 0, 0, 2), (0, 0, 3, 2), (0, 0, 0, 0)):
         _lib.set_option("score_frames_per_lane", F)
         _lib.set_option("score_packed", pk)
         _lib.set_option("score_model_groups", G)
+        _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
-        assert ll_close(fll, want) < TOL, (F, pk, G)
+        assert ll_close(fll, want) < TOL, (F, pk, G, eng, ll_close(fll, want))
         for u, n in enumerate(lens):
             if n == 0:
                 assert arg[u] == -1 and np.all(sums[u] == 0)
             else:
                 assert np.max(np.abs(sums[u] - want_sums[u])) < 2e-5 * n * 60, (u, F)
-                assert arg[u] == int(np.argmax(want_sums[u])), (u, F, pk, G)
+                assert arg[u] == int(np.argmax(want_sums[u])), (u, F, pk, G, eng)
 
 
 def test_argmax_first_maximum_wins(built_lib):
