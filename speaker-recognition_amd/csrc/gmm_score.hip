@@ -383,7 +383,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // model groups: enough workgroups to fill the chip several times over
         int G = opt.model_groups;
         if (G <= 0) {
-            const int target = ctx().n_cu * 2 * 6;
+            const int target = ctx().n_cu * 3 * 16;   // >= ~16 rounds of resident workgroups: short tail
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
         G = std::max(1, std::min(G, S));

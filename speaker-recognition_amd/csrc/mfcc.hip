@@ -308,12 +308,16 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int r = 0; r < 4; r++) radix4(u[0][r], u[1][r], u[2][r], u[3][r], v[r], v[r + 4], v[r + 8], v[r + 12]);
 }
 
+// Mel rows are contiguous column runs; for the fast kernel they are re-laid as 4 passes x 16 bands,
+// every run of a pass zero-padded to the same multiple of 16 columns, so that 4 lanes sweep a band
+// with plain (unclamped) reads; element i of band b sits at pass_base[pass] + (i/4)*64 + (b%16)*4 + i%4,
+// i.e. one sweep step of all 64 lanes reads 64 consecutive floats (bank-conflict free).
 struct MelRuns {
-    const int *col0;       // [n_filters] first column of the row's nonzero run
-    const int *cnt;        // [n_filters] run length
-    const int *row_start;  // [n_filters+1] offset of the run in mel_val
-    int nnz;
-    int pass_iters[4];     // per pass of 16 bands: ceil(max run length / 4)
+    const int *col0;        // [64] first column of the band's run (0 for absent bands)
+    const float *pad_val;   // padded weights
+    int pad_floats;         // total floats in pad_val
+    int pass_base[4];       // float offset of each pass
+    int pass_len[4];        // padded run length of the pass (multiple of 16)
 };
 
 constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
@@ -331,9 +335,9 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     constexpr int NC = 1024;
     float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_2048^k, k < 1024
     float *s_melval = reinterpret_cast<float *>(s_tw + NC);
-    const int nnz_pad = (mr.nnz + 3) & ~3;
-    float *s_dct = s_melval + nnz_pad;
-    const int dct_pad = (p.n_ceps * p.n_filters + 3) & ~3;
+    float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
+    constexpr int DCT_LD = 64;
+    const int dct_pad = 16 * DCT_LD;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float2 *slab = reinterpret_cast<float2 *>(s_dct + dct_pad) + (size_t)wave * WAVE_SLAB_C;
@@ -341,8 +345,11 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
 
     for (int i = threadIdx.x; i < NC; i += 256) s_tw[i] = p.twiddle[i];
-    for (int i = threadIdx.x; i < mr.nnz; i += 256) s_melval[i] = p.mel_val[i];
-    for (int i = threadIdx.x; i < p.n_ceps * p.n_filters; i += 256) s_dct[i] = p.dct[i];
+    for (int i = threadIdx.x; i < mr.pad_floats; i += 256) s_melval[i] = mr.pad_val[i];
+    for (int i = threadIdx.x; i < 16 * DCT_LD; i += 256) {
+        const int c = i / DCT_LD, b = i - c * DCT_LD;
+        s_dct[i] = (c < p.n_ceps && b < p.n_filters) ? p.dct[c * p.n_filters + b] : 0.f;
+    }
     __syncthreads();
 
     // ---- per-lane constants ----
@@ -366,16 +373,13 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     }
     // mel: 4 lanes per band, 16 bands per pass
     const int m_part = lane & 3, m_bl = lane >> 2;
-    int m_c0[4], m_cnt[4], m_rs[4];
+    int m_c0[4];
     float m_floor[4];
 #pragma unroll
     for (int ps = 0; ps < 4; ps++) {
         const int band = 16 * ps + m_bl;
-        const bool ok = band < p.n_filters;
-        m_c0[ps] = ok ? mr.col0[band] : 0;
-        m_cnt[ps] = ok ? mr.cnt[band] : 0;
-        m_rs[ps] = ok ? mr.row_start[band] : 0;
-        m_floor[ps] = ok ? p.mel_floor[band] : 0.f;
+        m_c0[ps] = mr.col0[band];
+        m_floor[ps] = band < p.n_filters ? p.mel_floor[band] : 0.f;
     }
 
     const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
@@ -394,14 +398,26 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     }
     int64_t utt_f0 = frame_off[utt], utt_f1 = frame_off[utt + 1], utt_s0 = sample_off[utt];
 
-    // sample fetch for one frame: three taps per row (previous, even, odd sample)
+    // Sample fetch for one frame: three taps per row (previous, even, odd sample).  Addresses are
+    // clamped into the frame, never predicated: out-of-frame taps carry a zero window weight, and
+    // all loads of a frame are in flight together (a predicated load forces a wait each).
+    int off_m[NZ1], off_0[NZ1], off_1[NZ1];
+#pragma unroll
+    for (int n1 = 0; n1 < NZ1; n1++) {
+        const int i0 = 2 * (64 * n1 + lane);
+        off_0[n1] = i0 < L ? i0 : L - 1;
+        off_m[n1] = i0 - 1 < 0 ? 0 : (i0 - 1 < L ? i0 - 1 : L - 1);
+        off_1[n1] = i0 + 1 < L ? i0 + 1 : L - 1;
+    }
+    // (held as float: a 32-bit register per tap, so the prefetched samples are not re-packed --
+    // packing would put a wait right behind the loads instead of one iteration later)
     auto fetch = [&](int64_t base, float (&xm)[NZ1], float (&x0)[NZ1], float (&x1)[NZ1]) {
+        const PcmT *fp = pcm + base;
 #pragma unroll
         for (int n1 = 0; n1 < NZ1; n1++) {
-            const int i0 = 2 * (64 * n1 + lane);
-            x0[n1] = i0 < L ? (float)pcm[base + i0] : 0.f;
-            xm[n1] = (i0 > 0 && i0 < L) ? (float)pcm[base + i0 - 1] : 0.f;
-            x1[n1] = i0 + 1 < L ? (float)pcm[base + i0 + 1] : 0.f;
+            x0[n1] = (float)fp[off_0[n1]];
+            xm[n1] = (float)fp[off_m[n1]];
+            x1[n1] = (float)fp[off_1[n1]];
         }
     };
     float cm[NZ1], c0[NZ1], c1[NZ1];
@@ -414,7 +430,8 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         for (int n1 = 0; n1 < 16; n1++) v[n1] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int n1 = 0; n1 < NZ1; n1++)
-            v[n1] = make_float2(win_0[n1] * c0[n1] - win_m[n1] * cm[n1], win_1[n1] * c1[n1] - win_0p[n1] * c0[n1]);
+            v[n1] = make_float2(win_0[n1] * (float)c0[n1] - win_m[n1] * (float)cm[n1],
+                                win_1[n1] * (float)c1[n1] - win_0p[n1] * (float)c0[n1]);
         // ---- prefetch the next frame's samples (in flight during the transform) ----
         if (frame + 1 < f_end) {
             int64_t nf = frame + 1;
@@ -481,21 +498,15 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         float lm[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
-            // unconditional (clamped) loads so that a whole batch of LDS reads is in flight at once
+            const int len = mr.pass_len[ps];
+            const float *mv = s_melval + mr.pass_base[ps] + lane;     // step-major: 64 consecutive floats per step
+            const float *pp = pbuf + m_c0[ps] + m_part;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            const int last = m_cnt[ps] > 0 ? m_cnt[ps] - 1 : 0;
-            const float *mv = s_melval + m_rs[ps];
-            const float *pp = pbuf + m_c0[ps];
-            for (int it = 0; it < mr.pass_iters[ps]; it += 4) {
-                const int i0 = 4 * it + m_part, i1 = i0 + 4, i2 = i0 + 8, i3 = i0 + 12;
-                const int j0 = i0 < last ? i0 : last, j1 = i1 < last ? i1 : last;
-                const int j2 = i2 < last ? i2 : last, j3 = i3 < last ? i3 : last;
-                const float w0 = mv[j0], w1 = mv[j1], w2 = mv[j2], w3 = mv[j3];
-                const float x0 = pp[j0], x1 = pp[j1], x2 = pp[j2], x3 = pp[j3];
-                a0 = fmaf(i0 < m_cnt[ps] ? w0 : 0.f, x0, a0);
-                a1 = fmaf(i1 < m_cnt[ps] ? w1 : 0.f, x1, a1);
-                a2 = fmaf(i2 < m_cnt[ps] ? w2 : 0.f, x2, a2);
-                a3 = fmaf(i3 < m_cnt[ps] ? w3 : 0.f, x3, a3);
+            for (int i = 0; i < len; i += 16) {     // zero-padded runs: no bounds logic in the loop
+                a0 = fmaf(mv[16 * i], pp[i], a0);
+                a1 = fmaf(mv[16 * i + 64], pp[i + 4], a1);
+                a2 = fmaf(mv[16 * i + 128], pp[i + 8], a2);
+                a3 = fmaf(mv[16 * i + 192], pp[i + 12], a3);
             }
             float acc = (a0 + a1) + (a2 + a3);
             acc += __shfl_xor(acc, 1, 64);
@@ -508,26 +519,18 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             for (int ps = 0; ps < 4; ps++) s_lm[16 * ps + m_bl] = lm[ps];
         }
         wave_sync();
-        // ---- DCT-II rows 1..n_ceps: 4 lanes per coefficient ----
+        // ---- DCT-II rows 1..n_ceps: 4 lanes per coefficient, zero-padded table [16][64] ----
         {
             const int cidx = lane >> 2;
-            float o = 0.f;
-            if (cidx < p.n_ceps) {
-                const float *drow = s_dct + cidx * p.n_filters;
-                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-                const int nb = p.n_filters, lastb = nb - 1;
-                for (int b = m_part; b < nb; b += 16) {
-                    const int b1 = b + 4, b2 = b + 8, b3 = b + 12;
-                    const int c1 = b1 < lastb ? b1 : lastb, c2 = b2 < lastb ? b2 : lastb, c3 = b3 < lastb ? b3 : lastb;
-                    const float d0 = drow[b], d1 = drow[c1], d2 = drow[c2], d3 = drow[c3];
-                    const float l0 = s_lm[b], l1 = s_lm[c1], l2 = s_lm[c2], l3 = s_lm[c3];
-                    o0 = fmaf(d0, l0, o0);
-                    o1 = fmaf(b1 < nb ? d1 : 0.f, l1, o1);
-                    o2 = fmaf(b2 < nb ? d2 : 0.f, l2, o2);
-                    o3 = fmaf(b3 < nb ? d3 : 0.f, l3, o3);
-                }
-                o = (o0 + o1) + (o2 + o3);
+            const float *drow = s_dct + cidx * DCT_LD + m_part;
+            const float *lp = s_lm + m_part;
+            float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 64; b += 8) {
+                o0 = fmaf(drow[b], lp[b], o0);
+                o1 = fmaf(drow[b + 4], lp[b + 4], o1);
             }
+            float o = o0 + o1;
             o += __shfl_xor(o, 1, 64);
             o += __shfl_xor(o, 2, 64);
             if (m_part == 0 && cidx < p.n_ceps) raw[frame * p.n_ceps + cidx] = o;
@@ -615,9 +618,10 @@ struct MfccDeviceTables {
     DevBuf<float> window, mel_val, mel_floor, dct;
     DevBuf<float2> twiddle;
     DevBuf<int> mel_row, mel_col, mel_col0, mel_cnt;
+    DevBuf<float> mel_pad;
     int device = -1;
     int nnz = 0, max_cnt = 0;
-    int pass_iters[4] = {0, 0, 0, 0};
+    int pass_base[4] = {0, 0, 0, 0}, pass_len[4] = {0, 0, 0, 0}, pad_floats = 0;
     bool runs_contiguous = true;
 };
 
@@ -627,7 +631,7 @@ static MfccDev upload_tables(SRMfcc &m) {
         const int L = m.frame_len, NF = m.fft_size, nc = NF / 2, B = m.n_filters, C = m.n_ceps;
         std::vector<float> w(L), dctf((size_t)C * B), val, floor_ln(B);
         std::vector<float2> twd(nc);
-        std::vector<int> row(B + 1, 0), col, col0(B, 0), cnt(B, 0);
+        std::vector<int> row(B + 1, 0), col, col0(64, 0), cnt(64, 0);
         for (int i = 0; i < L; i++) w[i] = (float)m.window[i];
         for (size_t i = 0; i < dctf.size(); i++) dctf[i] = (float)m.dct[i];
         for (int k = 0; k < nc; k++) {
@@ -649,7 +653,7 @@ static MfccDev upload_tables(SRMfcc &m) {
             col0[b] = cnt[b] ? col[row[b]] : 0;
             if (cnt[b] && col[row[b + 1] - 1] - col0[b] + 1 != cnt[b]) t->runs_contiguous = false;
             t->max_cnt = std::max(t->max_cnt, cnt[b]);
-            t->pass_iters[b / 16] = std::max(t->pass_iters[b / 16], (cnt[b] + 3) / 4);
+            t->pass_len[b / 16] = std::max(t->pass_len[b / 16], ((cnt[b] + 15) / 16) * 16);
             floor_ln[b] = (float)std::log(1e-100 * rs);   // POWER_SPECTRUM_FLOOR, MFCC.py:8,67
         }
         if (col.empty()) fail("empty mel filterbank");
@@ -660,6 +664,21 @@ static MfccDev upload_tables(SRMfcc &m) {
         t->mel_col.upload(col.data(), col.size());
         t->mel_val.upload(val.data(), val.size());
         t->mel_floor.upload(floor_ln.data(), floor_ln.size());
+        // padded re-layout for the fast kernel: pass ps holds bands 16ps..16ps+15, runs padded to pass_len
+        int total = 0;
+        for (int ps = 0; ps < 4; ps++) {
+            t->pass_base[ps] = total;
+            total += 16 * t->pass_len[ps];
+        }
+        t->pad_floats = (total + 3) & ~3;
+        std::vector<float> padv((size_t)std::max(4, t->pad_floats), 0.0f);
+        for (int b = 0; b < B; b++) {
+            const int ps = b / 16, bl = b % 16;
+            for (int i = 0; i < cnt[b]; i++)
+                padv[(size_t)t->pass_base[ps] + (size_t)(i >> 2) * 64 + (size_t)bl * 4 + (i & 3)] = val[row[b] + i];
+            if (col0[b] + t->pass_len[ps] + 3 > 1100) t->runs_contiguous = false;   // padded sweep must stay inside the slab's power-spectrum region
+        }
+        t->mel_pad.upload(padv.data(), padv.size());
         t->mel_col0.upload(col0.data(), col0.size());
         t->mel_cnt.upload(cnt.data(), cnt.size());
         t->nnz = (int)col.size();
@@ -738,17 +757,19 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
 
     if (NF > 0) {
         auto &tabs = *std::static_pointer_cast<MfccDeviceTables>(m.dev);
-        const bool fast = m.fft_size == 2048 && tabs.runs_contiguous && !mfcc_force_generic();
+        const bool fast = m.fft_size == 2048 && tabs.runs_contiguous && m.n_ceps <= 16 && !mfcc_force_generic();
         ScopedKernelTimer t(T_MFCC);
         if (fast) {
             MelRuns mr;
             mr.col0 = tabs.mel_col0.p;
-            mr.cnt = tabs.mel_cnt.p;
-            mr.row_start = tabs.mel_row.p;
-            mr.nnz = tabs.nnz;
-            for (int ps = 0; ps < 4; ps++) mr.pass_iters[ps] = tabs.pass_iters[ps];
+            mr.pad_val = tabs.mel_pad.p;
+            mr.pad_floats = tabs.pad_floats;
+            for (int ps = 0; ps < 4; ps++) {
+                mr.pass_base[ps] = tabs.pass_base[ps];
+                mr.pass_len[ps] = tabs.pass_len[ps];
+            }
             const size_t lds = (size_t)1024 * sizeof(float2) +
-                               (size_t)(((tabs.nnz + 3) & ~3) + ((m.n_ceps * m.n_filters + 3) & ~3)) * sizeof(float) +
+                               (size_t)(tabs.pad_floats + 16 * 64) * sizeof(float) +
                                (size_t)4 * WAVE_SLAB_C * sizeof(float2);
             // one contiguous frame range per wave; enough waves to fill the chip a few times over
             const int blocks_per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
