@@ -14,6 +14,7 @@
 // two ds_read_b128 feed 8*F FMAs.  The log-sum-exp is online per lane, in the log2 domain
 // (v_exp_f32 / v_log_f32 are base-2).  No MFMA: the 2-FMA distance form is not a contraction.
 #include "score.hpp"
+#include "wave_ops.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -207,8 +208,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                 m[f] = NEG_BIG;
                 ssum[f] = 0.0f;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+            mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
         __syncthreads();

@@ -18,6 +18,7 @@
 // utterance.  The accumulator layout puts a frame's 16 mixture rows in one lane, so the online
 // log-sum-exp is lane-local; the two half-waves (other 16 rows) merge once per model.
 #include "score.hpp"
+#include "wave_ops.hpp"
 
 #include <algorithm>
 
@@ -118,16 +119,19 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
         for (int t = 0; t < cd.n_records; t++) {
             const float4 *at = cur + t * TILE_F4 + lane;
             f32x16 acc[FT];
-#pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[ft][r] = 0.0f;
+            // A fragments are fetched one step ahead of the MFMAs that consume them.  The first MFMA
+            // of each chain takes a constant-zero C operand (an inline constant in the ISA) instead
+            // of 16 zeroed VGPRs: vector-ALU instructions issued next to an MFMA stream delay its
+            // issue (measured with scripts/ubench/mfma_f32_lse.hip), so every v_mov saved counts.
+            const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            float4 a_nxt = at[0];
 #pragma unroll
             for (int kq = 0; kq < KQ; kq++) {
-                const float4 a = at[kq * 64];
+                const float4 a = a_nxt;
+                if (kq + 1 < KQ) a_nxt = at[(kq + 1) * 64];
 #pragma unroll
                 for (int ft = 0; ft < FT; ft++) {
-                    acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[ft][4 * kq + 0], acc[ft], 0, 0, 0);
+                    acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, breg[ft][4 * kq + 0], kq == 0 ? zero16 : acc[ft], 0, 0, 0);
                     acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, breg[ft][4 * kq + 1], acc[ft], 0, 0, 0);
                     acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, breg[ft][4 * kq + 2], acc[ft], 0, 0, 0);
                     acc[ft] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, breg[ft][4 * kq + 3], acc[ft], 0, 0, 0);
@@ -154,8 +158,8 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
 #pragma unroll
             for (int ft = 0; ft < FT; ft++) {
                 // merge the two half-waves (the other 16 mixture rows of the same frame)
-                const float om = __shfl_xor(m[ft], 32, 64);
-                const float os = __shfl_xor(ssum[ft], 32, 64);
+                const float om = other_half(m[ft]);
+                const float os = other_half(ssum[ft]);
                 const float mn = fmaxf(m[ft], om);
                 const float tot = ssum[ft] * __builtin_amdgcn_exp2f(m[ft] - mn) +
                                   os * __builtin_amdgcn_exp2f(om - mn);
@@ -168,8 +172,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
                 m[ft] = NEG_BIG;
                 ssum[ft] = 0.0f;
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+            mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
         __syncthreads();
