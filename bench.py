@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--utts", type=int, default=N_UTT, help="utterances per GPU (default: the cfg-1 size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-utts", type=int, default=12)
+    ap.add_argument("--device-override", type=int, default=-1,
+                    help="testing only: put every rank on this device (N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +91,7 @@ def main():
     from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
     from speaker_recognition_amd.pygmm import GMM
 
-    _lib.set_device(local_rank)
+    _lib.set_device(local_rank if args.device_override < 0 else args.device_override)
     clips, models = build_workload(rank, args.utts, FRAMES_PER_UTT)
     pcm = Batch.from_pcm(clips)                           # resident in HBM before the timed region
     ex = MfccExtractor(FS, **MFCC_KW)

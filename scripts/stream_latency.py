@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] (streaming): 8 kHz audio in 1 s windows -> MFCC (reference defaults: 32/16 ms,
+FFT 2048, 13 ceps) -> CMVN -> 256-mixture speaker GMMs -> decision.  Measures the host-observed
+decision latency per window (H2D of the window + 4 kernels + D2H of the result, synchronous) and the
+throughput when many independent streams are batched.  VAD (third-party LTSD in the reference) is not
+part of this path."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speaker_recognition_amd import _lib, synth  # noqa: E402
+from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet  # noqa: E402
+from speaker_recognition_amd.pygmm import GMM  # noqa: E402
+
+
+def main():
+    fs, n_speakers, K = 8000, int(os.environ.get("STREAM_S", 20)), 256
+    ex = MfccExtractor(fs)
+    models = ModelSet([GMM.from_arrays(*synth.synth_gmm(K, 13, 7 + s)) for s in range(n_speakers)])
+    audio = synth.synth_speech(3, 40.0, fs)
+    out = {"fs": fs, "window_s": 1.0, "speakers": n_speakers, "mixtures": K, "dim": 13,
+           "frames_per_window": ex.num_frames(fs)}
+    # single stream, one window at a time
+    win = Batch.from_pcm([audio[:fs]])
+    lat = []
+    for i in range(230):
+        chunk = audio[(i % 39) * fs // 2:(i % 39) * fs // 2 + fs]
+        t0 = time.perf_counter()
+        win.update_pcm(chunk)
+        sums, arg = ex.predict_batch(models, win, nd=0)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat[30:])
+    out["single_stream_latency_ms"] = {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)),
+                                       "p99": float(np.percentile(lat, 99)), "min": float(lat.min())}
+    # many concurrent streams batched per tick
+    for n_streams in (64, 1024):
+        batch = Batch.from_pcm([audio[(j % 39) * fs // 2:(j % 39) * fs // 2 + fs] for j in range(n_streams)])
+        cat = np.concatenate([audio[(j % 39) * fs // 2:(j % 39) * fs // 2 + fs] for j in range(n_streams)])
+        ts = []
+        for i in range(30):
+            t0 = time.perf_counter()
+            batch.update_pcm(cat)
+            sums, arg = ex.predict_batch(models, batch, nd=0)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = np.array(ts[5:])
+        out["batched_%d_streams" % n_streams] = {"tick_ms_p50": float(np.percentile(ts, 50)),
+                                                 "windows_per_s": n_streams / (np.percentile(ts, 50) * 1e-3),
+                                                 "realtime_factor": n_streams * 1.0 / (np.percentile(ts, 50) * 1e-3)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,12 @@ class Batch:
                                          _lib.as_i64p(offsets), len(offsets) - 1)
         return cls(h)
 
+    def update_pcm(self, samples) -> None:
+        """Overwrite the batch's int16 samples in place (same layout): the serving loop's H2D."""
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        check(lib().sr_batch_update_pcm(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.size),
+              "sr_batch_update_pcm")
+
     @property
     def n_utt(self) -> int:
         return lib().sr_batch_num_utterances(self._h)

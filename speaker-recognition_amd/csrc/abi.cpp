@@ -349,6 +349,17 @@ SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
     SR_CATCH(nullptr)
 }
 
+int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
+    SR_TRY
+    if (!b || !pcm) fail("null argument");
+    if (b->kind != SRBatch::PCM16) fail("sr_batch_update_pcm needs an int16 PCM batch");
+    if (n_samples != b->n_rows) fail("sample count %lld does not match the batch (%lld)", (long long)n_samples, (long long)b->n_rows);
+    b->pcm16.upload(pcm, (size_t)n_samples);
+    sync_stream();
+    return 0;
+    SR_CATCH(-1)
+}
+
 void sr_batch_free(SRBatch *b) { delete b; }
 int sr_batch_num_utterances(SRBatch *b) { return b ? b->n_utt : 0; }
 int64_t sr_batch_num_rows(SRBatch *b) { return b ? b->n_rows : 0; }

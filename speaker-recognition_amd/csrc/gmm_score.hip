@@ -371,7 +371,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     }
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
-    int FT = opt.mfma_ft ? opt.mfma_ft : 2;
+    int FT = opt.mfma_ft;
+    if (FT == 0) {   // 2 column tiles per wave unless the utterances are too short to fill 256-frame tiles
+        const double mean_len = feat.n_utt ? (double)feat.n_rows / feat.n_utt : 0.0;
+        const double fill2 = mean_len / (256.0 * std::ceil(std::max(1.0, mean_len) / 256.0));
+        FT = (mean_len > 0 && fill2 < 0.80) ? 1 : 2;
+    }
     if (DP > 40 && FT > 3) FT = 3;
     TileTable &tt = feat.tiles_for(use_mfma ? 128 * FT : 256 * F);
     const int U = feat.n_utt;

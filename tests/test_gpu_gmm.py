@@ -157,3 +157,53 @@ def test_full_size_cfg1_properties(built_lib, oracle_built):
         want = np.array([go.score_all(go.GMMParams(*m), utts[u].astype(np.float64)) for m in models])
         assert np.max(np.abs(sums[u] - want) / np.abs(want)) < 2e-5
         assert int(np.argmax(want)) == arg[u]
+
+
+def test_cfg2_ubm_map_speakers_vs_oracle(built_lib, oracle_built):
+    """BASELINE configs[2] shape at a size the oracle can follow: a 512-mixture UBM plus MAP-adapted
+    speaker models (means shifted, sigmas and weights shared -- gmmubm.cc:40-81), 39-dim; per-frame
+    LL of every model and the rejection margin (best speaker - UBM) against the oracle."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    ubm = synth.synth_gmm(512, 39, 99)
+    spk = [synth.synth_map_speaker(ubm, 500 + s) for s in range(6)]
+    models = [ubm] + spk
+    utts = [synth.draw_frames(spk[u % 6], 150 + 37 * u, 700 + u) for u in range(4)]
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
+    for eng in (1, 2, 0):
+        _lib.set_option("score_engine", eng)
+        sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+        assert ll_close(fll, want) < TOL, (eng, ll_close(fll, want))
+        for u in range(4):
+            w = np.array([want[s, off[u]:off[u + 1]].sum() for s in range(7)])
+            assert int(np.argmax(w[1:])) == int(np.argmax(sums[u, 1:])) == u % 6
+            margin = (sums[u, 1:].max() - sums[u, 0]) / len(utts[u])
+            assert abs(margin - (w[1:].max() - w[0]) / len(utts[u])) < 1e-3
+
+
+def test_streaming_shape_short_windows(built_lib, oracle_built):
+    """BASELINE configs[4] shape: many short windows (61-98 frames, 1 s of 8 kHz audio) against a
+    256-mixture model set; both engines, every tile mostly empty."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    models = [synth.synth_gmm(256, 13, 300 + s) for s in range(3)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    lens = [61, 98, 98, 61, 77, 1, 98]
+    utts = [synth.draw_frames(models[u % 3], n, 50 + u) for u, n in enumerate(lens)]
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for eng in (1, 2, 0):
+        _lib.set_option("score_engine", eng)
+        sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+        assert ll_close(fll, want) < TOL, eng
+        for u in range(len(lens)):
+            w = np.array([want[s, off[u]:off[u + 1]].sum() for s in range(3)])
+            assert int(np.argmax(w)) == arg[u]
