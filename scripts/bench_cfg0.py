@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""BASELINE configs[0] end to end: 10 speakers x 30 s synthetic 16 kHz mono WAV, 25 ms / 10 ms frames,
+13 MFCC, 16-mixture diagonal GMM per speaker, enroll + predict.
+
+Device path: this package's ModelInterface (MFCC kernels -> GPU EM -> fused scoring).
+CPU path (timed on this box's host cores, same WAVs): the float64 numpy restatement of the
+reference's MFCC.py + the reference's own compiled C++ (oracle/_ref/pygmm_ref.so: train_model with
+the reference's defaults, score_all / len as GMMSetPyGMM.predict_one) when present."""
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+from scipy.io import wavfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import gmm_oracle as go, mfcc_oracle as mo  # noqa: E402
+from speaker_recognition_amd import synth  # noqa: E402
+from speaker_recognition_amd._lib import Parameter  # noqa: E402
+from speaker_recognition_amd.cli import read_wav  # noqa: E402
+from speaker_recognition_amd.interface import ModelInterface  # noqa: E402
+
+FS, KW, K = 16000, dict(win_length_ms=25, win_shift_ms=10), 16
+SPK = [3 * i for i in range(10)]
+
+
+def main():
+    tmp = tempfile.mkdtemp()
+    enroll, test = [], []
+    for s in SPK:
+        e = os.path.join(tmp, "enroll_%d.wav" % s)
+        t = os.path.join(tmp, "test_%d.wav" % s)
+        wavfile.write(e, FS, synth.synth_speech(s, 30.0, FS, seed=1000 + s))
+        wavfile.write(t, FS, synth.synth_speech(s, 30.0, FS, seed=2000 + s))
+        enroll.append((str(s), e))
+        test.append((str(s), t))
+
+    # ---- device path ----
+    m = ModelInterface(gmm_order=K, feature_kwargs=KW, gmm_kwargs={"seed": 1}, verbose=False)
+    m.enroll("warm", *read_wav(enroll[0][1]))         # context + code-object warm-up, not timed
+    m.train()
+    m = ModelInterface(gmm_order=K, feature_kwargs=KW, gmm_kwargs={"seed": 1}, verbose=False)
+    t0 = time.perf_counter()
+    for label, f in enroll:
+        m.enroll(label, *read_wav(f))
+    t1 = time.perf_counter()
+    m.train()
+    t2 = time.perf_counter()
+    pred = m.predict_many([read_wav(f) for _, f in test])
+    t3 = time.perf_counter()
+    dev = {"enroll_features_s": t1 - t0, "train_s": t2 - t1, "predict_s": t3 - t2, "total_s": t3 - t0,
+           "correct": int(sum(p == l for p, (l, _) in zip(pred, test))), "of": len(test)}
+
+    # ---- CPU path ----
+    cpu = None
+    if os.path.exists(go.REF_SO):
+        ref = go.RefLib()
+        t0 = time.perf_counter()
+        feats = {l: mo.extract(*read_wav(f), **KW) for l, f in enroll}
+        t1 = time.perf_counter()
+        handles = {}
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        saved = os.dup(1)
+        os.dup2(devnull, 1)                            # the reference prints its parameter block
+        try:
+            for l, X in feats.items():
+                h = ref.lib.new_gmm(K, 1)
+                p = Parameter(nr_instance=len(X), nr_dim=X.shape[1], nr_mixture=K, min_covar=1e-3, threshold=0.01,
+                              nr_iteration=200, init_with_kmeans=0, concurrency=os.cpu_count(), verbosity=0)
+                rows, keep = ref.rows(X)
+                ref.lib.train_model(h, rows, C.byref(p))
+                handles[l] = h
+        finally:
+            os.dup2(saved, 1)
+        t2 = time.perf_counter()
+        ok = 0
+        for l, f in test:
+            X = mo.extract(*read_wav(f), **KW)
+            scores = {k: ref.score_all(h, X, os.cpu_count()) / len(X) for k, h in handles.items()}
+            ok += int(max(scores, key=scores.get) == l)
+        t3 = time.perf_counter()
+        cpu = {"enroll_features_s": t1 - t0, "train_s": t2 - t1, "predict_s": t3 - t2, "total_s": t3 - t0,
+               "correct": ok, "of": len(test), "cores": os.cpu_count(), "kind": "reference C++ (GMM) + numpy port (MFCC)"}
+        for f in ("gmm-training-intermediate-dump.model",):
+            if os.path.exists(f):
+                os.remove(f)
+    print(json.dumps({"config": "BASELINE configs[0]: 10 x 30 s enroll + 10 x 30 s predict, 16 kHz, 25/10 ms, 13 MFCC, 16 mixtures",
+                      "device": dev, "cpu": cpu, "speedup_total": (cpu["total_s"] / dev["total_s"]) if cpu else None}))
+
+
+if __name__ == "__main__":
+    main()

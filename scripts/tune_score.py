@@ -33,7 +33,9 @@ def main():
     n = feats.n_rows
     flops = float(n) * S * K * (4 * D + 6)
     # (frames per lane | -FT for the matrix-core engine, packed, groups)
-    variants = [(4, 1, 0), (-2, 0, 1), (-2, 0, 2), (-2, 0, 4), (-2, 0, 5), (-2, 0, 10), (-2, 0, 20), (-1, 0, 4), (-3, 0, 4)]
+    variants = [(4, 1, 0), (4, -1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0), (-3, 0, 0)]
+    if os.environ.get('TUNE_FEW'):
+        variants = [(4, 1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0)]
     if D > 40:
         variants = [v for v in variants if v[0] <= 2 and v[0] >= -3]
     ref = None

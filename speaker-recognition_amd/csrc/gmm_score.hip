@@ -372,10 +372,13 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     int FT = opt.mfma_ft;
-    if (FT == 0) {   // 2 column tiles per wave unless the utterances are too short to fill 256-frame tiles
+    if (FT == 0) {
+        // measured (scripts/tune_score.py over D in {13,26,34,39}, K in {64..2048}): one 32-frame column
+        // tile per wave (88 VGPRs, 5 waves/SIMD) is as fast or up to 15 % faster than two, except for
+        // very small model sets; short utterances also want the smaller 128-frame workgroup tile
         const double mean_len = feat.n_utt ? (double)feat.n_rows / feat.n_utt : 0.0;
         const double fill2 = mean_len / (256.0 * std::ceil(std::max(1.0, mean_len) / 256.0));
-        FT = (mean_len > 0 && fill2 < 0.80) ? 1 : 2;
+        FT = (S >= 8 || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
     }
     if (DP > 40 && FT > 3) FT = 3;
     TileTable &tt = feat.tiles_for(use_mfma ? 128 * FT : 256 * F);

@@ -664,7 +664,27 @@ static MfccDev upload_tables(SRMfcc &m) {
         t->mel_col.upload(col.data(), col.size());
         t->mel_val.upload(val.data(), val.size());
         t->mel_floor.upload(floor_ln.data(), floor_ln.size());
-        // padded re-layout for the fast kernel: pass ps holds bands 16ps..16ps+15, runs padded to pass_len
+        // Padded re-layout for the fast kernel: pass ps holds bands 16ps..16ps+15.  Four lanes sweep a
+        // band, 8 bands share a 32-lane LDS group; a band's sweep start is moved down to a multiple of
+        // 4 columns whose 4-bank window (start/4 mod 8) no other band of its group uses, with leading
+        // zero weights -- the power-spectrum gather is then bank-conflict free.
+        std::vector<int> start(64, 0), lead(64, 0);
+        for (int grp = 0; grp < 8; grp++) {           // bands 8*grp .. 8*grp+7 sweep together
+            bool used[8] = {false, false, false, false, false, false, false, false};
+            for (int k = 7; k >= 0; k--) {            // widest start first: it has the most room below
+                const int b = 8 * grp + k;
+                if (b >= B || cnt[b] == 0) continue;
+                int st = col0[b] & ~3;
+                while (st > 0 && used[(st >> 2) & 7]) st -= 4;
+                if (used[(st >> 2) & 7]) st = col0[b] & ~3;   // no free window below: accept a conflict
+                used[(st >> 2) & 7] = true;
+                start[b] = st;
+                lead[b] = col0[b] - st;
+            }
+        }
+        for (int ps = 0; ps < 4; ps++) t->pass_len[ps] = 0;
+        for (int b = 0; b < B; b++)
+            t->pass_len[b / 16] = std::max(t->pass_len[b / 16], ((lead[b] + cnt[b] + 15) / 16) * 16);
         int total = 0;
         for (int ps = 0; ps < 4; ps++) {
             t->pass_base[ps] = total;
@@ -674,10 +694,13 @@ static MfccDev upload_tables(SRMfcc &m) {
         std::vector<float> padv((size_t)std::max(4, t->pad_floats), 0.0f);
         for (int b = 0; b < B; b++) {
             const int ps = b / 16, bl = b % 16;
-            for (int i = 0; i < cnt[b]; i++)
-                padv[(size_t)t->pass_base[ps] + (size_t)(i >> 2) * 64 + (size_t)bl * 4 + (i & 3)] = val[row[b] + i];
-            if (col0[b] + t->pass_len[ps] + 3 > 1100) t->runs_contiguous = false;   // padded sweep must stay inside the slab's power-spectrum region
+            for (int i = 0; i < cnt[b]; i++) {
+                const int e = lead[b] + i;
+                padv[(size_t)t->pass_base[ps] + (size_t)(e >> 2) * 64 + (size_t)bl * 4 + (e & 3)] = val[row[b] + i];
+            }
+            if (start[b] + t->pass_len[ps] + 3 > 1100) t->runs_contiguous = false;   // padded sweep must stay inside the slab's power-spectrum region
         }
+        for (int b = 0; b < 64; b++) col0[b] = start[b];   // the kernel sweeps from the aligned start
         t->mel_pad.upload(padv.data(), padv.size());
         t->mel_col0.upload(col0.data(), col0.size());
         t->mel_cnt.upload(cnt.data(), cnt.size());
