@@ -10,7 +10,7 @@
 // Mapping: a workgroup (256 threads = 4 wave64) owns one tile of 256*F frames of one
 // utterance; every lane keeps F frames (F*D floats) in VGPRs for the whole kernel, so X is
 // read from HBM exactly once.  Mixture parameters stream through LDS in chunks (double
-// buffered, prefetched through registers); all lanes read the same LDS address (broadcast),
+// buffered by LDS-DMA); all lanes read the same LDS address (broadcast),
 // two ds_read_b128 feed 8*F FMAs.  The log-sum-exp is online per lane, in the log2 domain
 // (v_exp_f32 / v_log_f32 are base-2).  No MFMA: the 2-FMA distance form is not a contraction.
 #include "score.hpp"
@@ -342,8 +342,7 @@ void upload_model_set(SRModelSet &s) {
 }
 
 // The expanded-form (matrix-core) layout is packed lazily: only sets that take that engine pay.
-static void ensure_mfma_layout(SRModelSet &s, const std::vector<const GMM *> *models) {
-    (void)models;
+static void ensure_mfma_layout(SRModelSet &s) {
     if (s.d_mfma_params.p) return;
     s.d_mfma_params.upload(s.mfma.params.data(), s.mfma.params.size());
     s.d_mfma_chunks.upload(s.mfma.chunks.data(), s.mfma.chunks.size());
@@ -406,7 +405,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
         if (use_mfma) {
-            ensure_mfma_layout(set, nullptr);
+            ensure_mfma_layout(set);
             MfmaLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
