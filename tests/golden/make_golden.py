@@ -71,6 +71,39 @@ def gmm_golden():
         out[name + "_X"] = X
         out[name + "_ll"] = ll1
         out[name + "_sum"] = np.float64(ref.score_all(h, X, 2))
+    # ---- MAP adaptation (train_model_from_ubm, pygmm.hh:34): deterministic in the reference (the
+    # trainer starts from a copy of the UBM, gmmubm.cc:25-38), so its result pins the E-step
+    # responsibilities, N_k and the means-only update.  Models come back through dump() (6 digits).
+    import ctypes as C
+    from speaker_recognition_amd._lib import Parameter
+    name, path, p = [c for c in cases if c[0] == "syn16x13"][0]
+    ubm_h = ref.load(path)
+    rng = np.random.default_rng(77)
+    k = rng.choice(p.K, size=700, p=p.weights / p.weights.sum())
+    Xa = (p.mean[k] + 0.25 + 0.8 * p.sigma[k] * rng.standard_normal((700, p.D))).astype(np.float32).astype(np.float64)
+    out["map_X"] = Xa
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    for iters in (1, 4):
+        h = ref.lib.new_gmm(p.K, 1)
+        par = Parameter(nr_instance=len(Xa), nr_dim=p.D, nr_mixture=p.K, min_covar=1e-3, threshold=0.01,
+                        nr_iteration=iters, init_with_kmeans=0, concurrency=2, verbosity=0)
+        rows, keep = ref.rows(Xa)
+        sys.stdout.flush()
+        os.dup2(devnull, 1)                      # the reference prints its parameter block
+        try:
+            ref.lib.train_model_from_ubm(h, ubm_h, rows, C.byref(par))
+        finally:
+            os.dup2(saved, 1)
+        dump_path = os.path.join(tmpdir, "map%d.model" % iters)
+        ref.lib.dump(h, dump_path.encode())
+        q = go.parse_model_text(open(dump_path).read())
+        out["map%d_mean" % iters] = q.mean
+        out["map%d_w" % iters] = q.weights
+        out["map%d_sigma" % iters] = q.sigma
+    for f in ("gmm-training-intermediate-dump.model",):
+        if os.path.exists(f):
+            os.remove(f)
     out["cases"] = np.array([c[0] for c in cases])
     np.savez_compressed(os.path.join(ROOT, "tests/golden/gmm_golden.npz"), **out)
     print("gmm_golden.npz:", [c[0] for c in cases])

@@ -132,3 +132,25 @@ def test_gmmset_rejection_and_pickle(built_lib, tmp_path):
     gs2 = pickle.loads(blob)
     gs2.after_pickle()
     assert gs2.predict(tests) == ["s0", "s1", "s2"]
+
+
+def test_map_training_vs_reference_dso_golden(built_lib, gmm_golden):
+    """train_model_from_ubm on the GPU (legacy symbol, double** rows) against the models the
+    reference's own compiled trainer produced for the same UBM and frames (1 and 4 iterations)."""
+    import ctypes as C
+    from speaker_recognition_amd._lib import Parameter
+    from speaker_recognition_amd.pygmm import GMM
+    L, g = built_lib, gmm_golden
+    ubm = GMM.from_arrays(g["syn16x13_w"], g["syn16x13_mean"], g["syn16x13_sigma"])
+    X = np.ascontiguousarray(g["map_X"])
+    n, d = X.shape
+    rows = (C.POINTER(C.c_double) * n)(*[C.cast(X[i].ctypes.data, C.POINTER(C.c_double)) for i in range(n)])
+    for iters in (1, 4):
+        spk = GMM(16)
+        p = Parameter(nr_instance=n, nr_dim=d, nr_mixture=16, min_covar=1e-3, threshold=0.01,
+                      nr_iteration=iters, init_with_kmeans=0, concurrency=4, verbosity=0)
+        L.train_model_from_ubm(spk.gmm, ubm.gmm, rows, C.byref(p))
+        w, mu, sg = spk.params()
+        ref = g["map%d_mean" % iters]
+        assert np.max(np.abs(mu - ref) / np.maximum(1.0, np.abs(ref))) < 5e-5, (iters, np.max(np.abs(mu - ref)))
+        assert np.array_equal(w, g["syn16x13_w"]) and np.array_equal(sg, g["syn16x13_sigma"])

@@ -95,3 +95,19 @@ def test_mfcc_constants(mfcc_golden):
 def test_signal_too_short_asserts():
     with pytest.raises(AssertionError):
         mo.extract(16000, np.zeros(5 * 512, dtype=np.int16))          # MFCC.py:56
+
+
+def test_map_adaptation_matches_reference_dso(oracle_built, gmm_golden):
+    """train_model_from_ubm is deterministic in the reference (it starts from the UBM copy); the
+    oracle's MAP iteration reproduces its dumped models to the 6 digits the text format keeps."""
+    go, g = oracle_built, gmm_golden
+    ubm = _params(go, g, "syn16x13")
+    X = g["map_X"]
+    q = ubm
+    for it in range(1, 5):
+        q = go.em_iteration(q, X, map_relevance=16.0, ubm=ubm)
+        if it in (1, 4):
+            ref = g["map%d_mean" % it]
+            assert np.max(np.abs(q.mean - ref) / np.maximum(1.0, np.abs(ref))) < 1e-5, it
+            assert np.array_equal(g["map%d_w" % it], ubm.weights)        # gmmubm.cc:40-42
+            assert np.array_equal(g["map%d_sigma" % it], ubm.sigma)      # gmmubm.cc:76-78
