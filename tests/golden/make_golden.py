@@ -104,6 +104,34 @@ def gmm_golden():
     for f in ("gmm-training-intermediate-dump.model",):
         if os.path.exists(f):
             os.remove(f)
+    # ---- full EM (train_model, pygmm.hh:33).  The reference draws its initial means with a
+    # rand()-seeded engine; in a FRESH process with the same call sequence that draw repeats, so
+    # "nr_iteration = 0" (initialisation only, gmm.cc:591-592) in one process and "nr_iteration = N"
+    # in another give the start and the end of the same run.  The start is stored exactly: the
+    # picked rows are identified by matching the dumped (6-digit) means back to rows of X.
+    import subprocess
+    true = synth.synth_gmm(8, 13, 31)
+    Xe = synth.draw_frames(true, 1500, 32).astype(np.float64)
+    xpath = os.path.join(tmpdir, "em_X.npy")
+    np.save(xpath, Xe)
+    helper = os.path.join(ROOT, "tests/golden/_ref_train.py")
+
+    def ref_train(iters):
+        mp = os.path.join(tmpdir, "em_%d.model" % iters)
+        subprocess.run([sys.executable, helper, xpath, "8", str(iters), mp], check=True, stdout=subprocess.DEVNULL)
+        return go.parse_model_text(open(mp).read())
+
+    init = ref_train(0)
+    init_again = ref_train(0)
+    assert np.array_equal(init.mean, init_again.mean), "reference initialisation is not repeatable across processes"
+    rows_picked = [int(np.argmin(np.sum((Xe - m) ** 2, axis=1))) for m in init.mean]
+    assert np.max(np.abs(Xe[rows_picked] - init.mean) / np.maximum(1, np.abs(init.mean))) < 1e-5
+    out["em_X"] = Xe
+    out["em_init_rows"] = np.array(rows_picked)
+    out["em_init_sigma_dumped"] = init.sigma
+    for iters in (1, 2, 6):
+        q = ref_train(iters)
+        out["em%d_w" % iters], out["em%d_mean" % iters], out["em%d_sigma" % iters] = q.weights, q.mean, q.sigma
     out["cases"] = np.array([c[0] for c in cases])
     np.savez_compressed(os.path.join(ROOT, "tests/golden/gmm_golden.npz"), **out)
     print("gmm_golden.npz:", [c[0] for c in cases])

@@ -111,3 +111,25 @@ def test_map_adaptation_matches_reference_dso(oracle_built, gmm_golden):
             assert np.max(np.abs(q.mean - ref) / np.maximum(1.0, np.abs(ref))) < 1e-5, it
             assert np.array_equal(g["map%d_w" % it], ubm.weights)        # gmmubm.cc:40-42
             assert np.array_equal(g["map%d_sigma" % it], ubm.sigma)      # gmmubm.cc:76-78
+
+
+def _em_start(g):
+    X = g["em_X"]
+    sig = np.sqrt(((X - X.mean(0)) ** 2).sum(0) / (len(X) - 1))        # gmm.cc:309-325
+    return X, np.full(8, 1.0 / 8), X[g["em_init_rows"]].copy(), np.tile(sig, (8, 1))
+
+
+def test_em_matches_reference_trainer(oracle_built, gmm_golden):
+    """Full EM against the reference's own train_model: same start (its rand()-seeded draw repeats
+    across fresh processes; see tests/golden/make_golden.py), models after 1, 2 and 6 iterations equal
+    to the 6 digits its dump keeps -- E-step, weights, means, variances and the sigma floor."""
+    go, g = oracle_built, gmm_golden
+    X, w, mu, sg = _em_start(g)
+    assert np.max(np.abs(sg[0] - g["em_init_sigma_dumped"][0]) / sg[0]) < 1e-5
+    p = go.GMMParams(w, mu, sg)
+    for it in range(1, 7):
+        p = go.em_iteration(p, X)
+        if it in (1, 2, 6):
+            assert np.max(np.abs(p.weights - g["em%d_w" % it])) < 2e-6, it
+            assert np.max(np.abs(p.mean - g["em%d_mean" % it])) < 2e-5, it
+            assert np.max(np.abs(p.sigma - g["em%d_sigma" % it]) / g["em%d_sigma" % it]) < 2e-5, it
