@@ -158,7 +158,7 @@ def main():
                    "frames_per_gpu": n_frames, "speakers": N_MODELS, "mixtures": N_MIX, "dim": DIM,
                    "sharding": "utterances/%d ranks, models replicated, no collective" % world},
         "roofline": {
-            "kernel": "gmm_score_mfma_kernel<39,2> (v_mfma_f32_32x32x2_f32; auto-selected engine)",
+            "kernel": _lib.last_score_kernel() + "; auto-selected engine",
             "bound": "mfma",
             "note": "compute-bound: arithmetic intensity S*K*(4D+6)/(4D) = %.0f flop/B vs machine balance ~20, so "
                     "HBM cannot be the bound; peak = dense fp32 MFMA = fp32 vector peak = 157.3 TFLOP/s; flops are "

@@ -125,6 +125,9 @@ int sr_score_batch_set(SRModelSet *set, SRBatch *features, double *sums_out, int
 typedef struct SRMfcc SRMfcc;
 SRMfcc *sr_mfcc_create(double fs, double win_length_ms, double win_shift_ms, int fft_size,
                        int n_filters, int n_ceps, double pre_emphasis);
+/* n_lpc > 0: append LPC-n_lpc columns to every frame (the reference's mix_feature,
+ * src/feature/__init__.py:25-30 -> LPC.py:40-57; same framing, no deltas); 0 switches them off. */
+int sr_mfcc_set_lpc(SRMfcc *m, int n_lpc);
 void sr_mfcc_free(SRMfcc *m);
 int sr_mfcc_frame_len(SRMfcc *m);
 int sr_mfcc_frame_shift(SRMfcc *m);
@@ -159,6 +162,8 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *   "score_frames_per_lane" 1|2|4, "score_model_groups" n, "score_packed" -1 (scalar FMA) | 1 (packed),
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel). */
 int sr_set_option(const char *key, long value);
+/* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */
+const char *sr_last_score_kernel(void);
 
 #ifdef __cplusplus
 }

@@ -40,10 +40,10 @@ def main():
         test.append((str(s), t))
 
     # ---- device path ----
-    m = ModelInterface(gmm_order=K, feature_kwargs=KW, gmm_kwargs={"seed": 1}, verbose=False)
+    m = ModelInterface(gmm_order=K, feature_kwargs=KW, lpc=False, gmm_kwargs={"seed": 1}, verbose=False)
     m.enroll("warm", *read_wav(enroll[0][1]))         # context + code-object warm-up, not timed
     m.train()
-    m = ModelInterface(gmm_order=K, feature_kwargs=KW, gmm_kwargs={"seed": 1}, verbose=False)
+    m = ModelInterface(gmm_order=K, feature_kwargs=KW, lpc=False, gmm_kwargs={"seed": 1}, verbose=False)
     t0 = time.perf_counter()
     for label, f in enroll:
         m.enroll(label, *read_wav(f))

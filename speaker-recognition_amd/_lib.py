@@ -24,9 +24,10 @@ EXT_SYMBOLS = [
     "sr_modelset_size", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
     "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
     "sr_batch_dim", "sr_batch_offsets", "sr_batch_download", "sr_score_batch_set",
-    "sr_mfcc_create", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
+    "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
+    "sr_last_score_kernel",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -100,6 +101,7 @@ def lib():
         "sr_batch_download": (i32, [vp, fp]),
         "sr_score_batch_set": (i32, [vp, vp, dp, C.POINTER(i32), fp, i32]),
         "sr_mfcc_create": (vp, [dbl, dbl, dbl, i32, i32, i32, dbl]),
+        "sr_mfcc_set_lpc": (i32, [vp, i32]),
         "sr_mfcc_free": (None, [vp]),
         "sr_mfcc_frame_len": (i32, [vp]),
         "sr_mfcc_frame_shift": (i32, [vp]),
@@ -112,6 +114,7 @@ def lib():
         "sr_profile_reset": (i32, []),
         "sr_profile_get": (i32, [i32, dp, C.POINTER(C.c_long)]),
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
+        "sr_last_score_kernel": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -177,6 +180,10 @@ def synchronize() -> None:
 
 def set_option(key: str, value: int) -> None:
     check(lib().sr_set_option(key.encode(), int(value)), "sr_set_option")
+
+
+def last_score_kernel() -> str:
+    return lib().sr_last_score_kernel().decode()
 
 
 def profile_enable(on: bool = True) -> None:

@@ -38,6 +38,7 @@ def get_args(argv=None):
     parser.add_argument("--win-shift-ms", type=float, default=16)
     parser.add_argument("--fft-size", type=int, default=2048)
     parser.add_argument("--deltas", type=int, default=0, choices=[0, 1, 2], help="append delta orders")
+    parser.add_argument("--no-lpc", action="store_true", help="MFCC half of mix_feature only (13 dims)")
     parser.add_argument("--seed", type=int, default=-1, help="EM initialisation seed (-1: random)")
     parser.add_argument("--device", type=int, default=0)
     return parser.parse_args(argv)
@@ -96,7 +97,8 @@ def _make_interface(args):
     if args.fft_size != 2048:
         fk["FFT_SIZE"] = args.fft_size
     return ModelInterface(gmm_order=args.mixtures, feature_kwargs=fk, diff=args.deltas > 0,
-                          nd=max(1, args.deltas), gmm_kwargs={"seed": args.seed})
+                          nd=max(1, args.deltas), lpc=not args.no_lpc and args.deltas == 0,
+                          gmm_kwargs={"seed": args.seed})
 
 
 def main(argv=None):

@@ -141,12 +141,15 @@ class MfccExtractor:
     """Device MFCC extractor; constants as MFCCExtractor.__init__ (src/feature/MFCC.py:20-41)."""
 
     def __init__(self, fs, win_length_ms=32, win_shift_ms=16, FFT_SIZE=2048, n_filters=50,
-                 n_ceps=13, pre_emphasis_coef=0.95):
+                 n_ceps=13, pre_emphasis_coef=0.95, n_lpc=0):
         h = lib().sr_mfcc_create(float(fs), float(win_length_ms), float(win_shift_ms),
                                  int(FFT_SIZE), int(n_filters), int(n_ceps), float(pre_emphasis_coef))
         if not h:
             raise SRError("sr_mfcc_create failed: %s" % _lib.last_error())
         self._h = C.c_void_p(h)
+        self.n_lpc = int(n_lpc)        # > 0: every frame also carries LPC-n_lpc columns (mix_feature)
+        if self.n_lpc:
+            check(lib().sr_mfcc_set_lpc(self._h, self.n_lpc), "sr_mfcc_set_lpc")
         self.fs, self.FFT_SIZE, self.n_bands, self.coefs = fs, FFT_SIZE, n_filters, n_ceps
         self.PRE_EMPH = pre_emphasis_coef
         self.FRAME_LEN = lib().sr_mfcc_frame_len(self._h)

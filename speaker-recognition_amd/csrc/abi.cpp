@@ -399,6 +399,16 @@ SRMfcc *sr_mfcc_create(double fs, double win_length_ms, double win_shift_ms, int
     SR_CATCH(nullptr)
 }
 
+int sr_mfcc_set_lpc(SRMfcc *m, int n_lpc) {
+    SR_TRY
+    if (!m) fail("null extractor");
+    if (n_lpc != 0 && n_lpc != 10 && n_lpc != 12 && n_lpc != 15 && n_lpc != 16 && n_lpc != 20)
+        fail("LPC order %d is not instantiated (10, 12, 15, 16, 20; 0 = off)", n_lpc);
+    m->n_lpc = n_lpc;
+    return 0;
+    SR_CATCH(-1)
+}
+
 void sr_mfcc_free(SRMfcc *m) { delete m; }
 int sr_mfcc_frame_len(SRMfcc *m) { return m ? m->frame_len : 0; }
 int sr_mfcc_frame_shift(SRMfcc *m) { return m ? m->frame_shift : 0; }
@@ -487,5 +497,7 @@ int sr_set_option(const char *key, long value) {
     return 0;
     SR_CATCH(-1)
 }
+
+const char *sr_last_score_kernel(void) { return last_score_kernel(); }
 
 }  // extern "C"

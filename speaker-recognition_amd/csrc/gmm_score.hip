@@ -265,6 +265,9 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
 
 // ---------------- host side ----------------
 
+static char g_last_kernel[96] = "";
+const char *last_score_kernel() { return g_last_kernel; }
+
 ScoreOptions &score_options() {
     static ScoreOptions o;
     return o;
@@ -421,6 +424,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.clamp = (flags & 1) ? 1 : 0;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
+            snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
             ScopedKernelTimer t(T_SCORE);
             launch_score_mfma(a, DP, FT);
         } else {
@@ -436,6 +440,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.dim = feat.dim;
             a.n_models = S;
             a.clamp = (flags & 1) ? 1 : 0;
+            snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
+                     (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");
             ScopedKernelTimer t(T_SCORE);
             dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
         }

@@ -11,6 +11,7 @@
 // float64 tables built on the host exactly as the reference builds them.
 #include "batch.hpp"
 #include "mfcc.hpp"
+#include "wave_ops.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -258,12 +259,6 @@ void mfcc_frames_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict_
 // i.e. three register passes and two LDS exchanges instead of five LDS passes; the waves of a
 // workgroup never synchronise with each other (wave-local LDS slab, wavefront-scope fences).
 // Mel rows are contiguous column runs (melfb.m structure), lane = band; DCT lane = coefficient.
-
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -543,7 +538,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
 __global__ __launch_bounds__(256)
 void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict__ raw_off,
                        const int64_t *__restrict__ out_off, int n_ceps, int nd, int cmvn,
-                       float *__restrict__ out) {
+                       float *__restrict__ out, int out_stride) {
     const int u = blockIdx.x;
     const int64_t r0 = raw_off[u];
     const int64_t T = raw_off[u + 1] - r0;
@@ -592,12 +587,11 @@ void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict_
         }
         __syncthreads();
     }
-    const int dim_out = n_ceps * (nd + 1);
     if (live) {
         const double mu = s_mean[c], inv = s_inv[c];
         for (int64_t t = stripe; t < To; t += n_stripes) {
             const int64_t tr = t + nd;   // row of the normalised features this output row ends on
-            float *dst = out + (o0 + t) * dim_out;
+            float *dst = out + (o0 + t) * out_stride;
             const double z0 = ((double)raw[(r0 + tr) * n_ceps + c] - mu) * inv;
             dst[c] = (float)z0;
             if (nd >= 1) {
@@ -752,6 +746,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     ensure_device();
     if (pcm.kind != SRBatch::PCM16 && pcm.kind != SRBatch::PCMF32) fail("MFCC needs a PCM batch");
     if (nd < 0 || nd > 2) fail("delta order must be 0, 1 or 2");
+    if (m.n_lpc > 0 && nd != 0) fail("LPC columns (mix_feature) come without deltas: use nd = 0");
     const MfccDev dev = upload_tables(m);
     const int U = pcm.n_utt;
     std::vector<int64_t> raw_off(U + 1, 0), out_off(U + 1, 0);
@@ -765,11 +760,11 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
     w.raw_off.upload(raw_off.data(), raw_off.size());
 
-    const bool same_shape = out.kind == SRBatch::FEATURES && out.offsets == out_off &&
-                            out.dim == m.n_ceps * (nd + 1);
+    const int dim_out = m.n_ceps * (nd + 1) + m.n_lpc;
+    const bool same_shape = out.kind == SRBatch::FEATURES && out.offsets == out_off && out.dim == dim_out;
     out.kind = SRBatch::FEATURES;
     out.n_utt = U;
-    out.dim = m.n_ceps * (nd + 1);
+    out.dim = dim_out;
     out.n_rows = out_off[U];
     out.data.ensure((size_t)std::max<int64_t>(1, out.n_rows) * out.dim);
     if (!same_shape) {
@@ -840,9 +835,11 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     if (U > 0 && out.n_rows > 0) {
         ScopedKernelTimer t(T_CMVN);
         hipLaunchKernelGGL(cmvn_delta_kernel, dim3(U), dim3(256), 0, ctx().stream, w.raw.p,
-                           w.raw_off.p, out.d_offsets.p, m.n_ceps, nd, cmvn, out.data.p);
+                           w.raw_off.p, out.d_offsets.p, m.n_ceps, nd, cmvn, out.data.p, out.dim);
         SR_HIP(hipGetLastError());
     }
+    if (m.n_lpc > 0 && NF > 0)   // mix_feature: LPC columns next to the cepstra (same frames, nd == 0)
+        lpc_extract_into(m, pcm, w.raw_off.p, NF, m.n_lpc, out.data.p, out.dim, m.n_ceps);
     sync_stream();   // raw_off / out_off host vectors feed async uploads
 }
 

@@ -17,6 +17,8 @@ struct SRMfcc {
     std::vector<double> melbank;   // [n_filters][fft_size/2+1]
     std::vector<double> dct;       // [n_ceps][n_filters]  (DCT-II rows 1..n_ceps)
     std::shared_ptr<void> dev;     // device tables, created on first use
+    std::shared_ptr<void> dev_window_f64;   // float64 window for the LPC kernel
+    int n_lpc = 0;                 // > 0: append LPC columns (mix_feature, feature/__init__.py:25-30)
     SRMfcc(double fs, double win_length_ms, double win_shift_ms, int fft_size, int n_filters,
            int n_ceps, double pre_emph);
 };
@@ -24,5 +26,7 @@ struct SRMfcc {
 namespace sr {
 int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples);
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out);
-void mfcc_set_force_generic(bool on);   // A/B: route FFT_SIZE 2048 through the generic LDS kernel
+void mfcc_set_force_generic(bool on);
+void lpc_extract_into(SRMfcc &m, SRBatch &pcm, const int64_t *d_frame_off, int64_t n_frames, int n_lpc,
+                      float *out, int out_stride, int col_off);   // A/B: route FFT_SIZE 2048 through the generic LDS kernel
 }  // namespace sr

@@ -33,6 +33,7 @@ struct MfmaLaunch {
 };
 void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
 ScoreOptions &score_options();
+const char *last_score_kernel();   // name of the kernel variant the last scoring call launched
 
 // Device-resident results of the last scoring call (valid until the next one).
 struct ScoreResult {

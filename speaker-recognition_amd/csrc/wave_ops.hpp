@@ -7,6 +7,14 @@
 
 namespace sr {
 
+// Orders LDS traffic between the lanes of ONE wave (no instruction emitted: a wave's LDS operations
+// execute in order; this only stops the compiler from moving them across).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Sum of `v` over the 64 lanes of the wave; the result is valid in every lane (it comes back
 // through SGPRs).  float64, fixed order: row-wise prefix sums by DPP row_shr 1/2/4/8, then the
 // four row totals.

@@ -1,10 +1,16 @@
 """Mirror of the reference's ``src/feature/__init__.py``.
 
-``mix_feature`` there concatenates MFCC with LPC-15 (:25-30).  LPC (a per-frame Levinson
-recursion from the absent scikits.talkbox) is outside this path's scope, so
-``mix_feature`` returns the MFCC half only -- stated here rather than silently substituted.
+``mix_feature`` concatenates MFCC (the reference's own MFCC.py when bob is absent, :11-16) with
+LPC-15 (:25-30): 13 + 15 = 28 dims at the defaults.  Both halves come out of ONE device pass here
+(same frames, same window / pre-emphasis).  ``lpc=False`` returns the MFCC half only (what the
+GMM path of BASELINE.json's configs uses); ``diff``/``nd`` append deltas to the MFCC half and are
+exclusive with the LPC columns (the reference's mix_feature has no deltas either).
 """
-from . import MFCC
+import numpy as np
+
+from . import LPC, MFCC
+from ..core import MfccExtractor
+from .utils import cached_func
 
 
 def get_extractor(extract_func, **kwargs):
@@ -13,5 +19,13 @@ def get_extractor(extract_func, **kwargs):
     return f
 
 
-def mix_feature(tup, **kwargs):
-    return MFCC.extract(tup, **kwargs)
+@cached_func
+def _mix_extractor(fs, n_lpc, **kwargs):
+    return MfccExtractor(fs, n_lpc=n_lpc, **kwargs)
+
+
+def mix_feature(tup, lpc=True, diff=False, nd=1, n_lpc=15, **kwargs):
+    if not lpc or diff:
+        return MFCC.extract(tup, diff=diff, nd=nd, **kwargs)
+    fs, signal = tup
+    return _mix_extractor(fs, n_lpc, **kwargs).extract(np.asarray(signal), nd=0)

@@ -4,7 +4,8 @@ device-backed ``GMMSetPyGMM`` (the reference's C++ back-end, interface.py:19-23,
 drop-in boundary of this repo; its scikit-learn default is third-party code).
 
 Extensions (all keyword-only, defaults = the reference's behaviour): ``gmm_order``,
-``feature_kwargs`` (forwarded to ``feature.MFCC.extract``), ``diff``/``nd`` (append deltas),
+``feature_kwargs`` (forwarded to the extractor), ``lpc`` (False: MFCC half of mix_feature only),
+``diff``/``nd`` (append deltas to the MFCC half; excludes the LPC columns),
 ``gmm_kwargs`` (forwarded to ``pygmm.GMM``), ``ubm`` (MAP-adapt speakers from a UBM).
 VAD (``init_noise`` / ``filter``; third-party pyssp LTSD in the reference) is out of scope.
 """
@@ -27,12 +28,12 @@ class ModelInterface(object):
 
     UBM_MODEL_FILE = None
 
-    def __init__(self, *, gmm_order=32, feature_kwargs=None, diff=False, nd=1, gmm_kwargs=None,
+    def __init__(self, *, gmm_order=32, feature_kwargs=None, diff=False, nd=1, lpc=True, gmm_kwargs=None,
                  verbose=True):
         self.features = defaultdict(list)
         self.gmm_order = gmm_order
         self.feature_kwargs = dict(feature_kwargs or {})
-        self.diff, self.nd = diff, nd
+        self.diff, self.nd, self.lpc = diff, nd, lpc
         self.gmm_kwargs = dict(gmm_kwargs or {})
         self.verbose = verbose
         self.gmmset = GMMSet(gmm_order=gmm_order, **self.gmm_kwargs)
@@ -45,7 +46,7 @@ class ModelInterface(object):
         raise NotImplementedError("VAD (filters/VAD.py) is outside the MFCC + GMM hot path")
 
     def _features(self, fs, signal):
-        return mix_feature((fs, signal), diff=self.diff, nd=self.nd, **self.feature_kwargs)
+        return mix_feature((fs, signal), lpc=self.lpc, diff=self.diff, nd=self.nd, **self.feature_kwargs)
 
     def enroll(self, name, fs, signal):
         """add the signal to this person's training dataset"""

@@ -74,3 +74,26 @@ def test_silence_floor_matches_reference(built_lib):
     ref = mo.get_mfcc_extractor(fs).raw_cepstra(pcm.astype(float))
     assert np.all(np.isfinite(raw))
     assert np.max(np.abs(raw - ref)) < 5e-3, np.max(np.abs(raw - ref))
+
+
+def test_lpc_and_mix_feature_vs_oracle(built_lib):
+    """mix_feature = [13 MFCC | 15 LPC] per frame in one device pass (feature/__init__.py:25-30).
+    The LPC half runs in float64 on the device (ill-conditioned Toeplitz systems) and is compared
+    with the float64 restatement of talkbox's algorithm; silent frames give zeros."""
+    from oracle import lpc_oracle as lo, mfcc_oracle as mo
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.feature import LPC, mix_feature
+    for fs, kw in ((16000, {}), (16000, dict(win_length_ms=25, win_shift_ms=10)), (8000, {})):
+        pcm = synth.synth_speech(6, 1.1, fs)
+        pcm[2000:3500] = 0
+        mix = mix_feature((fs, pcm), **kw)
+        ref_m = mo.extract(fs, pcm, **kw)
+        ref_l = lo.extract(fs, pcm, **kw)
+        assert mix.shape == (ref_m.shape[0], 28)
+        assert np.max(np.abs(mix[:, :13] - ref_m)) < 1e-3
+        scale = np.maximum(1.0, np.abs(ref_l))
+        assert np.max(np.abs(mix[:, 13:] - ref_l) / scale) < 2e-6, np.max(np.abs(mix[:, 13:] - ref_l) / scale)
+        only = LPC.extract(fs, pcm, **kw)
+        assert np.array_equal(only, mix[:, 13:])
+        assert np.all(only[np.all(ref_l == 0, axis=1)] == 0)
+    assert mix_feature((16000, synth.synth_speech(1, 0.5, 16000)), lpc=False).shape[1] == 13

@@ -133,3 +133,26 @@ def test_em_matches_reference_trainer(oracle_built, gmm_golden):
             assert np.max(np.abs(p.weights - g["em%d_w" % it])) < 2e-6, it
             assert np.max(np.abs(p.mean - g["em%d_mean" % it])) < 2e-5, it
             assert np.max(np.abs(p.sigma - g["em%d_sigma" % it]) / g["em%d_sigma" % it]) < 2e-5, it
+
+
+def test_lpc_oracle_solves_the_normal_equations():
+    """LPC (talkbox, third-party, absent -> parity unpinned): the restated Levinson-Durbin recursion
+    solves the Toeplitz normal equations of the restated biased autocorrelation (independent solver),
+    and the autocorrelation equals the direct time-domain sum."""
+    from scipy.linalg import solve_toeplitz
+    from oracle import lpc_oracle as lo
+    from speaker_recognition_amd import synth
+    ex = lo.LPCExtractor(16000)
+    pcm = synth.synth_speech(2, 0.6, 16000).astype(float)
+    feat = ex.extract(pcm)
+    assert feat.shape == ((len(pcm) - 512) // 256 + 1, 15)
+    for f in (0, 7, 20):
+        frame = pcm[f * 256:f * 256 + 512] * ex.window
+        frame[1:] -= frame[:-1] * 0.95
+        r = lo.acorr_lpc(frame)
+        direct = np.array([np.dot(frame[:512 - k], frame[k:]) for k in range(16)]) / 512
+        assert np.max(np.abs(direct - r[:16])) < 1e-9 * abs(r[0])
+        a = solve_toeplitz(r[:15], -r[1:16])
+        assert np.max(np.abs(a - feat[f])) < 1e-8
+    silent = ex.extract(np.zeros(4000))
+    assert silent.shape[1] == 15 and np.all(silent == 0)          # NaN -> 0, LPC.py:56
