@@ -376,11 +376,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     int FT = opt.mfma_ft;
     if (FT == 0) {
         // measured (scripts/tune_score.py over D in {13,26,34,39}, K in {64..2048}): one 32-frame column
-        // tile per wave (88 VGPRs, 5 waves/SIMD) is as fast or up to 15 % faster than two, except for
-        // very small model sets; short utterances also want the smaller 128-frame workgroup tile
+        // tile per wave (88 VGPRs, 5 waves/SIMD) is up to 15 % faster than two for K >= 128 and model
+        // sets of >= 8; two win slightly at K = 64; short utterances want the smaller 128-frame tile
         const double mean_len = feat.n_utt ? (double)feat.n_rows / feat.n_utt : 0.0;
         const double fill2 = mean_len / (256.0 * std::ceil(std::max(1.0, mean_len) / 256.0));
-        FT = (S >= 8 || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
+        const double tiles_per_model = (double)set.mfma.chunks.size() * MFMA_CT / std::max(1, S);   // ~K/32
+        FT = ((S >= 8 && tiles_per_model >= 4.0) || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
     }
     if (DP > 40 && FT > 3) FT = 3;
     TileTable &tt = feat.tiles_for(use_mfma ? 128 * FT : 256 * F);

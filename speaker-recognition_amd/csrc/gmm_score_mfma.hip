@@ -144,10 +144,17 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
 #pragma unroll
                 for (int r = 1; r < 16; r++) mx = fmaxf(mx, acc[ft][r]);
                 const float mn = fmaxf(m[ft], mx);
-                float e = 0.0f;
+                // rows two at a time: the subtraction and the running sum as packed fp32 ops (fewer
+                // vector-ALU instructions next to the MFMA stream; v_exp_f32 has no packed form)
+                typedef float v2 __attribute__((ext_vector_type(2)));
+                const v2 mn2 = {mn, mn};
+                v2 e2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < 16; r++) e += __builtin_amdgcn_exp2f(acc[ft][r] - mn);
-                ssum[ft] = fmaf(ssum[ft], __builtin_amdgcn_exp2f(m[ft] - mn), e);
+                for (int r = 0; r < 16; r += 2) {
+                    const v2 d = (v2){acc[ft][r], acc[ft][r + 1]} - mn2;
+                    e2 += (v2){__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+                }
+                ssum[ft] = fmaf(ssum[ft], __builtin_amdgcn_exp2f(m[ft] - mn), e2.x + e2.y);
                 m[ft] = mn;
             }
         }
