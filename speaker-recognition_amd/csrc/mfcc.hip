@@ -355,6 +355,9 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float2 w64[4];        // W_64^(b*c)
 #pragma unroll
     for (int c = 0; c < 4; c++) w64[c] = tw(s_tw, (32 * bb * c) & 2047, NC);
+    float2 utw[16];       // untangle twiddles W_2048^(lane + 64 j)
+#pragma unroll
+    for (int j = 0; j < 16; j++) utw[j] = s_tw[lane + 64 * j];
     const int L = p.frame_len;
     // window taps of this lane's samples: y[i0] = w0 x[i0] - wm x[i0-1], y[i0+1] = w1 x[i0+1] - w0p x[i0]
     float win_m[NZ1], win_0[NZ1], win_1[NZ1], win_0p[NZ1];
@@ -474,11 +477,11 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const int k = lane + 64 * j;
-            const float2 zk = slab[k];
+            const float2 zk = v[j];                              // Z[lane + 64 j] is this lane's own output
             const float2 zr = slab[(NC - k) & (NC - 1)];
             const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
             const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
-            const float2 xo = cmul(s_tw[k], o);
+            const float2 xo = cmul(utw[j], o);
             const float xr = e.x + xo.x, xi = e.y + xo.y;
             pw[j] = xr * xr + xi * xi;
         }
