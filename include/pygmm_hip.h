@@ -142,6 +142,18 @@ SRBatch *sr_mfcc_extract_batch(SRMfcc *m, SRBatch *pcm, int nd, int cmvn);
 int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out,
                          int *argmax_out, int flags);
 
+/* Fixed-shape serving session: n_windows windows of window_samples int16 samples per tick.  Two
+ * slots of pinned + device buffers and a second HIP stream: the H2D copy of tick i+1 overlaps the
+ * kernels of tick i.  submit() returns after queueing (at most two ticks in flight); collect()
+ * waits for the oldest tick and hands back sums[n_windows][S], argmax[n_windows] and the
+ * device-side time from the start of its H2D to its last kernel. */
+typedef struct SRStream SRStream;
+SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t window_samples, int nd,
+                           int flags);
+int sr_stream_submit(SRStream *s, const int16_t *pcm /* [n_windows][window_samples] */);
+int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *device_ms);
+void sr_stream_free(SRStream *s);
+
 /* GPU EM / MAP on contiguous fp32 frames (the engine behind train_model*). Returns the number
  * of iterations run, negative on error. seed < 0 -> time-based. */
 int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,

@@ -27,7 +27,7 @@ EXT_SYMBOLS = [
     "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
-    "sr_last_score_kernel",
+    "sr_last_score_kernel", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -115,6 +115,10 @@ def lib():
         "sr_profile_get": (i32, [i32, dp, C.POINTER(C.c_long)]),
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
+        "sr_stream_create": (vp, [vp, vp, i32, i64, i32, i32]),
+        "sr_stream_submit": (i32, [vp, C.POINTER(C.c_int16)]),
+        "sr_stream_collect": (i32, [vp, dp, C.POINTER(i32), dp]),
+        "sr_stream_free": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -199,3 +199,40 @@ class MfccExtractor:
                 self._h = None
         except Exception:
             pass
+
+
+class ServingStream:
+    """Double-buffered fixed-shape serving session (sr_stream_*): ``n_windows`` windows of
+    ``window_samples`` int16 samples per tick; ``submit`` queues a tick (H2D on its own HIP stream,
+    overlapping the previous tick's kernels), ``collect`` returns the oldest tick's decisions."""
+
+    def __init__(self, extractor: MfccExtractor, models: ModelSet, n_windows: int, window_samples: int,
+                 nd: int = 0, clamp_compat: bool = True):
+        self._keep = (extractor, models)
+        self.n_windows, self.window_samples, self.n_models = int(n_windows), int(window_samples), len(models)
+        h = lib().sr_stream_create(extractor._h, models._h, self.n_windows, self.window_samples, int(nd),
+                                   _lib.SR_CLAMP_COMPAT if clamp_compat else 0)
+        if not h:
+            raise SRError("sr_stream_create failed: %s" % _lib.last_error())
+        self._h = C.c_void_p(h)
+
+    def submit(self, pcm) -> None:
+        a = np.ascontiguousarray(pcm, dtype=np.int16)
+        if a.size != self.n_windows * self.window_samples:
+            raise ValueError("expected %d x %d samples" % (self.n_windows, self.window_samples))
+        check(lib().sr_stream_submit(self._h, a.ctypes.data_as(C.POINTER(C.c_int16))), "sr_stream_submit")
+
+    def collect(self):
+        sums = np.empty((self.n_windows, self.n_models), dtype=np.float64)
+        arg = np.empty(self.n_windows, dtype=np.int32)
+        ms = C.c_double(0)
+        check(lib().sr_stream_collect(self._h, _lib.as_dp(sums), _lib.as_i32p(arg), C.byref(ms)), "sr_stream_collect")
+        return sums, arg, ms.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().sr_stream_free(self._h)
+                self._h = None
+        except Exception:
+            pass

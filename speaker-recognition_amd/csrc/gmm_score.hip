@@ -274,6 +274,7 @@ ScoreOptions &score_options() {
 }
 
 struct ScoreWorkspace {
+    std::vector<int> gcb_host;           // what group_chunk_begin currently holds
     DevBuf<double> partial;
     DevBuf<double> sums;
     DevBuf<int> argmax;
@@ -404,7 +405,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             const int model = (int)(((int64_t)g * S) / G);
             gcb[g] = mcb[model];
         }
-        w.group_chunk_begin.upload(gcb.data(), gcb.size());
+        bool uploaded = false;
+        if (w.gcb_host != gcb) {
+            w.gcb_host = gcb;
+            w.group_chunk_begin.upload(w.gcb_host.data(), w.gcb_host.size());
+            uploaded = true;
+        }
         w.partial.ensure((size_t)tt.n_tiles * S * 4);
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
@@ -447,7 +453,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
         }
         SR_HIP(hipGetLastError());
-        sync_stream();  // gcb (host vector) must outlive its async upload
+        if (uploaded) sync_stream();   // first call with this grouping only; the copy source is the workspace's own vector
     }
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);

@@ -738,6 +738,7 @@ void mfcc_set_force_generic(bool on) { mfcc_force_generic_flag() = on; }
 struct MfccWorkspace {
     DevBuf<float> raw;
     DevBuf<int64_t> raw_off;
+    std::vector<int64_t> raw_off_host;   // what raw_off currently holds (skip the upload + sync when unchanged)
 };
 static MfccWorkspace &mws() {
     static MfccWorkspace *w = new MfccWorkspace();   // leaked on purpose: no hipFree at exit
@@ -761,7 +762,12 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     const int64_t NF = raw_off[U];
     auto &w = mws();
     w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
-    w.raw_off.upload(raw_off.data(), raw_off.size());
+    bool uploaded = false;
+    if (w.raw_off_host != raw_off) {
+        w.raw_off_host = raw_off;
+        w.raw_off.upload(w.raw_off_host.data(), w.raw_off_host.size());
+        uploaded = true;
+    }
 
     const int dim_out = m.n_ceps * (nd + 1) + m.n_lpc;
     const bool same_shape = out.kind == SRBatch::FEATURES && out.offsets == out_off && out.dim == dim_out;
@@ -774,6 +780,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
         out.offsets = out_off;
         out.tile_tables.clear();
         out.d_offsets.upload(out.offsets.data(), out.offsets.size());
+        uploaded = true;
     }
 
     if (NF > 0) {
@@ -843,7 +850,9 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     }
     if (m.n_lpc > 0 && NF > 0)   // mix_feature: LPC columns next to the cepstra (same frames, nd == 0)
         lpc_extract_into(m, pcm, w.raw_off.p, NF, m.n_lpc, out.data.p, out.dim, m.n_ceps);
-    sync_stream();   // raw_off / out_off host vectors feed async uploads
+    // Same shapes as the previous call (the serving loop): nothing was uploaded, nothing to wait for --
+    // the kernels stay queued behind whatever the caller does next on the stream.
+    if (uploaded) sync_stream();
 }
 
 }  // namespace sr

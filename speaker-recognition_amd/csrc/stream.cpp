@@ -1,0 +1,159 @@
+// stream.cpp -- fixed-shape serving session (BASELINE configs[4]: 1 s windows of 8 kHz audio):
+// `n_windows` windows of `window_samples` samples per tick -> MFCC -> CMVN(/deltas) -> speaker set ->
+// decision per window.  Two slots of pinned host + device buffers and a second HIP stream: the H2D
+// copy of tick i+1 runs while the kernels of tick i do (hipStream double buffering); results come
+// back through pinned memory; the host only waits in sr_stream_collect.
+// (The reference's conversation loop -- gui.py:179-214 -- polls a 1.5 s window every 0.4 s; its
+// VAD front end is third-party and out of scope.)
+#include "../../include/pygmm_hip.h"
+
+#include "batch.hpp"
+#include "mfcc.hpp"
+#include "score.hpp"
+
+#include <cstring>
+#include <deque>
+
+struct SRStream {
+    SRMfcc *mfcc = nullptr;
+    SRModelSet *set = nullptr;
+    int n_windows = 0, nd = 0, n_models = 0, flags = 0;
+    int64_t window_samples = 0;
+    hipStream_t copy_stream = nullptr;
+    struct Slot {
+        int16_t *h_pcm = nullptr;        // pinned
+        double *h_sums = nullptr;        // pinned [n_windows][S]
+        int *h_argmax = nullptr;         // pinned [n_windows]
+        SRBatch pcm, feat;
+        hipEvent_t h2d_done = nullptr, done = nullptr, t_submit = nullptr;
+        bool busy = false;
+    } slot[2];
+    std::deque<int> in_flight;           // slot indices, oldest first
+    long submitted = 0;
+};
+
+using namespace sr;
+
+namespace {
+
+void stream_destroy(SRStream *s) {
+    if (!s) return;
+    for (auto &sl : s->slot) {
+        if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
+        if (sl.h_sums) (void)hipHostFree(sl.h_sums);
+        if (sl.h_argmax) (void)hipHostFree(sl.h_argmax);
+        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        if (sl.t_submit) (void)hipEventDestroy(sl.t_submit);
+    }
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+    delete s;
+}
+
+}  // namespace
+
+extern "C" {
+
+SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t window_samples, int nd,
+                           int flags) {
+    try {
+        ensure_device();
+        if (!m || !set || n_windows <= 0 || window_samples <= 0) fail("bad arguments to sr_stream_create");
+        if (mfcc_num_frames(*m, window_samples) - nd <= 0) fail("window of %lld samples yields no frames", (long long)window_samples);
+        auto *s = new SRStream();
+        s->mfcc = m;
+        s->set = set;
+        s->n_windows = n_windows;
+        s->window_samples = window_samples;
+        s->nd = nd;
+        s->flags = flags;
+        s->n_models = set->host.n_models;
+        SR_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        const size_t n_samp = (size_t)n_windows * window_samples;
+        for (auto &sl : s->slot) {
+            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_pcm), n_samp * sizeof(int16_t), hipHostMallocDefault));
+            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_sums), (size_t)n_windows * s->n_models * sizeof(double), hipHostMallocDefault));
+            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_argmax), (size_t)n_windows * sizeof(int), hipHostMallocDefault));
+            SR_HIP(hipEventCreate(&sl.h2d_done));
+            SR_HIP(hipEventCreate(&sl.done));
+            SR_HIP(hipEventCreate(&sl.t_submit));
+            sl.pcm.kind = SRBatch::PCM16;
+            sl.pcm.n_utt = n_windows;
+            sl.pcm.n_rows = (int64_t)n_samp;
+            sl.pcm.offsets.resize(n_windows + 1);
+            for (int u = 0; u <= n_windows; u++) sl.pcm.offsets[u] = (int64_t)u * window_samples;
+            sl.pcm.pcm16.alloc(n_samp);
+            SR_HIP(hipMemsetAsync(sl.pcm.pcm16.p, 0, n_samp * sizeof(int16_t), ctx().stream));
+            sl.pcm.d_offsets.upload(sl.pcm.offsets.data(), sl.pcm.offsets.size());
+            sync_stream();
+            // one synchronous pass per slot builds every table / workspace for this shape, so the
+            // steady state launches kernels only
+            mfcc_extract_batch(*m, sl.pcm, nd, 1, sl.feat);
+            (void)score_device(*set, sl.feat, false, flags);
+            sync_stream();
+        }
+        return s;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return nullptr;
+    }
+}
+
+void sr_stream_free(SRStream *s) {
+    if (s) (void)hipDeviceSynchronize();
+    stream_destroy(s);
+}
+
+int sr_stream_submit(SRStream *s, const int16_t *pcm) {
+    try {
+        if (!s || !pcm) fail("null argument");
+        if (s->in_flight.size() >= 2) fail("two ticks already in flight: collect one first");
+        const int k = (int)(s->submitted & 1);
+        auto &sl = s->slot[k];
+        const size_t bytes = (size_t)s->n_windows * s->window_samples * sizeof(int16_t);
+        std::memcpy(sl.h_pcm, pcm, bytes);                      // caller's buffer is free again on return
+        SR_HIP(hipEventRecord(sl.t_submit, s->copy_stream));
+        SR_HIP(hipMemcpyAsync(sl.pcm.pcm16.p, sl.h_pcm, bytes, hipMemcpyHostToDevice, s->copy_stream));
+        SR_HIP(hipEventRecord(sl.h2d_done, s->copy_stream));
+        SR_HIP(hipStreamWaitEvent(ctx().stream, sl.h2d_done, 0));
+        mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);          // launches only (tables cached)
+        const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags);
+        SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx().stream));
+        SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
+                              hipMemcpyDeviceToHost, ctx().stream));
+        SR_HIP(hipEventRecord(sl.done, ctx().stream));
+        sl.busy = true;
+        s->in_flight.push_back(k);
+        s->submitted++;
+        return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+
+int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *device_ms) {
+    try {
+        if (!s) fail("null stream");
+        if (s->in_flight.empty()) fail("nothing in flight");
+        const int k = s->in_flight.front();
+        s->in_flight.pop_front();
+        auto &sl = s->slot[k];
+        SR_HIP(hipEventSynchronize(sl.done));
+        if (sums_out) std::memcpy(sums_out, sl.h_sums, (size_t)s->n_windows * s->n_models * sizeof(double));
+        if (argmax_out) std::memcpy(argmax_out, sl.h_argmax, (size_t)s->n_windows * sizeof(int));
+        if (device_ms) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, sl.t_submit, sl.done);
+            *device_ms = ms;
+        }
+        sl.busy = false;
+        return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+
+}  // extern "C"

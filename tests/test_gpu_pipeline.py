@@ -171,3 +171,29 @@ def test_em_training_vs_reference_trainer_golden(built_lib, gmm_golden):
         assert np.max(np.abs(w - g["em%d_w" % iters])) < 1e-5, iters
         assert np.max(np.abs(mu - g["em%d_mean" % iters])) < 1e-4, (iters, np.max(np.abs(mu - g["em%d_mean" % iters])))
         assert np.max(np.abs(sg - g["em%d_sigma" % iters]) / g["em%d_sigma" % iters]) < 5e-4, iters
+
+
+def test_serving_stream_double_buffered_equals_synchronous(built_lib):
+    """sr_stream_*: ticks submitted two deep (H2D of tick i+1 on its own HIP stream while tick i
+    computes) return exactly what the synchronous fused step returns for the same windows."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, ServingStream
+    from speaker_recognition_amd.pygmm import GMM
+    fs, nwin = 8000, 6
+    ex = MfccExtractor(fs)
+    ms = ModelSet([GMM.from_arrays(*synth.synth_gmm(32, 13, 60 + s)) for s in range(5)])
+    audio = synth.synth_speech(4, 12.0, fs)
+    ticks = [np.stack([audio[(t * nwin + j) * 3000:(t * nwin + j) * 3000 + fs] for j in range(nwin)]) for t in range(5)]
+    want = [ex.predict_batch(ms, Batch.from_pcm(list(tk)), nd=0) for tk in ticks]
+    st = ServingStream(ex, ms, nwin, fs)
+    got = []
+    st.submit(ticks[0])
+    for t in range(1, 5):
+        st.submit(ticks[t])             # two in flight
+        got.append(st.collect())
+    got.append(st.collect())
+    for (ws, wa), (gs, ga, ms_dev) in zip(want, got):
+        assert np.array_equal(ws, gs) and np.array_equal(wa, ga)
+        assert ms_dev > 0
+    with pytest.raises(Exception):
+        st.collect()                    # nothing in flight
