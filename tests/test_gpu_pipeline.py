@@ -197,3 +197,25 @@ def test_serving_stream_double_buffered_equals_synchronous(built_lib):
         assert ms_dev > 0
     with pytest.raises(Exception):
         st.collect()                    # nothing in flight
+
+
+def test_model_interface_default_mix_feature_roundtrip(built_lib, tmp_path):
+    """Reference defaults end to end: mix_feature (13 MFCC + 15 LPC = 28 dims, 32/16 ms), 32-mixture
+    speaker GMMs, dump -> load -> predict; batch prediction equals one-by-one prediction."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.interface import ModelInterface
+    fs = 16000
+    m = ModelInterface(gmm_kwargs={"seed": 2}, verbose=False)
+    for s in (0, 9, 18):
+        m.enroll("spk%d" % s, fs, synth.synth_speech(s, 8.0, fs, seed=1000 + s))
+    assert len(m.features["spk0"][0]) == 28
+    m.train()
+    assert m.gmmset.gmms[0].get_dim() == 28 and m.gmmset.gmms[0].get_nr_mixtures() == 32
+    f = str(tmp_path / "m.bin")
+    m.dump(f)
+    m2 = ModelInterface.load(f)
+    tests = [(fs, synth.synth_speech(s, 4.0, fs, seed=2000 + s)) for s in (0, 9, 18)]
+    one = [m2.predict(*t) for t in tests]
+    assert one == ["spk0", "spk9", "spk18"]
+    assert m2.predict_many(tests) == one
+    assert m2.predict(fs, np.zeros(100, np.int16)) is None          # too short: the reference swallows it (interface.py:89-93)
