@@ -103,16 +103,20 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    _lib.profile_enable(True)      # HIP-event kernel timers (pre-warms the runtime's event pool once)
     for _ in range(args.warmup):
         sums, arg = ex.predict_batch(ms, pcm, nd=ND)
-    _lib.profile_enable(True)
-    _lib.profile_reset()
+    _lib.profile_reset()           # timed region starts with zeroed timers
     barrier()
     t0 = time.perf_counter()
+    marks = []
     for _ in range(args.steps):
         sums, arg = ex.predict_batch(ms, pcm, nd=ND)
+        marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("SR_BENCH_DEBUG"):
+        print("step ends (ms since t0):", [round((m - t0) * 1e3, 2) for m in marks], "total", round(elapsed * 1e3, 2), file=sys.stderr)
     _lib.profile_enable(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)

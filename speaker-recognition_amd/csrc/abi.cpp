@@ -440,7 +440,9 @@ int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, doubl
     if (!m || !set || !pcm) fail("null argument");
     static SRBatch *feat_ws = new SRBatch();   // reused across steps: the serving loop allocates nothing
     mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
-    score_batch_set(*set, *feat_ws, sums_out, argmax_out, nullptr, flags);
+    const ScoreResult r = score_device(*set, *feat_ws, false, flags);
+    fetch_results(r, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
+                  argmax_out, nullptr);
     return 0;
     SR_CATCH(-1)
 }
@@ -454,8 +456,14 @@ int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
 }
 
 int sr_profile_enable(int on) {
+    SR_TRY
+    if (on) {
+        ensure_device();
+        profile_prewarm();
+    }
     ctx().profiling = on != 0;
     return 0;
+    SR_CATCH(-1)
 }
 
 int sr_profile_reset(void) {

@@ -85,6 +85,24 @@ ScopedKernelTimer::~ScopedKernelTimer() {
     g_pending.push_back({kind, e0, e1});
 }
 
+// The HIP runtime grows its signal pool the first time more than a handful of events have been
+// recorded (measured: one ~8 ms stall in the second profiled step).  Do that growth here, once, so
+// that timed regions bracketed by events see none of it.
+void profile_prewarm() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    std::vector<hipEvent_t> ev(64);
+    for (auto &e : ev) {
+        SR_HIP(hipEventCreate(&e));
+        SR_HIP(hipEventRecord(e, ctx().stream));
+    }
+    SR_HIP(hipStreamSynchronize(ctx().stream));
+    float ms = 0.f;
+    for (size_t i = 1; i < ev.size(); i++) (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
+    for (auto &e : ev) g_pool.push_back(e);
+}
+
 void profile_collect() {
     if (g_pending.empty()) return;
     SR_HIP(hipStreamSynchronize(ctx().stream));

@@ -51,6 +51,7 @@ struct ScopedKernelTimer {
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 void profile_collect();          // resolves pending event pairs (synchronises the stream)
+void profile_prewarm();          // grows the runtime's event/signal pools once, outside any timed region
 void profile_reset();
 void profile_get(int kind, double *ms, long *launches);
 
@@ -90,5 +91,26 @@ struct DevBuf {
 };
 
 inline void sync_stream() { SR_HIP(hipStreamSynchronize(ctx().stream)); }
+
+// Pinned host staging buffer.  A D2H copy straight into the caller's pageable memory makes the
+// runtime pin that range on the fly: measured ~8 ms whenever the caller's buffer lands on a new
+// address (a fresh numpy array); results therefore come back through this buffer + a memcpy.
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+        SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+};
 
 }  // namespace sr

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace sr {
 
@@ -468,18 +469,49 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     return r;
 }
 
+struct ResultStaging {
+    PinnedBuf<double> sums;
+    PinnedBuf<int> argmax;
+    PinnedBuf<float> frame_ll;
+};
+static ResultStaging &staging() {
+    static ResultStaging *s = new ResultStaging();   // leaked on purpose (no hipHostFree at exit)
+    return *s;
+}
+
+// Copies the last scoring call's results to host memory through pinned staging.
+void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
+                   int *argmax_out, float *frame_ll_out) {
+    auto &st = staging();
+    const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
+    const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
+    if (sums_out && U) {
+        st.sums.ensure(U * S);
+        SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+    }
+    if (argmax_out && U) {
+        st.argmax.ensure(U);
+        SR_HIP(hipMemcpyAsync(st.argmax.p, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    }
+    if (fll_n) {
+        if (stage_fll) {
+            st.frame_ll.ensure(fll_n);
+            SR_HIP(hipMemcpyAsync(st.frame_ll.p, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+        } else {
+            SR_HIP(hipMemcpyAsync(frame_ll_out, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+        }
+    }
+    sync_stream();
+    if (sums_out && U) std::memcpy(sums_out, st.sums.p, U * S * sizeof(double));
+    if (argmax_out && U) std::memcpy(argmax_out, st.argmax.p, U * sizeof(int));
+    if (stage_fll) std::memcpy(frame_ll_out, st.frame_ll.p, fll_n * sizeof(float));
+}
+
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags) {
     const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags);
-    const size_t U = (size_t)feat.n_utt, S = (size_t)set.host.n_models;
-    if (sums_out && U)
-        SR_HIP(hipMemcpyAsync(sums_out, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
-    if (argmax_out && U)
-        SR_HIP(hipMemcpyAsync(argmax_out, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-    if (frame_ll_out && r.d_frame_ll)
-        SR_HIP(hipMemcpyAsync(frame_ll_out, r.d_frame_ll, S * (size_t)feat.n_rows * sizeof(float),
-                              hipMemcpyDeviceToHost, ctx().stream));
-    sync_stream();
+    fetch_results(r, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
+                  frame_ll_out);
 }
 
 }  // namespace sr

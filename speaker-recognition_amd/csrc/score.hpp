@@ -47,6 +47,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 // Same, then copies what the caller asked for to host memory.
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags);
+// Results of the last scoring call -> host memory, through pinned staging buffers.
+void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
+                   int *argmax_out, float *frame_ll_out);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);
 
