@@ -5,15 +5,17 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/pmc
 rm -rf $O; mkdir -p $O
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="${PMC_CMD:-python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline}"
 cd /tmp
 i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+if [ -n "$PMC_SETS" ]; then IFS=';' read -ra SETS <<< "$PMC_SETS"; else SETS=(); fi
+if [ ${#SETS[@]} -eq 0 ]; then SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INST_CYCLES_VMEM" \
            "GRBM_GUI_ACTIVE GRBM_COUNT" \
            "FETCH_SIZE" \
-           "WRITE_SIZE"; do
+           "WRITE_SIZE"); fi
+for set in "${SETS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -o p$i -- $CMD > $O/p$i.log 2>&1
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)

@@ -32,20 +32,20 @@ def main():
     feats = Batch.from_features(utts)
     n = feats.n_rows
     flops = float(n) * S * K * (4 * D + 6)
-    # (frames per lane | -FT for the matrix-core engine, packed, groups)
-    variants = [(4, 1, 0), (4, -1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0), (-3, 0, 0)]
+    # (frames per lane | -FT for the fp32 matrix-core engine | -(10+FT) for the split-bf16 one, packed, groups)
+    variants = [(4, 1, 0), (4, -1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0), (-3, 0, 0), (-11, 0, 0), (-12, 0, 0)]
     if os.environ.get('TUNE_FEW'):
-        variants = [(4, 1, 0), (2, 1, 0), (-1, 0, 0), (-2, 0, 0)]
+        variants = [(4, 1, 0), (-1, 0, 0), (-2, 0, 0), (-11, 0, 0), (-12, 0, 0)]
     if D > 40:
-        variants = [v for v in variants if v[0] <= 2 and v[0] >= -3]
+        variants = [v for v in variants if v[0] <= 2 and v[0] >= -3 or v[0] == -11]
     ref = None
     res = {v: [] for v in variants}
     _lib.profile_enable(True)
     for r in range(rounds + 1):
         for v in variants:
             F, pk, G = v
-            _lib.set_option("score_engine", 2 if F < 0 else 1)
-            _lib.set_option("score_mfma_ft", -F if F < 0 else 0)
+            _lib.set_option("score_engine", 3 if F <= -10 else 2 if F < 0 else 1)
+            _lib.set_option("score_mfma_ft", -F - 10 if F <= -10 else -F if F < 0 else 0)
             _lib.set_option("score_frames_per_lane", F if F > 0 else 0)
             _lib.set_option("score_packed", pk)
             _lib.set_option("score_model_groups", G)

@@ -1,0 +1,122 @@
+// Microbenchmark 3: the split-bf16 scoring tile -- per 32x32 (mixture x frame) tile 6*KS
+// v_mfma_f32_32x32x16_bf16 on one accumulator (A parts from LDS, B parts resident), then the online
+// log2-sum-exp over the 16 accumulator rows.  MODE 0: MFMA only; 1: epilogue after the chain (the
+// waves of a SIMD overlap each other at best); 2: the epilogue of tile t-1 interleaved with the
+// MFMAs of tile t inside one wave (two accumulators, sched_group_barrier pattern).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int KS = 5;
+
+__device__ __forceinline__ void chain(f32x16 &acc, const uint4 *at, const bf16x8 (&b)[KS][3]) {
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint4 n0 = at[0], n1 = at[64], n2 = at[128];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, n0), a1 = __builtin_bit_cast(bf16x8, n1), a2 = __builtin_bit_cast(bf16x8, n2);
+        if (ks + 1 < KS) { n0 = at[((ks + 1) * 3) * 64]; n1 = at[((ks + 1) * 3 + 1) * 64]; n2 = at[((ks + 1) * 3 + 2) * 64]; }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[ks][0], ks == 0 ? zero16 : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][0], acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void lse(const f32x16 &acc, float &m, float &ssum) {
+    float mx = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; r++) mx = fmaxf(mx, acc[r]);
+    const float mn = fmaxf(m, mx);
+    float e = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) e += __builtin_amdgcn_exp2f(acc[r] - mn);
+    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), e);
+    m = mn;
+}
+
+template <int MODE, int WPE>
+__global__ __launch_bounds__(256, WPE) void k(float *out, const uint4 *bin, int tiles) {
+    __shared__ uint4 lds[2][KS * 3 * 64];
+    for (int i = threadIdx.x; i < 2 * KS * 3 * 64; i += 256) (&lds[0][0])[i] = make_uint4(0x3c003c00u + i, 0x3a003b00u, 0x38003900u, 0x36003700u);
+    __syncthreads();
+    bf16x8 b[KS][3];
+    for (int ks = 0; ks < KS; ks++)
+        for (int p = 0; p < 3; p++) b[ks][p] = __builtin_bit_cast(bf16x8, bin[(threadIdx.x * 7 + ks * 3 + p) & 255]);
+    const int lane = threadIdx.x & 63;
+    float m = -1e30f, ssum = 0.f;
+    if (MODE == 0 || MODE == 1) {
+        for (int t = 0; t < tiles; t++) {
+            f32x16 acc;
+            chain(acc, &lds[t & 1][lane], b);
+            if (MODE == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[r]));
+                m = acc[3];
+            } else {
+                lse(acc, m, ssum);
+            }
+        }
+    } else {
+        f32x16 accA, accB;
+        chain(accB, &lds[1][lane], b);
+        for (int t = 0; t < tiles; t += 2) {
+            chain(accA, &lds[0][lane], b);
+            lse(accB, m, ssum);
+            if (MODE == 2) {
+#pragma unroll
+                for (int i = 0; i < 6 * KS; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+                }
+            }
+            chain(accB, &lds[1][lane], b);
+            lse(accA, m, ssum);
+            if (MODE == 2) {
+#pragma unroll
+                for (int i = 0; i < 6 * KS; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+        }
+        lse(accB, m, ssum);
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = m + ssum;
+}
+
+template <int MODE, int WPE>
+void run(const char *name, int blocks_per_cu, const uint4 *bin) {
+    int tiles = 800, grid = 256 * blocks_per_cu;
+    float *out;
+    hipMalloc(&out, (size_t)grid * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, 4);
+    hipDeviceSynchronize();
+    float best = 1e9;
+    for (int r = 0; r < 3; r++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, tiles);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    double mfmas = (double)grid * 4 * tiles * 6 * KS;
+    double tf = mfmas * 2.0 * 32 * 32 * 16 / (best * 1e-3) / 1e12;
+    printf("%-44s waves/SIMD=%d  %.3f ms  %.0f TFLOP/s bf16 (%.1f%% of 2516)\n", name, blocks_per_cu, best, tf, tf / 25.16);
+    hipFree(out);
+}
+
+int main() {
+    uint4 *bin; hipMalloc(&bin, 4096); hipMemset(bin, 0x3c, 4096);
+    for (int w = 1; w <= 4; w++) {
+        run<0, 4>("MFMA only", w, bin);
+        run<1, 4>("MFMA then LSE epilogue", w, bin);
+        run<3, 3>("pipelined epilogue, compiler schedule", w, bin);
+        run<2, 3>("pipelined epilogue, 1 MFMA : 3 VALU", w, bin);
+    }
+    return 0;
+}

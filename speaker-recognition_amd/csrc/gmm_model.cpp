@@ -228,4 +228,110 @@ PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp) {
     return pm;
 }
 
+static inline uint32_t f32_bits(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    return u;
+}
+static inline float bits_f32(uint32_t u) {
+    float v;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+static inline uint32_t bf16_rne_bits(float v) {   // fp32 bit pattern of v rounded to bf16
+    const uint32_t u = f32_bits(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+
+void split_bf16x3(float v, uint16_t out[3]) {
+    const uint32_t h = bf16_rne_bits(v);
+    const float r1 = v - bits_f32(h);            // exact in fp32
+    const uint32_t m = bf16_rne_bits(r1);
+    const float r2 = r1 - bits_f32(m);           // exact
+    const uint32_t l = bf16_rne_bits(r2);
+    out[0] = (uint16_t)(h >> 16);
+    out[1] = (uint16_t)(m >> 16);
+    out[2] = (uint16_t)(l >> 16);
+}
+
+PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models) {
+    PackedBf16x3 pm;
+    const int dim = models[0]->dim;
+    pm.ks = (dim + 1 + 7) / 8;
+    const int KS = pm.ks;
+    const size_t tile_u16 = (size_t)KS * 3 * 64 * 8;
+    const double LOG2E = 1.4426950408889634073599;
+    const double SQRT_2_PI = 2.5066282746310002;
+    pm.center.assign(dim, 0.0f);
+    {
+        std::vector<double> acc(dim, 0.0);
+        size_t cnt = 0;
+        for (const GMM *g : models) {
+            for (int k = 0; k < g->nr_mixtures; k++)
+                for (int d = 0; d < dim; d++) acc[d] += g->mean[(size_t)k * dim + d];
+            cnt += (size_t)g->nr_mixtures;
+        }
+        for (int d = 0; d < dim; d++) pm.center[d] = (float)(acc[d] / (double)cnt);
+    }
+    size_t live = 0, padded = 0;
+    pm.model_chunk_begin.push_back(0);
+    // slot (ks, hh, j): feature d = 8 ks + j; hh = 0 -> A2 (pairs with x'^2), hh = 1 -> A1 (pairs with
+    // x'); the last upper slot (d = 8 KS - 1 >= dim) carries C (pairs with the constant 1)
+    std::vector<float> sq((size_t)KS * 8), lin((size_t)KS * 8);
+    for (size_t s = 0; s < models.size(); s++) {
+        const GMM &g = *models[s];
+        const int K = g.nr_mixtures;
+        const int n_tiles = (K + MT - 1) / MT;
+        const size_t base = pm.params.size();
+        pm.params.resize(base + (size_t)n_tiles * tile_u16, 0);
+        live += (size_t)K;
+        padded += (size_t)n_tiles * MT;
+        for (int t = 0; t < n_tiles; t++) {
+            uint16_t *tile = pm.params.data() + base + (size_t)t * tile_u16;
+            for (int i = 0; i < MT; i++) {
+                const int k = t * MT + i;
+                std::fill(sq.begin(), sq.end(), 0.0f);
+                std::fill(lin.begin(), lin.end(), 0.0f);
+                float cst_f = NEG_BIG;
+                if (k < K) {
+                    double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                    double a = 0.0;
+                    for (int d = 0; d < dim; d++) {
+                        const double sg = g.sigma[(size_t)k * dim + d];
+                        const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
+                        const double iv = 1.0 / (sg * sg);
+                        sq[d] = (float)(-0.5 * LOG2E * iv);
+                        lin[d] = (float)(LOG2E * mu * iv);
+                        cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
+                        a += mu * mu * iv;
+                    }
+                    pm.amp = std::max(pm.amp, a);
+                    cst *= LOG2E;
+                    if (std::isfinite(cst) && cst > (double)NEG_BIG) cst_f = (float)cst;
+                }
+                lin[(size_t)KS * 8 - 1] = cst_f;
+                for (int d = 0; d < KS * 8; d++) {
+                    const int ks = d >> 3, j = d & 7;
+                    for (int hh = 0; hh < 2; hh++) {
+                        uint16_t parts[3];
+                        split_bf16x3(hh ? lin[d] : sq[d], parts);
+                        const int lane = i + 32 * hh;
+                        for (int p = 0; p < 3; p++)
+                            tile[(((size_t)ks * 3 + p) * 64 + lane) * 8 + j] = parts[p];
+                    }
+                }
+            }
+            ChunkDesc cd;
+            cd.offset_f4 = (uint32_t)((base + (size_t)t * tile_u16) / 8);
+            cd.n_records = 1;
+            cd.model_done = (t + 1 == n_tiles) ? (int)s : -1;
+            cd.pad = 0;
+            pm.chunks.push_back(cd);
+        }
+        pm.model_chunk_begin.push_back((int)pm.chunks.size());
+    }
+    pm.pad_waste = 1.0 - (double)live / (double)padded;
+    return pm;
+}
+
 }  // namespace sr

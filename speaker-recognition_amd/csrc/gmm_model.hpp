@@ -83,6 +83,27 @@ struct PackedMfma {
 };
 PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp);
 
+// ---- third layout: the same expanded form with every coefficient split into three bf16 parts
+// (hi + mid + lo carries all 24 significand bits of the fp32 value), for the bf16 matrix cores:
+//   a*b ~= a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)      (the three dropped products are < 2^-24 |a b|)
+// six v_mfma_f32_32x32x16_bf16 products with fp32 accumulation, 16x the fp32 MFMA rate each.
+// Contraction: KS = ceil((D+1)/8) steps of 16 slots; slot (ks, hh, j) belongs to feature d = 8 ks + j
+// and holds A2_kd (hh = 0, against x'_d^2) or A1_kd (hh = 1, against x'_d); the last upper slot
+// (d = 8 KS - 1 >= D) holds C_k against the constant 1.  A mixture tile = 32 mixtures; its image is
+// [ks][part][lane][8 bf16]: lane l supplies mixture l & 31, hh = l >> 5, j = 0..7 (one 16-byte LDS
+// read per lane and part).
+struct PackedBf16x3 {
+    int ks = 0;
+    std::vector<uint16_t> params;    // 16-byte granular (8 bf16)
+    std::vector<ChunkDesc> chunks;   // one mixture tile per chunk; offset in 16-byte units
+    std::vector<int> model_chunk_begin;
+    std::vector<float> center;       // [dim]
+    double amp = 0.0;
+    double pad_waste = 0.0;
+};
+PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models);
+void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts
+
 }  // namespace sr
 
 // Device-resident speaker set (C ABI handle `SRModelSet *`).
@@ -93,5 +114,9 @@ struct SRModelSet {
     sr::PackedMfma mfma;             // expanded-form layout for the matrix-core engine
     sr::DevBuf<float> d_mfma_params, d_center;
     sr::DevBuf<sr::ChunkDesc> d_mfma_chunks;
+    sr::PackedBf16x3 bx3;            // split-bf16 layout for the bf16 matrix-core engine
+    sr::DevBuf<uint16_t> d_bx3_params;
+    sr::DevBuf<float> d_bx3_center;
+    sr::DevBuf<sr::ChunkDesc> d_bx3_chunks;
     int device = -1;
 };

@@ -355,6 +355,14 @@ static void ensure_mfma_layout(SRModelSet &s) {
     sync_stream();
 }
 
+static void ensure_bx3_layout(SRModelSet &s) {
+    if (s.d_bx3_params.p) return;
+    s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
+    s.d_bx3_chunks.upload(s.bx3.chunks.data(), s.bx3.chunks.size());
+    s.d_bx3_center.upload(s.bx3.center.data(), s.bx3.center.size());
+    sync_stream();
+}
+
 ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags) {
     ensure_device();
     if (feat.kind != SRBatch::FEATURES) fail("scoring needs a feature batch");
@@ -366,13 +374,20 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     // engine choice (see score.hpp): the matrix-core kernel when its layout exists, is well
     // conditioned and not mostly padding; the vector-ALU kernel otherwise or when forced
     const bool mfma_ok = !set.mfma.params.empty();
-    bool use_mfma = false;
-    if (opt.engine == 2) {
+    const bool bx3_ok = !set.bx3.params.empty();
+    bool use_mfma = false, use_bx3 = false;
+    if (opt.engine == 3) {
+        if (!bx3_ok) fail("split-bf16 engine requested but the set has no bf16x3 layout");
+        use_bx3 = true;
+    } else if (opt.engine == 2) {
         if (!mfma_ok) fail("matrix-core engine requested but the set has no expanded-form layout");
         use_mfma = true;
     } else if (opt.engine == 0) {
-        use_mfma = mfma_ok && set.mfma.amp <= MFMA_MAX_AMP && set.mfma.pad_waste <= MFMA_MAX_PAD_WASTE;
+        // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
+        // shape swept (profiles/r01_tune_score.log); the fp32 one stays selectable (score_engine = 2)
+        use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
     }
+    const bool use_mat = use_mfma || use_bx3;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     int FT = opt.mfma_ft;
@@ -386,7 +401,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         FT = ((S >= 8 && tiles_per_model >= 4.0) || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
     }
     if (DP > 40 && FT > 3) FT = 3;
-    TileTable &tt = feat.tiles_for(use_mfma ? 128 * FT : 256 * F);
+    if (use_bx3) FT = opt.mfma_ft ? std::min(opt.mfma_ft, bx3_max_ft(set.bx3.ks)) : 1;   // one column tile per wave won or tied every sweep
+    TileTable &tt = feat.tiles_for(use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
@@ -400,7 +416,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
         G = std::max(1, std::min(G, S));
-        const std::vector<int> &mcb = use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
+        const std::vector<int> &mcb = use_bx3 ? set.bx3.model_chunk_begin
+                                      : use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
         std::vector<int> gcb(G + 1);
         for (int g = 0; g <= G; g++) {
             const int model = (int)(((int64_t)g * S) / G);
@@ -415,15 +432,16 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         w.partial.ensure((size_t)tt.n_tiles * S * 4);
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
-        if (use_mfma) {
-            ensure_mfma_layout(set);
+        if (use_mat) {
+            if (use_bx3) ensure_bx3_layout(set); else ensure_mfma_layout(set);
             MfmaLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
-            a.params = reinterpret_cast<const float4 *>(set.d_mfma_params.p);
-            a.chunks = set.d_mfma_chunks.p;
+            a.params = use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
+                               : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
+            a.chunks = use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
             a.group_chunk_begin = w.group_chunk_begin.p;
-            a.center = set.d_center.p;
+            a.center = use_bx3 ? set.d_bx3_center.p : set.d_center.p;
             a.partial = w.partial.p;
             a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
             a.n_frames = feat.n_rows;
@@ -432,9 +450,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.clamp = (flags & 1) ? 1 : 0;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
-            snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
             ScopedKernelTimer t(T_SCORE);
-            launch_score_mfma(a, DP, FT);
+            if (use_bx3) {
+                snprintf(g_last_kernel, sizeof g_last_kernel,
+                         "gmm_score_bf16x3_kernel<%d,%d> (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)", set.bx3.ks, FT);
+                launch_score_bf16x3(a, set.bx3.ks, FT);
+            } else {
+                snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
+                launch_score_mfma(a, DP, FT);
+            }
         } else {
             ScoreArgs a;
             a.X = feat.data.p;

@@ -10,12 +10,13 @@ struct ScoreOptions {
     int frames_per_lane = 0;   // 0 = auto; 1, 2 or 4 frames resident per lane
     int model_groups = 0;      // 0 = auto; workgroups per frame tile along the model axis
     int packed = 0;            // -1 = scalar v_fma_f32; 0 (auto) / 1 = v_pk_fma_f32, two frames per VGPR pair
-    int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel
-    int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernel (0 = auto)
+    int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel;
+                               // 3 = split-bf16 (3 parts, 6 products) matrix-core kernel
+    int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
 };
 
-// The matrix-core engine is used when the expanded form is well conditioned in fp32 and the
-// 32-mixture tiles are not mostly padding.
+// The matrix-core engines are used when the expanded form is well conditioned in fp32 and the
+// 32-mixture tiles are not mostly padding; otherwise the 2-FMA vector kernel (direct form).
 constexpr double MFMA_MAX_AMP = 2000.0;      // max_k sum_d (mu'_d/sigma_d)^2
 constexpr double MFMA_MAX_PAD_WASTE = 0.25;
 
@@ -32,6 +33,8 @@ struct MfmaLaunch {
     int dim, n_models, clamp, n_groups, n_tiles;
 };
 void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
+void launch_score_bf16x3(const MfmaLaunch &a, int KS, int FT);   // a.params = the bf16x3 image
+int bx3_max_ft(int ks);
 ScoreOptions &score_options();
 const char *last_score_kernel();   // name of the kernel variant the last scoring call launched
 

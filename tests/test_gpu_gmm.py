@@ -34,10 +34,10 @@ def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
         m = _gmm(g, c)
         ref = g[c + "_ll"]
         for F, pk, eng, ft in ((0, 0, 1, 0), (1, 0, 1, 0), (2, -1, 1, 0), (4, -1, 1, 0), (2, 1, 1, 0), (4, 1, 1, 0),
-                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 0, 0)):
+                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 3, 1), (0, 0, 3, 2), (0, 0, 0, 0)):
             _lib.set_option("score_frames_per_lane", F)
             _lib.set_option("score_packed", pk)
-            _lib.set_option("score_engine", eng)      # 1: vector-ALU kernel, 2: matrix-core kernel, 0: auto
+            _lib.set_option("score_engine", eng)      # 1: vector ALU, 2: fp32 matrix cores, 3: split-bf16 matrix cores, 0: auto
             _lib.set_option("score_mfma_ft", ft)
             ll = m.score(g[c + "_X"])
             assert ll_close(ll, ref) < TOL, (c, F, pk, eng, ft, ll_close(ll, ref))
@@ -92,7 +92,7 @@ def test_speaker_set_ragged_batch_vs_oracle(built_lib, oracle_built):
     off = np.concatenate([[0], np.cumsum(lens)])
     want_sums = np.array([[want[s, off[u]:off[u + 1]].sum() for s in range(S)] for u in range(len(lens))])
     for F, pk, G, eng in ((0, 0, 0, 1), (1, 0, 1, 1), (2, -1, 3, 1), (4, -1, 7, 1), (4, 1, 2, 1), (2, 1, 0, 1),
-                          (0, 0, 0, 2), (0, 0, 3, 2), (0, 0, 0, 0)):
+                          (0, 0, 0, 2), (0, 0, 3, 2), (0, 0, 0, 3), (0, 0, 2, 3), (0, 0, 0, 0)):
         _lib.set_option("score_frames_per_lane", F)
         _lib.set_option("score_packed", pk)
         _lib.set_option("score_model_groups", G)
@@ -175,7 +175,7 @@ def test_cfg2_ubm_map_speakers_vs_oracle(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
-    for eng in (1, 2, 0):
+    for eng in (1, 2, 3, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         assert ll_close(fll, want) < TOL, (eng, ll_close(fll, want))
@@ -200,7 +200,7 @@ def test_streaming_shape_short_windows(built_lib, oracle_built):
     X = np.concatenate(utts).astype(np.float64)
     want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
     off = np.concatenate([[0], np.cumsum(lens)])
-    for eng in (1, 2, 0):
+    for eng in (1, 2, 3, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         assert ll_close(fll, want) < TOL, eng
@@ -228,7 +228,7 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
         utts = [synth.draw_frames(models[u % 3], n, 40 + u) for u, n in enumerate([3, 130, 257, 1])]
         X = np.concatenate(utts).astype(np.float64)
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
-        for eng in (1, 2):
+        for eng in (1, 2, 3):
             _lib.set_option("score_engine", eng)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
             assert ll_close(fll, want) < TOL, (K, D, eng, ll_close(fll, want))
@@ -253,3 +253,45 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
         g13.score(np.zeros((10, 12), np.float32))
     with pytest.raises(_lib.SRError, match="dim"):
         ModelSet([g13, GMM.from_arrays(*synth.synth_gmm(4, 12, 1))])
+
+
+def test_engine_selection_and_split_bf16_accuracy(built_lib, oracle_built):
+    """The dispatcher: well-conditioned sets take the split-bf16 matrix-core kernel, sets whose
+    expanded form would cancel (means far apart in units of sigma) or whose 32-mixture tiles are
+    mostly padding take the direct-form vector kernel.  And the split is fp32-grade: against the
+    float64 oracle its per-frame error is no larger than twice the fp32 FMA-chain engines'."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(3)
+    S, K, D = 5, 64, 39
+    models = [synth.synth_gmm(K, D, 70 + s) for s in range(S)]
+    utts = [synth.draw_frames(models[u % S], 700, 10 + u, outlier_frac=0.0) for u in range(4)]
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=False) for m in models])
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    err = {}
+    for eng in (1, 2, 3, 0):
+        _lib.set_option("score_engine", eng)
+        sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+        err[eng] = float(np.max(np.abs(fll - want) / np.maximum(1.0, np.abs(want))))
+        if eng == 0:
+            assert "bf16x3" in _lib.last_score_kernel()
+    assert err[3] < 5e-6 and err[3] <= 2.0 * max(err[1], err[2]) + 1e-7, err
+    _lib.set_option("score_engine", 0)
+    # ill-conditioned expanded form: means ~30 sigma apart -> direct form on the vector ALU
+    far = []
+    for s in range(3):
+        w, mu, sg = synth.synth_gmm(K, D, 200 + s)
+        far.append((w, mu * 40.0, sg))
+    utts = [synth.draw_frames(far[u % 3], 300, 90 + u, outlier_frac=0.0) for u in range(3)]
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in far])
+    sums, arg, fll = ModelSet([GMM.from_arrays(*m) for m in far]).score(Batch.from_features(utts), frame_ll=True)
+    assert "vector ALU" in _lib.last_score_kernel()
+    assert ll_close(fll, want) < TOL
+    # K = 8: three quarters of every 32-mixture tile would be padding -> vector kernel
+    small = [synth.synth_gmm(8, 13, 300 + s) for s in range(3)]
+    ModelSet([GMM.from_arrays(*m) for m in small]).score(Batch.from_features([synth.draw_frames(small[0], 200, 1)]))
+    assert "vector ALU" in _lib.last_score_kernel()
