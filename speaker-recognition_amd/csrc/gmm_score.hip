@@ -225,7 +225,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
 // reference's argmax -- first maximum wins (gmmset.py:62-64, `max(enumerate(scores), key=...)`).
 __global__ __launch_bounds__(256)
 void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n_models,
-                         double *sums, int *argmax) {
+                         int per_tile, double *sums, int *argmax) {
     const int u = blockIdx.x;
     const int tb = utt_tile_begin[u], te = utt_tile_begin[u + 1];
     double best = -INFINITY;
@@ -233,11 +233,9 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
     for (int s = threadIdx.x; s < n_models; s += 256) {
         double acc = 0.0;
         for (int t = tb; t < te; t++) {
-            const double *p = partial + ((int64_t)t * n_models + s) * 4;
-            acc += p[0];
-            acc += p[1];
-            acc += p[2];
-            acc += p[3];
+            // per_tile = 4: one double per wave of the tile's workgroup; 1: already combined
+            const double *p = partial + ((int64_t)t * n_models + s) * per_tile;
+            for (int i = 0; i < per_tile; i++) acc += p[i];
         }
         sums[(int64_t)u * n_models + s] = acc;
         if (acc > best) {
@@ -412,7 +410,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // model groups: enough workgroups to fill the chip several times over
         int G = opt.model_groups;
         if (G <= 0) {
-            const int target = ctx().n_cu * 3 * 16;   // >= ~16 rounds of resident workgroups: short tail
+            // enough workgroups for a short tail: >= ~16 rounds of resident ones for the vector and
+            // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
+            // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
+            const int target = use_bx3 ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
         G = std::max(1, std::min(G, S));
@@ -483,7 +484,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, w.sums.p, w.argmax.p);
+                           w.partial.p, tt.d_utt_tile_begin.p, S, use_bx3 ? 1 : 4, w.sums.p, w.argmax.p);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;

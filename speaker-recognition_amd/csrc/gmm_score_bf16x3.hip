@@ -55,6 +55,7 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
     constexpr int PF = (TILE_U4 + 255) / 256;
     __shared__ uint4 lds_a[TILE_U4];
     __shared__ uint4 lds_b[TILE_U4];
+    __shared__ double close_slot[2][4];        // the four waves' sums of a closed model, two generations
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,7 +101,7 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
         const float *src = X + row[ft] * dim;
         float xs[8 * KS];
 #pragma unroll
-        for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < dim ? d : dim - 1];
+        for (int d = 0; d < 8 * KS; d++) xs[d] = __builtin_nontemporal_load(src + (d < dim ? d : dim - 1));   // read once: keep L2 for the mixture tiles
         // keep the loads unconditional and batched: without this the compiler sinks each one into
         // its own `d < dim` branch with a full wait
 #pragma unroll
@@ -146,7 +147,19 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
     }
     __syncthreads();
 
+    // A model's four wave sums meet in LDS and leave as ONE double per (tile, model): the store
+    // happens after the chunk's closing barrier, at the top of the next chunk (or after the loop).
+    int pending_model = -1, pending_gen = 0, gen = 0;
+    auto flush_pending = [&]() {
+        if (pending_model >= 0 && tid == 0) {
+            const double *p = close_slot[pending_gen];
+            partial[(int64_t)tile_id * n_models + pending_model] = ((p[0] + p[1]) + p[2]) + p[3];
+        }
+        pending_model = -1;
+    };
+
     auto do_chunk = [&](const uint4 *cur, uint4 *other, int c) {
+        flush_pending();
         const int model_done = done_next;
         if (c + 1 < chunk_end) {
             stage(other, c + 1);
@@ -224,7 +237,10 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
                 ssum[ft] = 0.0f;
             }
             mine = wave_sum_f64(mine);
-            if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
+            if (lane == 0) close_slot[gen][wave] = mine;
+            pending_model = s;
+            pending_gen = gen;
+            gen ^= 1;
         }
         __syncthreads();
     };
@@ -233,6 +249,7 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
         do_chunk(lds_a, lds_b, c);
         if (c + 1 < chunk_end) do_chunk(lds_b, lds_a, c + 1);
     }
+    flush_pending();
 }
 
 template <int KS, int FT>
