@@ -101,7 +101,7 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
         const float *src = X + row[ft] * dim;
         float xs[8 * KS];
 #pragma unroll
-        for (int d = 0; d < 8 * KS; d++) xs[d] = __builtin_nontemporal_load(src + (d < dim ? d : dim - 1));   // read once: keep L2 for the mixture tiles
+        for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < dim ? d : dim - 1];
         // keep the loads unconditional and batched: without this the compiler sinks each one into
         // its own `d < dim` branch with a full wait
 #pragma unroll
