@@ -159,6 +159,36 @@ def test_full_size_cfg1_properties(built_lib, oracle_built):
         assert int(np.argmax(want)) == arg[u]
 
 
+def test_full_size_cfg2_properties(built_lib, oracle_built):
+    """BASELINE configs[2] at full size (1e7 frames, 39-dim, a 512-mixture UBM + 200 MAP-adapted
+    speakers of 512 mixtures each): 200 distinct utterances repeated 50 times.  Size-independent
+    properties: every speaker's utterance is won by that speaker among the speakers, repeated
+    utterances give bit-identical sums wherever they sit in the batch, the open-set margin
+    (best speaker - UBM, gmmset.py:69-81) is positive; two utterances are checked against the
+    oracle on a subset of the models."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    S, K, D, T, REP = 200, 512, 39, 1000, 50
+    ubm = synth.synth_gmm(K, D, 99)
+    spk = [synth.synth_map_speaker(ubm, 500 + s) for s in range(S)]
+    models = [ubm] + spk
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    base = [synth.draw_frames(spk[s], T, 9000 + s) for s in range(S)]
+    utts = [base[u % S] for u in range(S * REP)]
+    sums, arg = ms.score(Batch.from_features(utts))
+    assert sums.shape == (S * REP, S + 1) and np.all(np.isfinite(sums))
+    assert np.array_equal(np.argmax(sums[:, 1:], axis=1), np.arange(S * REP) % S)
+    assert np.all(sums[:, 1:].max(axis=1) > sums[:, 0])
+    for r in (1, 17, REP - 1):
+        assert np.array_equal(sums[r * S:(r + 1) * S], sums[:S])
+    for u in (3, 9999):
+        sub = [0, 1 + u % S, 1 + (u + 1) % S, 1 + (u + 77) % S]
+        want = np.array([go.score_all(go.GMMParams(*models[i]), utts[u].astype(np.float64)) for i in sub])
+        assert np.max(np.abs(sums[u, sub] - want) / np.abs(want)) < 2e-5
+
+
 def test_cfg2_ubm_map_speakers_vs_oracle(built_lib, oracle_built):
     """BASELINE configs[2] shape at a size the oracle can follow: a 512-mixture UBM plus MAP-adapted
     speaker models (means shifted, sigmas and weights shared -- gmmubm.cc:40-81), 39-dim; per-frame
