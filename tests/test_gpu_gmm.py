@@ -325,3 +325,41 @@ def test_engine_selection_and_split_bf16_accuracy(built_lib, oracle_built):
     small = [synth.synth_gmm(8, 13, 300 + s) for s in range(3)]
     ModelSet([GMM.from_arrays(*m) for m in small]).score(Batch.from_features([synth.draw_frames(small[0], 200, 1)]))
     assert "vector ALU" in _lib.last_score_kernel()
+
+
+def test_random_shapes_all_engines(built_lib, oracle_built):
+    """Seeded sweep over random shapes -- dims 1..64, mixtures 1..300, 1..6 models of different sizes,
+    ragged utterances incl. empty ones -- with every engine forced in turn: per-frame LL, sums and
+    argmax against the oracle."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(2024)
+    for case in range(48):
+        D = int(rng.integers(1, 65))
+        S = int(rng.integers(1, 7))
+        Ks = [int(rng.integers(1, 301)) for _ in range(S)]
+        models = [synth.synth_gmm(Ks[s], D, 4000 + 10 * case + s) for s in range(S)]
+        lens = [int(v) for v in rng.choice([0, 1, 2, 31, 32, 33, 127, 128, 129, 255, 256, 257, 300, 640], size=int(rng.integers(1, 7)))]
+        if sum(lens) == 0:
+            lens.append(5)
+        utts = [synth.draw_frames(models[u % S], n, 77 + 100 * case + u, outlier_frac=0.02) for u, n in enumerate(lens)]
+        X = np.concatenate(utts).astype(np.float64)
+        want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+        off = np.concatenate([[0], np.cumsum(lens)])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        for eng in (1, 2, 3, 0):
+            _lib.set_option("score_engine", eng)
+            _lib.set_option("score_model_groups", int(rng.integers(0, 4)))
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            assert ll_close(fll, want) < TOL, (case, D, Ks, lens, eng, ll_close(fll, want))
+            for u, n in enumerate(lens):
+                if n == 0:
+                    assert arg[u] == -1 and np.all(sums[u] == 0)
+                    continue
+                w = want[:, off[u]:off[u + 1]].sum(axis=1)
+                assert np.max(np.abs(sums[u] - w)) < 2e-5 * n * 60 + 1e-3, (case, eng, u)
+                order = np.sort(w)
+                if S == 1 or order[-1] - order[-2] > 1e-3 * n:      # skip near-ties
+                    assert arg[u] == int(np.argmax(w)), (case, eng, u)
