@@ -148,6 +148,7 @@ int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, doubl
  * waits for the oldest tick and hands back sums[n_windows][S], argmax[n_windows] and the
  * device-side time from the start of its H2D to its last kernel. */
 typedef struct SRStream SRStream;
+#define SR_STREAM_GRAPH 0x100   /* flags: replay each tick's kernels + result copies as one hipGraph */
 SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t window_samples, int nd,
                            int flags);
 int sr_stream_submit(SRStream *s, const int16_t *pcm /* [n_windows][window_samples] */);

@@ -52,8 +52,8 @@ def main():
                                                  "windows_per_s": n_streams / (np.percentile(ts, 50) * 1e-3),
                                                  "realtime_factor": n_streams * 1.0 / (np.percentile(ts, 50) * 1e-3)}
     # double-buffered session: H2D of tick i+1 (own HIP stream, pinned memory) under the kernels of tick i
-    for n_streams in (1, 64, 1024):
-        st = ServingStream(ex, models, n_streams, fs)
+    for n_streams, graph in ((1, False), (1, True), (64, False), (64, True), (1024, False), (1024, True)):
+        st = ServingStream(ex, models, n_streams, fs, graph=graph)
         cat = np.stack([audio[(j % 39) * fs // 2:(j % 39) * fs // 2 + fs] for j in range(n_streams)])
         n_ticks = 60
         st.submit(cat)
@@ -64,7 +64,17 @@ def main():
             dev.append(st.collect()[2])
         st.collect()
         dt = (time.perf_counter() - t0) / n_ticks
-        out["double_buffered_%d_streams" % n_streams] = {"tick_ms": dt * 1e3, "windows_per_s": n_streams / dt,
+        # one tick at a time: submit -> collect, host-observed
+        one = []
+        for i in range(200):
+            t1 = time.perf_counter()
+            st.submit(cat)
+            st.collect()
+            one.append((time.perf_counter() - t1) * 1e3)
+        one = np.array(one[20:])
+        out["double_buffered_%d_streams%s" % (n_streams, "_hipgraph" if graph else "")] = {
+            "sync_tick_latency_ms_p50": float(np.percentile(one, 50)), "sync_tick_latency_ms_p99": float(np.percentile(one, 99)),
+            "tick_ms": dt * 1e3, "windows_per_s": n_streams / dt,
                                                          "device_ms_per_tick_p50": float(np.percentile(dev, 50))}
     print(json.dumps(out))
 

@@ -204,14 +204,15 @@ class MfccExtractor:
 class ServingStream:
     """Double-buffered fixed-shape serving session (sr_stream_*): ``n_windows`` windows of
     ``window_samples`` int16 samples per tick; ``submit`` queues a tick (H2D on its own HIP stream,
-    overlapping the previous tick's kernels), ``collect`` returns the oldest tick's decisions."""
+    overlapping the previous tick's kernels), ``collect`` returns the oldest tick's decisions.
+    ``graph=True`` replays each tick's kernels and result copies as one captured hipGraph."""
 
     def __init__(self, extractor: MfccExtractor, models: ModelSet, n_windows: int, window_samples: int,
-                 nd: int = 0, clamp_compat: bool = True):
+                 nd: int = 0, clamp_compat: bool = True, graph: bool = False):
         self._keep = (extractor, models)
         self.n_windows, self.window_samples, self.n_models = int(n_windows), int(window_samples), len(models)
         h = lib().sr_stream_create(extractor._h, models._h, self.n_windows, self.window_samples, int(nd),
-                                   _lib.SR_CLAMP_COMPAT if clamp_compat else 0)
+                                   (_lib.SR_CLAMP_COMPAT if clamp_compat else 0) | (_lib.SR_STREAM_GRAPH if graph else 0))
         if not h:
             raise SRError("sr_stream_create failed: %s" % _lib.last_error())
         self._h = C.c_void_p(h)

@@ -28,6 +28,8 @@ void fail(const char *fmt, ...) {
     throw Error(buf);
 }
 
+std::atomic<long> g_devbuf_epoch{0};
+
 static Ctx g_ctx;
 static bool g_ready = false;
 static std::mutex g_mu;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -55,6 +56,11 @@ void profile_prewarm();          // grows the runtime's event/signal pools once,
 void profile_reset();
 void profile_get(int kind, double *ms, long *launches);
 
+// Bumped by every device (re)allocation and every upload through DevBuf: a captured hipGraph holds
+// raw pointers into, and depends on the contents of, the library's cached workspaces, so it is
+// re-captured when this moved (stream.cpp).
+extern std::atomic<long> g_devbuf_epoch;
+
 // ---- device buffer ----
 template <typename T>
 struct DevBuf {
@@ -73,16 +79,21 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
+        g_devbuf_epoch++;
         if (count) SR_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
     }
     void ensure(size_t count) { if (count > n) alloc(count); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p);
+            g_devbuf_epoch++;
+        }
         p = nullptr;
         n = 0;
     }
     void upload(const T *src, size_t count) {
         ensure(count);
+        g_devbuf_epoch++;
         if (count) SR_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
     }
     void download(T *dst, size_t count) const {

@@ -3,6 +3,10 @@
 // decision per window.  Two slots of pinned host + device buffers and a second HIP stream: the H2D
 // copy of tick i+1 runs while the kernels of tick i do (hipStream double buffering); results come
 // back through pinned memory; the host only waits in sr_stream_collect.
+// With SR_STREAM_GRAPH the per-tick device work (4 kernels + 2 result copies) is captured once per
+// slot into a hipGraph and replayed with one hipGraphLaunch: the tick is launch-bound at small
+// n_windows.  The graph holds raw pointers into the library's cached workspaces, so it is
+// re-captured whenever any of them was reallocated or rewritten since (g_devbuf_epoch).
 // (The reference's conversation loop -- gui.py:179-214 -- polls a 1.5 s window every 0.4 s; its
 // VAD front end is third-party and out of scope.)
 #include "../../include/pygmm_hip.h"
@@ -26,6 +30,8 @@ struct SRStream {
         int *h_argmax = nullptr;         // pinned [n_windows]
         SRBatch pcm, feat;
         hipEvent_t h2d_done = nullptr, done = nullptr, t_submit = nullptr;
+        hipGraphExec_t exec = nullptr;   // SR_STREAM_GRAPH: the captured tick
+        long exec_epoch = -1;
         bool busy = false;
     } slot[2];
     std::deque<int> in_flight;           // slot indices, oldest first
@@ -45,9 +51,51 @@ void stream_destroy(SRStream *s) {
         if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.t_submit) (void)hipEventDestroy(sl.t_submit);
+        if (sl.exec) (void)hipGraphExecDestroy(sl.exec);
     }
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     delete s;
+}
+
+// The device side of one tick on the library's stream: kernels + result copies into the slot's
+// pinned buffers.  Launches only (every table is cached after the first pass over this shape).
+void enqueue_tick(SRStream *s, SRStream::Slot &sl) {
+    mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);
+    const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags & 0xff);
+    SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
+                          hipMemcpyDeviceToHost, ctx().stream));
+    SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
+                          hipMemcpyDeviceToHost, ctx().stream));
+}
+
+void capture_tick(SRStream *s, SRStream::Slot &sl) {
+    if (sl.exec) {
+        (void)hipGraphExecDestroy(sl.exec);
+        sl.exec = nullptr;
+    }
+    const bool prof = ctx().profiling;
+    ctx().profiling = false;             // no event records inside the capture
+    hipGraph_t g = nullptr;
+    const long epoch = g_devbuf_epoch.load();
+    SR_HIP(hipStreamBeginCapture(ctx().stream, hipStreamCaptureModeThreadLocal));
+    try {
+        enqueue_tick(s, sl);
+    } catch (...) {
+        (void)hipStreamEndCapture(ctx().stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        ctx().profiling = prof;
+        throw;
+    }
+    ctx().profiling = prof;
+    SR_HIP(hipStreamEndCapture(ctx().stream, &g));
+    if (g_devbuf_epoch.load() != epoch) {     // the pass itself touched a workspace: not steady state yet
+        (void)hipGraphDestroy(g);
+        fail("serving graph: the captured pass modified a cached workspace");
+    }
+    const hipError_t e = hipGraphInstantiate(&sl.exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    sl.exec_epoch = epoch;
 }
 
 }  // namespace
@@ -89,7 +137,7 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
             // one synchronous pass per slot builds every table / workspace for this shape, so the
             // steady state launches kernels only
             mfcc_extract_batch(*m, sl.pcm, nd, 1, sl.feat);
-            (void)score_device(*set, sl.feat, false, flags);
+            (void)score_device(*set, sl.feat, false, flags & 0xff);
             sync_stream();
         }
         return s;
@@ -116,12 +164,17 @@ int sr_stream_submit(SRStream *s, const int16_t *pcm) {
         SR_HIP(hipMemcpyAsync(sl.pcm.pcm16.p, sl.h_pcm, bytes, hipMemcpyHostToDevice, s->copy_stream));
         SR_HIP(hipEventRecord(sl.h2d_done, s->copy_stream));
         SR_HIP(hipStreamWaitEvent(ctx().stream, sl.h2d_done, 0));
-        mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);          // launches only (tables cached)
-        const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags);
-        SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
-                              hipMemcpyDeviceToHost, ctx().stream));
-        SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
-                              hipMemcpyDeviceToHost, ctx().stream));
+        if (s->flags & SR_STREAM_GRAPH) {
+            if (!sl.exec || sl.exec_epoch != g_devbuf_epoch.load()) {
+                // (re)build: one plain pass first so that every cache reflects this shape, then capture
+                enqueue_tick(s, sl);
+                capture_tick(s, sl);
+            } else {
+                SR_HIP(hipGraphLaunch(sl.exec, ctx().stream));
+            }
+        } else {
+            enqueue_tick(s, sl);
+        }
         SR_HIP(hipEventRecord(sl.done, ctx().stream));
         sl.busy = true;
         s->in_flight.push_back(k);

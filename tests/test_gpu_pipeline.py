@@ -175,7 +175,8 @@ def test_em_training_vs_reference_trainer_golden(built_lib, gmm_golden):
 
 def test_serving_stream_double_buffered_equals_synchronous(built_lib):
     """sr_stream_*: ticks submitted two deep (H2D of tick i+1 on its own HIP stream while tick i
-    computes) return exactly what the synchronous fused step returns for the same windows."""
+    computes) return exactly what the synchronous fused step returns for the same windows, with
+    plain launches and with the tick replayed as a captured hipGraph (SR_STREAM_GRAPH)."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, ServingStream
     from speaker_recognition_amd.pygmm import GMM
@@ -185,16 +186,21 @@ def test_serving_stream_double_buffered_equals_synchronous(built_lib):
     audio = synth.synth_speech(4, 12.0, fs)
     ticks = [np.stack([audio[(t * nwin + j) * 3000:(t * nwin + j) * 3000 + fs] for j in range(nwin)]) for t in range(5)]
     want = [ex.predict_batch(ms, Batch.from_pcm(list(tk)), nd=0) for tk in ticks]
-    st = ServingStream(ex, ms, nwin, fs)
-    got = []
-    st.submit(ticks[0])
-    for t in range(1, 5):
-        st.submit(ticks[t])             # two in flight
+    for graph in (False, True):         # plain launches, then the captured hipGraph replay
+        st = ServingStream(ex, ms, nwin, fs, graph=graph)
+        got = []
+        st.submit(ticks[0])
+        for t in range(1, 5):
+            st.submit(ticks[t])             # two in flight
+            if graph and t == 3:
+                # other API traffic between ticks rewrites the library's cached workspaces: the
+                # session must notice and re-capture instead of replaying stale pointers / tables
+                ex.predict_batch(ms, Batch.from_pcm([audio[:3 * fs], audio[fs:5 * fs]]), nd=0)
+            got.append(st.collect())
         got.append(st.collect())
-    got.append(st.collect())
-    for (ws, wa), (gs, ga, ms_dev) in zip(want, got):
-        assert np.array_equal(ws, gs) and np.array_equal(wa, ga)
-        assert ms_dev > 0
+        for (ws, wa), (gs, ga, ms_dev) in zip(want, got):
+            assert np.array_equal(ws, gs) and np.array_equal(wa, ga), graph
+            assert ms_dev > 0
     with pytest.raises(Exception):
         st.collect()                    # nothing in flight
 
