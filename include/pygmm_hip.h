@@ -155,6 +155,18 @@ int sr_stream_submit(SRStream *s, const int16_t *pcm /* [n_windows][window_sampl
 int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *device_ms);
 void sr_stream_free(SRStream *s);
 
+/* Long-term spectral divergence of half-overlapped Hann windows -- the measure behind the reference's
+ * voice-activity front end (src/filters/ltsd.py:32-64, which calls third-party pyssp.vad.ltsd; the
+ * algorithm is restated from its published form, parity unpinned).  winsize = int(0.04644 * fs)
+ * (ltsd.py:17,66-69), hop winsize/2, windows per signal = len/(winsize/2) - 1.
+ * sr_ltsd_noise_spectrum: mean amplitude spectrum (bins 0..winsize/2) over all windows of `noise`.
+ * sr_ltsd_compute: LTSD in dB of every window of every utterance of `pcm` against that spectrum;
+ * ltsd_out holds win_offsets_out[U] floats, utterance u's windows at [win_offsets_out[u], win_offsets_out[u+1]). */
+int64_t sr_ltsd_num_windows(int64_t n_samples, int winsize);
+int sr_ltsd_noise_spectrum(SRBatch *noise, int winsize, float *avg_amp_out /*[winsize/2+1]*/);
+int sr_ltsd_compute(SRBatch *pcm, int winsize, int order, const float *noise_amp /*[winsize/2+1]*/,
+                    float *ltsd_out, int64_t *win_offsets_out /*[U+1]*/);
+
 /* GPU EM / MAP on contiguous fp32 frames (the engine behind train_model*). Returns the number
  * of iterations run, negative on error. seed < 0 -> time-based. */
 int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,

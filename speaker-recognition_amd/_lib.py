@@ -27,7 +27,7 @@ EXT_SYMBOLS = [
     "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
-    "sr_last_score_kernel", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
+    "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -116,6 +116,9 @@ def lib():
         "sr_profile_get": (i32, [i32, dp, C.POINTER(C.c_long)]),
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
+        "sr_ltsd_num_windows": (i64, [i64, i32]),
+        "sr_ltsd_noise_spectrum": (i32, [vp, i32, fp]),
+        "sr_ltsd_compute": (i32, [vp, i32, i32, fp, fp, C.POINTER(i64)]),
         "sr_stream_create": (vp, [vp, vp, i32, i64, i32, i32]),
         "sr_stream_submit": (i32, [vp, C.POINTER(C.c_int16)]),
         "sr_stream_collect": (i32, [vp, dp, C.POINTER(i32), dp]),

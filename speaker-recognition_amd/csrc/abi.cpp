@@ -482,6 +482,29 @@ int sr_profile_get(int kind, double *total_ms, long *launches) {
     SR_CATCH(-1)
 }
 
+int64_t sr_ltsd_num_windows(int64_t n_samples, int winsize) {
+    SR_TRY
+    return ltsd_num_windows(n_samples, winsize);
+    SR_CATCH(-1)
+}
+
+int sr_ltsd_noise_spectrum(SRBatch *noise, int winsize, float *avg_amp_out) {
+    SR_TRY
+    if (!noise || !avg_amp_out) fail("null argument");
+    ltsd_noise_spectrum(*noise, winsize, avg_amp_out);
+    return 0;
+    SR_CATCH(-1)
+}
+
+int sr_ltsd_compute(SRBatch *pcm, int winsize, int order, const float *noise_amp, float *ltsd_out,
+                    int64_t *win_offsets_out) {
+    SR_TRY
+    if (!pcm || !noise_amp || !ltsd_out) fail("null argument");
+    ltsd_compute(*pcm, winsize, order, noise_amp, ltsd_out, win_offsets_out);
+    return 0;
+    SR_CATCH(-1)
+}
+
 int sr_set_option(const char *key, long value) {
     SR_TRY
     if (!key) fail("null key");

@@ -29,4 +29,10 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
 void mfcc_set_force_generic(bool on);
 void lpc_extract_into(SRMfcc &m, SRBatch &pcm, const int64_t *d_frame_off, int64_t n_frames, int n_lpc,
                       float *out, int out_stride, int col_off);   // A/B: route FFT_SIZE 2048 through the generic LDS kernel
+// ltsd.hip: long-term spectral divergence (voice-activity front end)
+int64_t ltsd_num_windows(int64_t n_samples, int N);
+void ltsd_noise_spectrum(SRBatch &noise, int N, float *avg_amp_out);
+void ltsd_compute(SRBatch &pcm, int N, int order, const float *noise_amp, float *ltsd_out,
+                  int64_t *win_offsets_out);
+
 }  // namespace sr

@@ -156,3 +156,26 @@ def test_lpc_oracle_solves_the_normal_equations():
         assert np.max(np.abs(a - feat[f])) < 1e-8
     silent = ex.extract(np.zeros(4000))
     assert silent.shape[1] == 15 and np.all(silent == 0)          # NaN -> 0, LPC.py:56
+
+
+def test_ltsd_oracle_properties():
+    """The LTSD restatement (parity unpinned -- third-party algorithm): window sizes the reference
+    uses, the edge rule, scale invariance of the measure when signal and noise scale together, and
+    the decision rule of the product's host side (pure Python, no device)."""
+    from oracle import ltsd_oracle as lo
+    assert lo.window_size(16000) == 743 and lo.window_size(8000) == 371
+    assert lo.num_windows(743 + 371, 743) == 2 and lo.num_windows(100, 743) == 0
+    rng = np.random.default_rng(0)
+    noise = rng.normal(0, 100, 16000)
+    sig = rng.normal(0, 100, 16000)
+    t = np.arange(4000) / 16000.0
+    sig[6000:10000] += 4000 * np.sin(2 * np.pi * 440 * t)
+    na, lam0, lam1 = lo.thresholds(noise, 743)
+    l = lo.ltsd(sig, na, 743)
+    assert np.all(l[:5] == 0) and np.all(l[-5:] == 0)
+    assert l[(6000 // 371) + 2] > lam1 and l[7] < lam0
+    l2 = lo.ltsd(3.0 * sig, 3.0 * na, 743)
+    assert np.allclose(l, l2, atol=1e-9)
+    from speaker_recognition_amd.filters.ltsd import voiced_runs
+    assert voiced_runs(np.array([0, 3, 3, 9, 3, 0, 3, 3, 0, 9.0]), 2.0, 5.0) == [(1, 4), (9, 9)]
+    assert voiced_runs(np.array([]), 1.0, 2.0) == []
