@@ -1,4 +1,4 @@
-"""Scoring kernel under a forced engine: `dbg_bx3.py ENGINE FT DEBUG [ROUNDS]` prints the HIP-event
+"""Scoring kernel under a forced engine: `time_score_engine.py ENGINE FT DEBUG [ROUNDS]` prints the HIP-event
 time per launch (cfg-1 shape).  Used for PMC passes on one engine (scripts/pmc.sh with PMC_CMD)."""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
