@@ -23,7 +23,8 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
 using namespace sr;
 
 // ---- guards: park the message, never unwind into C ----
-#define SR_TRY try {
+#define SR_TRY try {                                                     \
+    std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
 #define SR_CATCH(ret)                          \
     }                                          \
     catch (const std::exception &e) {          \

@@ -30,6 +30,11 @@ void fail(const char *fmt, ...) {
 
 std::atomic<long> g_devbuf_epoch{0};
 
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex *m = new std::recursive_mutex();   // leaked: usable during exit
+    return *m;
+}
+
 static Ctx g_ctx;
 static bool g_ready = false;
 static std::mutex g_mu;

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -31,6 +32,11 @@ struct Error : std::runtime_error {
             ::sr::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
                        __LINE__);                                                      \
     } while (0)
+
+// One lock around every compute entry point of the C ABI: the library keeps one stream and cached
+// workspaces per process, so concurrent callers (ctypes drops the GIL) are serialised rather than
+// left to race.  The reference's callers parallelise with processes (test-nperson.py:135-139).
+std::recursive_mutex &api_mutex();
 
 // ---- per-process device context: one stream, lazily created (fork-safe: nothing touches
 // HIP before the first call that needs the device). ----

@@ -79,6 +79,7 @@ void capture_tick(SRStream *s, SRStream::Slot &sl) {
     const long epoch = g_devbuf_epoch.load();
     SR_HIP(hipStreamBeginCapture(ctx().stream, hipStreamCaptureModeThreadLocal));
     try {
+        std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         enqueue_tick(s, sl);
     } catch (...) {
         (void)hipStreamEndCapture(ctx().stream, &g);
@@ -105,6 +106,7 @@ extern "C" {
 SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t window_samples, int nd,
                            int flags) {
     try {
+        std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         ensure_device();
         if (!m || !set || n_windows <= 0 || window_samples <= 0) fail("bad arguments to sr_stream_create");
         if (mfcc_num_frames(*m, window_samples) - nd <= 0) fail("window of %lld samples yields no frames", (long long)window_samples);
@@ -154,6 +156,7 @@ void sr_stream_free(SRStream *s) {
 
 int sr_stream_submit(SRStream *s, const int16_t *pcm) {
     try {
+        std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         if (!s || !pcm) fail("null argument");
         if (s->in_flight.size() >= 2) fail("two ticks already in flight: collect one first");
         const int k = (int)(s->submitted & 1);
@@ -188,6 +191,7 @@ int sr_stream_submit(SRStream *s, const int16_t *pcm) {
 
 int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *device_ms) {
     try {
+        std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         if (!s) fail("null stream");
         if (s->in_flight.empty()) fail("nothing in flight");
         const int k = s->in_flight.front();

@@ -363,3 +363,38 @@ def test_random_shapes_all_engines(built_lib, oracle_built):
                 order = np.sort(w)
                 if S == 1 or order[-1] - order[-2] > 1e-3 * n:      # skip near-ties
                     assert arg[u] == int(np.argmax(w)), (case, eng, u)
+
+
+def test_concurrent_host_threads(built_lib, oracle_built):
+    """ctypes releases the GIL, so Python threads reach the library concurrently; the entry points
+    serialise on one lock (one stream and cached workspaces per process) and every thread still gets
+    its own results."""
+    import threading
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    sets, batches, want = [], [], []
+    for t in range(4):
+        D, K, S = (13, 32, 3) if t % 2 else (39, 64, 5)
+        models = [synth.synth_gmm(K, D, 800 + 10 * t + s) for s in range(S)]
+        utts = [synth.draw_frames(models[u % S], 100 + 173 * u + 50 * t, 60 + u + 10 * t) for u in range(4)]
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        b = Batch.from_features(utts)
+        sets.append(ms)
+        batches.append(b)
+        want.append(ms.score(b))
+    got = [[] for _ in range(4)]
+
+    def worker(i):
+        for _ in range(25):
+            got[i].append(sets[i].score(batches[i]))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(4):
+        assert len(got[i]) == 25
+        for sums, arg in got[i]:
+            assert np.array_equal(sums, want[i][0]) and np.array_equal(arg, want[i][1])
