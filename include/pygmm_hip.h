@@ -108,6 +108,9 @@ SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
 /* Overwrite the samples of a PCM batch in place (same utterance layout, same or fewer samples per
  * utterance is NOT supported: the layout must match exactly) -- the serving loop's H2D, no allocation. */
 int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples);
+/* New contents AND a new utterance layout in the same handle: device buffers are reused (they only
+ * grow), so a serving loop whose batches change shape allocates nothing in steady state. */
+int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_offsets, int n_utt);
 void sr_batch_free(SRBatch *b);
 int sr_batch_num_utterances(SRBatch *b);
 int64_t sr_batch_num_rows(SRBatch *b);           /* samples (PCM) or frames (features) */

@@ -37,6 +37,33 @@ def main():
     lat = np.array(lat[30:])
     out["single_stream_latency_ms"] = {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)),
                                        "p99": float(np.percentile(lat, 99)), "min": float(lat.min())}
+    # the whole configs[4] chain: LTSD VAD in front (filters.VAD surface: noise calibration once, then per
+    # window LTSD -> voiced intervals -> the reference's one-third rule, gui/interface.py:43-53) and
+    # MFCC + GMM on the voiced samples only; all device buffers reused, host-observed latency per window
+    from speaker_recognition_amd.filters import VAD
+    rng = np.random.default_rng(5)
+    floor = rng.normal(0, 60, len(audio)).astype(np.int16)
+    gate = (np.arange(len(audio)) // (fs * 3 // 2)) % 2 == 0            # 1.5 s speech, 1.5 s background
+    scene = (np.where(gate, audio // 2, 0) + floor).astype(np.int16)
+    vad = VAD()
+    vad.init_noise(fs, rng.normal(0, 60, 3 * fs).astype(np.int16))
+    vwin = Batch.from_pcm([scene[:fs]])
+    lat_v, n_voiced, n_dec = [], 0, 0
+    for i in range(260):
+        chunk = scene[(i % 70) * fs // 2:(i % 70) * fs // 2 + fs]
+        t0 = time.perf_counter()
+        voiced, intervals = vad.filter(fs, chunk)
+        if len(voiced) > len(chunk) / 3 and ex.num_frames(len(voiced)) > 0:
+            vwin.reset_pcm([voiced])
+            sums, arg = ex.predict_batch(models, vwin, nd=0)
+            n_dec += 1
+        lat_v.append((time.perf_counter() - t0) * 1e3)
+        n_voiced += len(voiced)
+    lat_v = np.array(lat_v[30:])
+    out["single_stream_with_ltsd_vad_latency_ms"] = {
+        "p50": float(np.percentile(lat_v, 50)), "p90": float(np.percentile(lat_v, 90)),
+        "p99": float(np.percentile(lat_v, 99)), "windows_decided": n_dec, "windows": 260,
+        "voiced_fraction": n_voiced / (260.0 * fs)}
     # many concurrent streams batched per tick
     for n_streams in (64, 1024):
         batch = Batch.from_pcm([audio[(j % 39) * fs // 2:(j % 39) * fs // 2 + fs] for j in range(n_streams)])

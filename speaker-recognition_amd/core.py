@@ -67,6 +67,15 @@ class Batch:
         check(lib().sr_batch_update_pcm(self._h, a.ctypes.data_as(C.POINTER(C.c_int16)), a.size),
               "sr_batch_update_pcm")
 
+    def reset_pcm(self, signals) -> None:
+        """New int16 signals with a new layout into the same device buffers (they only grow)."""
+        sigs = [np.ascontiguousarray(x, dtype=np.int16) for x in signals]
+        offsets = np.zeros(len(sigs) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum([len(x) for x in sigs])
+        cat = np.ascontiguousarray(np.concatenate(sigs)) if sigs else np.zeros(0, np.int16)
+        check(lib().sr_batch_reset_pcm(self._h, cat.ctypes.data_as(C.POINTER(C.c_int16)), _lib.as_i64p(offsets),
+                                       len(sigs)), "sr_batch_reset_pcm")
+
     @property
     def n_utt(self) -> int:
         return lib().sr_batch_num_utterances(self._h)

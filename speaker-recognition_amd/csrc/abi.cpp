@@ -363,6 +363,26 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     SR_CATCH(-1)
 }
 
+int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_offsets, int n_utt) {
+    SR_TRY
+    if (!b || !sample_offsets) fail("null argument");
+    if (b->kind != SRBatch::PCM16) fail("sr_batch_reset_pcm needs an int16 PCM batch");
+    if (n_utt < 0 || sample_offsets[0] != 0) fail("bad PCM batch arguments");
+    for (int u = 0; u < n_utt; u++)
+        if (sample_offsets[u + 1] < sample_offsets[u]) fail("sample_offsets must be non-decreasing");
+    const int64_t n = sample_offsets[n_utt];
+    if (n > 0 && !pcm) fail("null PCM pointer");
+    b->n_utt = n_utt;
+    b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
+    b->n_rows = n;
+    b->tile_tables.clear();
+    b->pcm16.upload(pcm, (size_t)n);                 // device buffers only ever grow
+    b->d_offsets.upload(b->offsets.data(), b->offsets.size());
+    sync_stream();
+    return 0;
+    SR_CATCH(-1)
+}
+
 void sr_batch_free(SRBatch *b) { delete b; }
 int sr_batch_num_utterances(SRBatch *b) { return b ? b->n_utt : 0; }
 int64_t sr_batch_num_rows(SRBatch *b) { return b ? b->n_rows : 0; }

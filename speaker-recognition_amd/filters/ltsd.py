@@ -20,9 +20,14 @@ from ..core import Batch
 MAGIC_NUMBER = 0.04644
 
 
-def ltsd_values(signals, noise_amp, window_size, order=5):
-    """LTSD (dB) of every window of every signal -> list of float32 arrays (one per signal)."""
-    b = Batch.from_pcm([np.asarray(s) for s in signals])
+def ltsd_values(signals, noise_amp, window_size, order=5, batch=None):
+    """LTSD (dB) of every window of every signal -> list of float32 arrays (one per signal).
+    ``batch``: an int16 PCM ``Batch`` to reuse (its device buffers are rewritten in place)."""
+    if batch is not None and all(np.asarray(s).dtype == np.int16 for s in signals):
+        batch.reset_pcm(signals)
+        b = batch
+    else:
+        b = Batch.from_pcm([np.asarray(s) for s in signals])
     n_win = [max(0, len(s) // (window_size // 2) - 1) for s in signals]
     out = np.zeros(max(1, sum(n_win)), dtype=np.float32)
     off = np.zeros(len(signals) + 1, dtype=np.int64)
@@ -60,6 +65,11 @@ def voiced_runs(ltsds, lambda0, lambda1):
 class LTSD_VAD(object):
     order = 5
 
+    def __getstate__(self):           # device handles do not pickle (ModelInterface.dump)
+        d = dict(self.__dict__)
+        d["_batch"] = None
+        return d
+
     def __init__(self):
         self.fs = 0
         self.window_size = 0
@@ -67,6 +77,7 @@ class LTSD_VAD(object):
         self.lambda1 = 0.0
         self.noise_signal = None
         self.noise_amp = None
+        self._batch = None            # reused across filter() calls: a serving loop allocates nothing
 
     def _mononize_signal(self, signal):
         signal = np.asarray(signal)
@@ -89,7 +100,12 @@ class LTSD_VAD(object):
         self.lambda1 = self.lambda0 * 2.0
 
     def ltsd(self, signal):
-        return ltsd_values([self._mononize_signal(signal)], self.noise_amp, self.window_size, self.order)[0]
+        signal = self._mononize_signal(signal)
+        if signal.dtype == np.int16:
+            if self._batch is None:
+                self._batch = Batch.from_pcm([signal])
+            return ltsd_values([signal], self.noise_amp, self.window_size, self.order, batch=self._batch)[0]
+        return ltsd_values([signal], self.noise_amp, self.window_size, self.order)[0]
 
     def filter(self, signal):
         if self.noise_amp is None:
