@@ -22,6 +22,7 @@ def main():
     K = int(os.environ.get("CFG3_K", 2048))
     U = int(os.environ.get("CFG3_U", 12500))
     D, T = 39, 1000
+    _lib.set_option("score_engine", int(os.environ.get("CFG3_ENGINE", 0)))   # before the set is packed
     t0 = time.time()
     ubm = synth.synth_gmm(K, D, 99)
     w, mean, sigma = ubm

@@ -52,9 +52,7 @@ static SRModelSet &single_set(GMM *g) {
     if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
     if (!g->single || g->single->device != ctx().device) {
         auto s = std::make_shared<SRModelSet>();
-        s->host = pack_models({g});
-        s->mfma = pack_models_mfma({g}, s->host.dp);
-        s->bx3 = pack_models_bf16x3({g});
+        pack_model_set(*s, {g});
         upload_model_set(*s);
         g->single = s;
     }
@@ -298,9 +296,7 @@ SRModelSet *sr_modelset_create(GMM *const *models, int n_models) {
     for (auto *m : v)
         if (!m) fail("null GMM handle in model list");
     auto s = std::make_unique<SRModelSet>();
-    s->host = pack_models(v);
-    s->mfma = pack_models_mfma(v, s->host.dp);
-    s->bx3 = pack_models_bf16x3(v);
+    pack_model_set(*s, v);
     upload_model_set(*s);
     return s.release();
     SR_CATCH(nullptr)
@@ -538,8 +534,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_packed") {
         score_options().packed = (int)value;
     } else if (k == "score_engine") {
-        if (value < 0 || value > 3)
-            fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores) or 3 (split-bf16 matrix cores)");
+        if (value < 0 || value > 4)
+            fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores) "
+                 "or 4 (split-bf16, shared-sigma form)");
         score_options().engine = (int)value;
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");

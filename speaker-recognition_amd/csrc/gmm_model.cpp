@@ -334,4 +334,110 @@ PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models) {
     return pm;
 }
 
+bool models_share_sigma_and_weights(const std::vector<const GMM *> &models) {
+    if (models.size() < 2) return false;
+    const GMM &a = *models[0];
+    for (size_t s = 1; s < models.size(); s++) {
+        const GMM &b = *models[s];
+        if (b.nr_mixtures != a.nr_mixtures || b.dim != a.dim) return false;
+        if (std::memcmp(a.weights.data(), b.weights.data(), sizeof(double) * a.weights.size()) != 0) return false;
+        if (std::memcmp(a.sigma.data(), b.sigma.data(), sizeof(double) * a.sigma.size()) != 0) return false;
+    }
+    return true;
+}
+
+// one tile image [ks][part][lane][8]: coefficient of mixture row i at slot c = 16 ks + 8 hh + j
+static void put_tile_row(uint16_t *tile, int ksteps, int i, const std::vector<float> &coef) {
+    for (int c = 0; c < ksteps * 16; c++) {
+        uint16_t parts[3];
+        split_bf16x3(coef[c], parts);
+        const int ks = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+        const int lane = i + 32 * hh;
+        for (int p = 0; p < 3; p++) tile[(((size_t)ks * 3 + p) * 64 + lane) * 8 + j] = parts[p];
+    }
+}
+
+PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models) {
+    PackedBx3Shared pm;
+    const GMM &g0 = *models[0];
+    const int dim = g0.dim, K = g0.nr_mixtures;
+    const int S = (int)models.size();
+    pm.kq = (dim + 15) / 16;
+    pm.kl = (dim + 1 + 15) / 16;
+    pm.n_tiles = (K + MT - 1) / MT;
+    const size_t q_u16 = (size_t)pm.kq * 3 * 64 * 8, l_u16 = (size_t)pm.kl * 3 * 64 * 8;
+    const double LOG2E = 1.4426950408889634073599;
+    const double SQRT_2_PI = 2.5066282746310002;
+    pm.center.assign(dim, 0.0f);
+    {
+        std::vector<double> acc(dim, 0.0);
+        for (const GMM *g : models)
+            for (int k = 0; k < K; k++)
+                for (int d = 0; d < dim; d++) acc[d] += g->mean[(size_t)k * dim + d];
+        for (int d = 0; d < dim; d++) pm.center[d] = (float)(acc[d] / ((double)K * S));
+    }
+    const int n_blocks = (S + SHARED_SB - 1) / SHARED_SB;
+    const size_t block_u16 = (size_t)pm.n_tiles * (q_u16 + (size_t)SHARED_SB * l_u16);
+    pm.params.assign((size_t)n_blocks * block_u16, 0);
+    // the quadratic tiles are the same in every block
+    std::vector<uint16_t> qimg((size_t)pm.n_tiles * q_u16, 0);
+    {
+        std::vector<float> coef((size_t)pm.kq * 16);
+        for (int t = 0; t < pm.n_tiles; t++)
+            for (int i = 0; i < MT; i++) {
+                const int k = t * MT + i;
+                std::fill(coef.begin(), coef.end(), 0.0f);
+                if (k < K)
+                    for (int d = 0; d < dim; d++) {
+                        const double sg = g0.sigma[(size_t)k * dim + d];
+                        coef[d] = (float)(-0.5 * LOG2E / (sg * sg));
+                    }
+                put_tile_row(qimg.data() + (size_t)t * q_u16, pm.kq, i, coef);
+            }
+    }
+    std::vector<float> coef((size_t)pm.kl * 16);
+    for (int b = 0; b < n_blocks; b++) {
+        uint16_t *bp = pm.params.data() + (size_t)b * block_u16;
+        SharedBlock sb;
+        sb.offset_u4 = (uint32_t)(((size_t)b * block_u16) / 8);
+        sb.first_model = b * SHARED_SB;
+        sb.n_models = std::min(SHARED_SB, S - b * SHARED_SB);
+        sb.pad = 0;
+        pm.blocks.push_back(sb);
+        for (int t = 0; t < pm.n_tiles; t++) {
+            uint16_t *tp = bp + (size_t)t * (q_u16 + (size_t)SHARED_SB * l_u16);
+            std::memcpy(tp, qimg.data() + (size_t)t * q_u16, q_u16 * sizeof(uint16_t));
+            for (int si = 0; si < SHARED_SB; si++) {
+                uint16_t *lt = tp + q_u16 + (size_t)si * l_u16;
+                const int s = b * SHARED_SB + si;
+                for (int i = 0; i < MT; i++) {
+                    const int k = t * MT + i;
+                    std::fill(coef.begin(), coef.end(), 0.0f);
+                    float cst_f = NEG_BIG;
+                    if (s < S && k < K) {
+                        const GMM &g = *models[s];
+                        double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                        double a = 0.0;
+                        for (int d = 0; d < dim; d++) {
+                            const double sg = g.sigma[(size_t)k * dim + d];
+                            const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
+                            const double iv = 1.0 / (sg * sg);
+                            coef[d] = (float)(LOG2E * mu * iv);
+                            cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
+                            a += mu * mu * iv;
+                        }
+                        pm.amp = std::max(pm.amp, a);
+                        cst *= LOG2E;
+                        if (std::isfinite(cst) && cst > (double)NEG_BIG) cst_f = (float)cst;
+                    }
+                    coef[(size_t)pm.kl * 16 - 1] = cst_f;
+                    put_tile_row(lt, pm.kl, i, coef);
+                }
+            }
+        }
+    }
+    pm.pad_waste = 1.0 - ((double)K * S) / ((double)pm.n_tiles * MT * n_blocks * SHARED_SB);
+    return pm;
+}
+
 }  // namespace sr

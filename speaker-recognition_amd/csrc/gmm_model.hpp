@@ -102,6 +102,33 @@ struct PackedBf16x3 {
     double pad_waste = 0.0;
 };
 PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models);
+
+// ---- fourth layout: speaker sets that share sigma and weights (MAP adaptation moves the means only,
+// gmmubm.cc:40-81 -- a UBM and every speaker adapted from it).  The quadratic half of the
+// contraction, Q_k(x) = sum_d A2_kd x'_d^2, is then the same for every model at a given mixture:
+// it is evaluated once per (mixture tile, block of SHARED_SB models) and fed as the C operand of
+// each model's linear half L_sk(x) = sum_d A1_skd x'_d + C_sk.  Split-bf16 arithmetic as above.
+//   quadratic tile: KQ = ceil(D/16) steps, slot c = 16 ks + 8 hh + j <-> feature c (A2, against x'^2)
+//   linear tile:    KL = ceil((D+1)/16) steps, slot c < D <-> A1 (against x'), slot 16 KL - 1 <-> C_k (against 1)
+// Stream order (what a workgroup walks): per block of SHARED_SB models, per mixture tile t:
+//   [Q_t][L_{s0,t}] ... [L_{s14,t}]  -- 1 + SHARED_SB images, an even count, so the two LDS buffers
+// alternate statically.  The last block is padded with phantom models (C = -1e30, never stored).
+constexpr int SHARED_SB = 15;
+struct SharedBlock {
+    uint32_t offset_u4;   // first 16-byte fragment of the block's stream
+    int32_t first_model;
+    int32_t n_models;     // live models in this block (<= SHARED_SB)
+    int32_t pad;
+};
+struct PackedBx3Shared {
+    int kq = 0, kl = 0, n_tiles = 0;   // mixture tiles per model
+    std::vector<uint16_t> params;
+    std::vector<SharedBlock> blocks;
+    std::vector<float> center;
+    double amp = 0.0, pad_waste = 0.0;
+};
+bool models_share_sigma_and_weights(const std::vector<const GMM *> &models);
+PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models);
 void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts
 
 }  // namespace sr
@@ -118,5 +145,9 @@ struct SRModelSet {
     sr::DevBuf<uint16_t> d_bx3_params;
     sr::DevBuf<float> d_bx3_center;
     sr::DevBuf<sr::ChunkDesc> d_bx3_chunks;
+    sr::PackedBx3Shared shared;      // shared-sigma layout (empty unless the set qualifies)
+    sr::DevBuf<uint16_t> d_shared_params;
+    sr::DevBuf<sr::SharedBlock> d_shared_blocks;
+    sr::DevBuf<float> d_shared_center;
     int device = -1;
 };

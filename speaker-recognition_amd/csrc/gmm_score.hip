@@ -353,6 +353,27 @@ static void ensure_mfma_layout(SRModelSet &s) {
     sync_stream();
 }
 
+void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
+    s.host = pack_models(models);
+    size_t n_mix = 0;
+    for (const GMM *g : models) n_mix += (size_t)g->nr_mixtures;
+    const bool small = n_mix <= ((size_t)1 << 16);          // every layout is a few MB at most
+    const int forced = score_options().engine;
+    const bool shared_ok = (int)models.size() >= SHARED_MIN_MODELS && models[0]->dim <= 48 &&   // <= 3 + 4 contraction steps: no scratch
+                           models_share_sigma_and_weights(models);
+    if (shared_ok && (small || forced == 0 || forced == 4)) s.shared = pack_models_bx3_shared(models);
+    if (small || forced == 2) s.mfma = pack_models_mfma(models, s.host.dp);
+    if (small || forced == 3 || (forced == 0 && !shared_ok)) s.bx3 = pack_models_bf16x3(models);
+}
+
+static void ensure_shared_layout(SRModelSet &s) {
+    if (s.d_shared_params.p) return;
+    s.d_shared_params.upload(s.shared.params.data(), s.shared.params.size());
+    s.d_shared_blocks.upload(s.shared.blocks.data(), s.shared.blocks.size());
+    s.d_shared_center.upload(s.shared.center.data(), s.shared.center.size());
+    sync_stream();
+}
+
 static void ensure_bx3_layout(SRModelSet &s) {
     if (s.d_bx3_params.p) return;
     s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
@@ -373,8 +394,13 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     // conditioned and not mostly padding; the vector-ALU kernel otherwise or when forced
     const bool mfma_ok = !set.mfma.params.empty();
     const bool bx3_ok = !set.bx3.params.empty();
-    bool use_mfma = false, use_bx3 = false;
-    if (opt.engine == 3) {
+    const bool shared_ok = !set.shared.params.empty();
+    bool use_mfma = false, use_bx3 = false, use_shared = false;
+    if (opt.engine == 4) {
+        if (!shared_ok) fail("shared-sigma engine requested but the set does not qualify (>= %d models with "
+                             "identical sigma and weights, packed with that engine available)", SHARED_MIN_MODELS);
+        use_shared = true;
+    } else if (opt.engine == 3) {
         if (!bx3_ok) fail("split-bf16 engine requested but the set has no bf16x3 layout");
         use_bx3 = true;
     } else if (opt.engine == 2) {
@@ -383,9 +409,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     } else if (opt.engine == 0) {
         // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
         // shape swept (profiles/r01_tune_score.log); the fp32 one stays selectable (score_engine = 2)
-        use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
+        use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
+        if (!use_shared)
+            use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
     }
-    const bool use_mat = use_mfma || use_bx3;
+    const bool use_mat = use_mfma || use_bx3 || use_shared;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     int FT = opt.mfma_ft;
@@ -399,6 +427,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         FT = ((S >= 8 && tiles_per_model >= 4.0) || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
     }
     if (DP > 40 && FT > 3) FT = 3;
+    if (use_shared) FT = 1;
     if (use_bx3) FT = opt.mfma_ft ? std::min(opt.mfma_ft, bx3_max_ft(set.bx3.ks)) : 1;   // one column tile per wave won or tied every sweep
     TileTable &tt = feat.tiles_for(use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
@@ -413,16 +442,21 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // enough workgroups for a short tail: >= ~16 rounds of resident ones for the vector and
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
-            const int target = use_bx3 ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
+            const int target = use_shared ? ctx().n_cu * 2 * 6 : use_bx3 ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
-        G = std::max(1, std::min(G, S));
-        const std::vector<int> &mcb = use_bx3 ? set.bx3.model_chunk_begin
-                                      : use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
+        const int n_units = use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of
+        G = std::max(1, std::min(G, n_units));
         std::vector<int> gcb(G + 1);
-        for (int g = 0; g <= G; g++) {
-            const int model = (int)(((int64_t)g * S) / G);
-            gcb[g] = mcb[model];
+        if (use_shared) {
+            for (int g = 0; g <= G; g++) gcb[g] = (int)(((int64_t)g * n_units) / G);
+        } else {
+            const std::vector<int> &mcb = use_bx3 ? set.bx3.model_chunk_begin
+                                          : use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
+            for (int g = 0; g <= G; g++) {
+                const int model = (int)(((int64_t)g * S) / G);
+                gcb[g] = mcb[model];
+            }
         }
         bool uploaded = false;
         if (w.gcb_host != gcb) {
@@ -433,7 +467,30 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         w.partial.ensure((size_t)tt.n_tiles * S * 4);
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
-        if (use_mat) {
+        if (use_shared) {
+            ensure_shared_layout(set);
+            SharedLaunch a;
+            a.X = feat.data.p;
+            a.tiles = tt.d_tiles.p;
+            a.params = set.d_shared_params.p;
+            a.blocks = set.d_shared_blocks.p;
+            a.group_block_begin = w.group_chunk_begin.p;
+            a.center = set.d_shared_center.p;
+            a.partial = w.partial.p;
+            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.n_frames = feat.n_rows;
+            a.dim = feat.dim;
+            a.n_models = S;
+            a.n_mix_tiles = set.shared.n_tiles;
+            a.clamp = (flags & 1) ? 1 : 0;
+            a.n_groups = G;
+            a.n_tiles = tt.n_tiles;
+            snprintf(g_last_kernel, sizeof g_last_kernel,
+                     "gmm_score_bx3_shared_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-bf16 MFMA)",
+                     set.shared.kq, set.shared.kl, SHARED_SB);
+            ScopedKernelTimer t(T_SCORE);
+            launch_score_bx3_shared(a, set.shared.kq, set.shared.kl);
+        } else if (use_mat) {
             if (use_bx3) ensure_bx3_layout(set); else ensure_mfma_layout(set);
             MfmaLaunch a;
             a.X = feat.data.p;
@@ -484,7 +541,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, use_bx3 ? 1 : 4, w.sums.p, w.argmax.p);
+                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_bx3 || use_shared) ? 1 : 4, w.sums.p, w.argmax.p);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;

@@ -11,7 +11,8 @@ struct ScoreOptions {
     int model_groups = 0;      // 0 = auto; workgroups per frame tile along the model axis
     int packed = 0;            // -1 = scalar v_fma_f32; 0 (auto) / 1 = v_pk_fma_f32, two frames per VGPR pair
     int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel;
-                               // 3 = split-bf16 (3 parts, 6 products) matrix-core kernel
+                               // 3 = split-bf16 (3 parts, 6 products) matrix-core kernel;
+                               // 4 = split-bf16, shared-sigma form (sets whose models share sigma and weights)
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
 };
 
@@ -33,6 +34,22 @@ struct MfmaLaunch {
     int dim, n_models, clamp, n_groups, n_tiles;
 };
 void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
+struct SharedLaunch {
+    const float *X;
+    const TileDesc *tiles;
+    const uint16_t *params;
+    const SharedBlock *blocks;
+    const int *group_block_begin;
+    const float *center;
+    double *partial;
+    float *frame_ll;
+    int64_t n_frames;
+    int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
+};
+void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL);
+// Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
+// mostly phantom models).
+constexpr int SHARED_MIN_MODELS = 12;
 void launch_score_bf16x3(const MfmaLaunch &a, int KS, int FT);   // a.params = the bf16x3 image
 int bx3_max_ft(int ks);
 ScoreOptions &score_options();
@@ -55,5 +72,8 @@ void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, do
                    int *argmax_out, float *frame_ll_out);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);
+// Packs the layouts a set needs (all of them for small sets; for large ones the vector layout plus
+// the one the dispatcher will pick, or the one forced by score_engine at creation time).
+void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models);
 
 }  // namespace sr

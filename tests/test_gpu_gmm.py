@@ -178,6 +178,8 @@ def test_full_size_cfg2_properties(built_lib, oracle_built):
     base = [synth.draw_frames(spk[s], T, 9000 + s) for s in range(S)]
     utts = [base[u % S] for u in range(S * REP)]
     sums, arg = ms.score(Batch.from_features(utts))
+    from speaker_recognition_amd import _lib
+    assert "shared" in _lib.last_score_kernel()        # sigma and weights are common: the shared-sigma engine
     assert sums.shape == (S * REP, S + 1) and np.all(np.isfinite(sums))
     assert np.array_equal(np.argmax(sums[:, 1:], axis=1), np.arange(S * REP) % S)
     assert np.all(sums[:, 1:].max(axis=1) > sums[:, 0])
@@ -398,3 +400,47 @@ def test_concurrent_host_threads(built_lib, oracle_built):
         assert len(got[i]) == 25
         for sums, arg in got[i]:
             assert np.array_equal(sums, want[i][0]) and np.array_equal(arg, want[i][1])
+
+
+def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
+    """Sets whose models share sigma and weights (a UBM and speakers MAP-adapted from it,
+    gmmubm.cc:40-81) take the shared-sigma kernel: the quadratic half of the contraction once per
+    block of 15 models.  Per-frame LL, sums and argmax against the oracle for set sizes around the
+    block size (phantom padding), K not a multiple of 32, ragged utterances, several model groups;
+    the general engines agree; sets that do not qualify refuse engine 4."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    for K, D, S in ((64, 39, 14), (40, 13, 15), (96, 26, 31), (33, 39, 16), (128, 48, 12)):
+        ubm = synth.synth_gmm(K, D, 1234 + K)
+        models = [ubm] + [synth.synth_map_speaker(ubm, 7000 + s) for s in range(S)]
+        lens = [0, 1, 127, 128, 129, 300, 33]
+        utts = [synth.draw_frames(models[1 + u % S], n, 11 + u, outlier_frac=0.01) for u, n in enumerate(lens)]
+        X = np.concatenate(utts).astype(np.float64)
+        want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+        off = np.concatenate([[0], np.cumsum(lens)])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        for eng, G in ((0, 0), (4, 1), (4, 2), (4, 3), (3, 0), (1, 0)):
+            _lib.set_option("score_engine", eng)
+            _lib.set_option("score_model_groups", G)
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            if eng == 4 or (eng == 0 and (K, S) == (64, 14)):      # auto also weighs the padding (phantom models, K % 32)
+                assert "shared" in _lib.last_score_kernel(), (K, D, S, eng)
+            assert ll_close(fll, want) < TOL, (K, D, S, eng, G, ll_close(fll, want))
+            for u, n in enumerate(lens):
+                if n == 0:
+                    assert arg[u] == -1 and np.all(sums[u] == 0)
+                    continue
+                w = want[:, off[u]:off[u + 1]].sum(axis=1)
+                assert np.max(np.abs(sums[u] - w)) < 2e-5 * n * 60 + 1e-3, (K, D, S, eng, u)
+    _lib.set_option("score_model_groups", 0)
+    # different sigmas -> not eligible
+    other = [synth.synth_gmm(64, 39, 900 + s) for s in range(14)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in other])
+    _lib.set_option("score_engine", 4)
+    with pytest.raises(Exception):
+        ms.score(Batch.from_features([synth.draw_frames(other[0], 50, 1)]))
+    _lib.set_option("score_engine", 0)
+    ms.score(Batch.from_features([synth.draw_frames(other[0], 50, 1)]))
+    assert "shared" not in _lib.last_score_kernel()
