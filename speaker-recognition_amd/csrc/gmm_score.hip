@@ -264,7 +264,7 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
 
 // ---------------- host side ----------------
 
-static char g_last_kernel[96] = "";
+static char g_last_kernel[192] = "";
 const char *last_score_kernel() { return g_last_kernel; }
 
 ScoreOptions &score_options() {
