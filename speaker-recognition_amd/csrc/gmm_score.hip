@@ -401,10 +401,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                              "identical sigma and weights, packed with that engine available)", SHARED_MIN_MODELS);
         use_shared = true;
     } else if (opt.engine == 3) {
-        if (!bx3_ok) fail("split-bf16 engine requested but the set has no bf16x3 layout");
+        if (!bx3_ok) fail("split-bf16 engine requested but the set has no bf16x3 layout (sets of more than 65536 mixtures pack "
+                         "only the layouts selected by score_engine when they are created)");
         use_bx3 = true;
     } else if (opt.engine == 2) {
-        if (!mfma_ok) fail("matrix-core engine requested but the set has no expanded-form layout");
+        if (!mfma_ok) fail("fp32 matrix-core engine requested but the set has no expanded-form layout (sets of more than 65536 "
+                         "mixtures pack only the layouts selected by score_engine when they are created)");
         use_mfma = true;
     } else if (opt.engine == 0) {
         // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
