@@ -208,6 +208,22 @@ def main():
                                "gmm_score": ms_score / max(1, args.steps), "finalize": ms_fin / max(1, args.steps)},
         "device": _lib.device_name(),
     }
+    if world == 1:
+        # the other engines on the same batch, outside the timed region (HIP-event time per launch)
+        alt = {}
+        _lib.profile_enable(True)
+        for name, eng in (("fp32_mfma", 2), ("vector_alu", 1)):
+            _lib.set_option("score_engine", eng)
+            ex.predict_batch(ms, pcm, nd=ND)
+            _lib.profile_reset()
+            for _ in range(3):
+                ex.predict_batch(ms, pcm, nd=ND)
+            t_alt, n_alt = _lib.profile_get(_lib.T_SCORE)
+            alt[name] = {"kernel": _lib.last_score_kernel(), "ms_per_launch": t_alt / max(1, n_alt),
+                         "frac_of_fp32_peak": flops_per_launch / (t_alt / max(1, n_alt) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+        _lib.set_option("score_engine", 0)
+        _lib.profile_enable(False)
+        result["roofline"]["other_engines"] = alt
     if not args.no_cpu_baseline and world == 1:
         cb, spec = cpu_baseline_leg(args.cpu_sample_utts, 10.04)
         if cb is None:
