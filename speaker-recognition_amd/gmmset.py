@@ -1,15 +1,15 @@
-"""Speaker set -- mirrors the reference's ``src/testbench/gmmset.py`` (GMMSet :15-91,
-GMMSetPyGMM :94-105): one GMM per label, prediction = argmax over speakers of the summed
-per-frame log-likelihood, optional UBM rejection.
+"""Speaker set -- API mirror of the reference's ``src/testbench/gmmset.py`` (``GMMSet`` :15-91,
+``GMMSetPyGMM`` :94-105): one GMM per label, prediction = arg max over speakers of the summed
+per-frame log-likelihood, optional open-set rejection against a UBM.  Same method names, arguments
+and results; the implementation is this package's.
 
-The reference scores speaker by speaker through the ABI (gmmset.py:59-64, :95-99).  Here all
-speaker models are packed into one device-resident set and scored in ONE fused launch: every
-frame tile is read from HBM once and walked over all S models.
+The reference scores speaker by speaker through the ABI (gmmset.py:59-64, :95-99).  Here every
+speaker model sits in one device-resident ``ModelSet`` and an utterance -- or a whole list of them
+-- is scored against all of them in ONE fused launch: each frame tile leaves HBM once.
 """
 from __future__ import annotations
 
-import operator
-from collections import defaultdict
+from collections import OrderedDict
 
 import numpy as np
 
@@ -19,48 +19,45 @@ from .pygmm import GMM
 
 class GMMSet(object):
     def __init__(self, gmm_order=32, ubm=None, reject_threshold=10, **kwargs):
-        self.kwargs = kwargs
-        self.gmms = []
-        self.ubm = ubm
-        self.reject_threshold = reject_threshold
-        if ubm is not None:
-            self.gmm_order = ubm.get_nr_mixtures()
-        else:
-            self.gmm_order = gmm_order
-        self.y = []
-        self._set = None            # packed device copy of self.gmms (rebuilt when the list changes)
+        self.ubm, self.reject_threshold, self.kwargs = ubm, reject_threshold, kwargs
+        # speakers adapted from a UBM inherit its size (gmmset.py:24-27)
+        self.gmm_order = gmm_order if ubm is None else ubm.get_nr_mixtures()
+        self.gmms, self.y = [], []
+        self._set = None            # packed device copy of self.gmms, rebuilt when the list changes
 
     # ---- enrolment ----
-    def fit_new(self, x, label):
-        self.y.append(label)
-        gmm = GMM(self.gmm_order, **self.kwargs)
-        gmm.fit(x, self.ubm)
+    def _append(self, label, gmm):
         self.gmms.append(gmm)
+        self.y.append(label)
         self._set = None
+
+    def fit_new(self, x, label):
+        """Train one model on the frames ``x`` (EM, or MAP adaptation when a UBM was given)."""
+        model = GMM(self.gmm_order, **self.kwargs)
+        model.fit(x, self.ubm)
+        self._append(label, model)
 
     def cluster_by_label(self, X, y):
-        Xtmp = defaultdict(list)
-        for ind, x in enumerate(X):
-            Xtmp[y[ind]].extend(x)
-        yp, Xp = zip(*Xtmp.items())
-        return Xp, yp
+        """Pool the frame lists of equal labels -> (tuple of frame lists, tuple of labels)."""
+        pooled = OrderedDict()
+        for frames, label in zip(X, y):
+            pooled.setdefault(label, []).extend(frames)
+        return tuple(pooled.values()), tuple(pooled.keys())
 
     def auto_tune_parameter(self, X, y):
-        return                       # a TODO in the reference as well (gmmset.py:45-48)
+        return None                  # unimplemented in the reference as well (gmmset.py:44-47)
 
     def fit(self, X, y):
-        X, y = self.cluster_by_label(X, y)
-        for ind, x in enumerate(X):
-            self.fit_new(x, y[ind])
-        self.auto_tune_parameter(X, y)
+        frames, labels = self.cluster_by_label(X, y)
+        for f, lab in zip(frames, labels):
+            self.fit_new(f, lab)
+        self.auto_tune_parameter(frames, labels)
 
     def load_gmm(self, label, fname):
-        self.y.append(label)
-        gmm = GMM.load(fname)
-        for key, val in self.kwargs.items():
-            setattr(gmm, key, val)
-        self.gmms.append(gmm)
-        self._set = None
+        model = GMM.load(fname)
+        for name, value in self.kwargs.items():
+            setattr(model, name, value)
+        self._append(label, model)
 
     # ---- scoring ----
     def _model_set(self):
@@ -69,35 +66,38 @@ class GMMSet(object):
         return self._set
 
     def gmm_score(self, gmm, x):
-        return np.sum(gmm.score(x))
+        return float(np.sum(gmm.score(x)))
 
     def predict_one_scores(self, x):
-        """Summed log-likelihood of utterance x under every speaker model (one launch)."""
-        sums, _ = self._model_set().score(Batch.from_features([x]))
-        return list(sums[0])
+        """Summed log-likelihood of utterance ``x`` under every speaker model (one launch)."""
+        totals, _ = self._model_set().score(Batch.from_features([x]))
+        return totals[0].tolist()
+
+    def _label_of_best(self, scores):
+        return self.y[int(np.argmax(scores))]          # numpy's argmax keeps the first maximum, as
+                                                        # max(enumerate(...)) does (gmmset.py:62-64)
 
     def predict_one(self, x):
-        scores = self.predict_one_scores(x)
-        return self.y[max(enumerate(scores), key=operator.itemgetter(1))[0]]   # first maximum wins
+        return self._label_of_best(self.predict_one_scores(x))
 
     def predict(self, X):
-        """All utterances in one batch; the argmax comes back from the device."""
-        X = list(X)
-        if not X:
+        """All utterances in one batch; the arg max comes back from the device."""
+        utterances = list(X)
+        if not utterances:
             return []
-        _, arg = self._model_set().score(Batch.from_features(X))
-        return [self.y[i] if i >= 0 else None for i in arg]
+        _, winners = self._model_set().score(Batch.from_features(utterances))
+        return [None if w < 0 else self.y[w] for w in winners]
 
     def predict_one_with_rejection(self, x):
-        assert self.ubm is not None, "UBM must be given prior to conduct reject prediction."
-        scores = self.predict_one_scores(x)
-        x_len = len(x)               # normalize score
-        scores = [v / x_len for v in scores]
-        max_tup = max(enumerate(scores), key=operator.itemgetter(1))
-        ubm_score = self.gmm_score(self.ubm, x) / x_len
-        if max_tup[1] - ubm_score < self.reject_threshold:
-            return None
-        return self.y[max_tup[0]]
+        """Open-set decision (gmmset.py:69-81): per-frame margin of the best speaker over the UBM
+        below ``reject_threshold`` -> None."""
+        if self.ubm is None:
+            raise AssertionError("UBM must be given prior to conduct reject prediction.")
+        n = float(len(x))
+        per_frame = np.asarray(self.predict_one_scores(x)) / n
+        best = int(np.argmax(per_frame))
+        margin = per_frame[best] - self.gmm_score(self.ubm, x) / n
+        return self.y[best] if margin >= self.reject_threshold else None
 
     def predict_with_reject(self, X):
         return [self.predict_one_with_rejection(x) for x in X]
@@ -105,18 +105,19 @@ class GMMSet(object):
 
 class GMMSetPyGMM(GMMSet):
     def predict_one(self, x):
-        scores = [s / len(x) for s in self.predict_one_scores(x)]              # gmmset.py:96
-        return self.y[max(enumerate(scores), key=operator.itemgetter(1))[0]]
+        # the reference divides every total by the frame count first (gmmset.py:96); same winner
+        return self._label_of_best(np.asarray(self.predict_one_scores(x)) / float(len(x)))
 
+    # models travel through pickle as their text dumps (gmmset.py:101-105)
     def before_pickle(self):
         self._set = None
-        self.gmms = [x.dumps() for x in self.gmms]
+        self.gmms = [m.dumps() for m in self.gmms]
 
     def after_pickle(self):
-        self.gmms = [GMM.loads(x) for x in self.gmms]
         self._set = None
+        self.gmms = [GMM.loads(text) for text in self.gmms]
 
     def __getstate__(self):
-        st = dict(self.__dict__)
-        st["_set"] = None
-        return st
+        state = dict(self.__dict__)
+        state["_set"] = None
+        return state
