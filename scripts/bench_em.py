@@ -17,7 +17,8 @@ from speaker_recognition_amd.pygmm import GMM  # noqa: E402
 
 
 def main():
-    n, K, D, iters = int(os.environ.get("EM_N", 512000)), 256, 13, 10
+    n, K, D, iters = (int(os.environ.get("EM_N", 512000)), int(os.environ.get("EM_K", 256)),
+                      int(os.environ.get("EM_D", 13)), int(os.environ.get("EM_ITERS", 10)))
     true = synth.synth_gmm(K, D, 5)
     X = synth.draw_frames(true, n, 11)
     g = GMM(K, nr_iteration=iters, threshold=-1.0, seed=3)      # threshold < 0: never stop early
