@@ -182,25 +182,15 @@ void gmm_score_bf16x3_kernel(const float *__restrict__ X, const TileDesc *__rest
                 n1 = at[((ks + 1) * 3 + 1) * 64];
                 n2 = at[((ks + 1) * 3 + 2) * 64];
             }
-            // smallest products first
+            // small products first, and consecutive MFMAs share one operand
+            const bf16x8 aa[6] = {a2, a1, a1, a0, a0, a0};
+            const int bi[6] = {0, 0, 1, 1, 2, 0};
 #pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, breg[ft][ks][0], ks == 0 ? zero16 : acc[ft], 0, 0, 0);
+            for (int pr = 0; pr < 6; pr++)
 #pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, breg[ft][ks][2], acc[ft], 0, 0, 0);
-#pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[ft][ks][1], acc[ft], 0, 0, 0);
-#pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, breg[ft][ks][0], acc[ft], 0, 0, 0);
-#pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, breg[ft][ks][1], acc[ft], 0, 0, 0);
-#pragma unroll
-            for (int ft = 0; ft < FT; ft++)
-                acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, breg[ft][ks][0], acc[ft], 0, 0, 0);
+                for (int ft = 0; ft < FT; ft++)
+                    acc[ft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa[pr], breg[ft][ks][bi[pr]],
+                                                                      (ks == 0 && pr == 0) ? zero16 : acc[ft], 0, 0, 0);
         }
         // online log2-sum-exp over this lane's 16 mixture rows of each frame column
 #pragma unroll

@@ -71,11 +71,12 @@ __device__ __forceinline__ void sh_chain(f32x16 &acc, const f32x16 &init, const 
             n1 = at[((ks + 1) * 3 + 1) * 64];
             n2 = at[((ks + 1) * 3 + 2) * 64];
         }
+        // small products first, consecutive MFMAs share one operand (as gmm_score_bf16x3.hip)
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[ks][0], ks == 0 ? init : acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[ks][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b[ks][0], acc, 0, 0, 0);
     }
 }
