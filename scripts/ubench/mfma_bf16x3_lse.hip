@@ -5,6 +5,7 @@
 // MFMAs of tile t inside one wave (two accumulators, sched_group_barrier pattern).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int KS = 5;
@@ -36,10 +37,13 @@ __device__ __forceinline__ void lse(const f32x16 &acc, float &m, float &ssum) {
     m = mn;
 }
 
+static int g_tiles = 800;
+static bool g_random_lds = false;
+
 template <int MODE, int WPE>
-__global__ __launch_bounds__(256, WPE) void k(float *out, const uint4 *bin, int tiles) {
+__global__ __launch_bounds__(256, WPE) void k(float *out, const uint4 *bin, int tiles, int rnd) {
     __shared__ uint4 lds[2][KS * 3 * 64];
-    for (int i = threadIdx.x; i < 2 * KS * 3 * 64; i += 256) (&lds[0][0])[i] = make_uint4(0x3c003c00u + i, 0x3a003b00u, 0x38003900u, 0x36003700u);
+    for (int i = threadIdx.x; i < 2 * KS * 3 * 64; i += 256) (&lds[0][0])[i] = rnd ? bin[(i * 7 + 3) & 255] : make_uint4(0x3c003c00u + i, 0x3a003b00u, 0x38003900u, 0x36003700u);
     __syncthreads();
     bf16x8 b[KS][3];
     for (int ks = 0; ks < KS; ks++)
@@ -88,17 +92,17 @@ __global__ __launch_bounds__(256, WPE) void k(float *out, const uint4 *bin, int 
 
 template <int MODE, int WPE>
 void run(const char *name, int blocks_per_cu, const uint4 *bin) {
-    int tiles = 800, grid = 256 * blocks_per_cu;
+    int tiles = g_tiles, grid = 256 * blocks_per_cu;
     float *out;
     hipMalloc(&out, (size_t)grid * 256 * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, 4);
+    hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, 4, (int)g_random_lds);
     hipDeviceSynchronize();
     float best = 1e9;
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < 6; r++) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, tiles);
+        hipLaunchKernelGGL((k<MODE, WPE>), dim3(grid), dim3(256), 0, 0, out, bin, tiles, (int)g_random_lds);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -110,8 +114,17 @@ void run(const char *name, int blocks_per_cu, const uint4 *bin) {
     hipFree(out);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    // argv[1] = "random": operand bits from an LCG instead of a constant pattern (data toggling -> power)
+    const bool rnd = argc > 1 && argv[1][0] == 'r';
     uint4 *bin; hipMalloc(&bin, 4096); hipMemset(bin, 0x3c, 4096);
+    if (rnd) {
+        unsigned h[1024]; unsigned x = 12345u;
+        for (int i = 0; i < 1024; i++) { x = x * 1664525u + 1013904223u; h[i] = (x & 0x807f807fu) | 0x3f003f00u; }   // bf16 pairs in [1,2) with random mantissas / signs
+        hipMemcpy(bin, h, 4096, hipMemcpyHostToDevice);
+    }
+    g_tiles = argc > 2 ? atoi(argv[2]) : 800;
+    g_random_lds = rnd;
     for (int w = 1; w <= 4; w++) {
         run<0, 4>("MFMA only", w, bin);
         run<1, 4>("MFMA then LSE epilogue", w, bin);
