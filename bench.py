@@ -189,6 +189,7 @@ def main():
         "metric": "frames/sec scored (MFCC+GMM)",
         "value": world * n_frames * args.steps / elapsed,
         "unit": "frames/s",
+        "frames_per_s_per_gpu": n_frames * args.steps / elapsed,
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
