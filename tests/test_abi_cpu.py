@@ -113,3 +113,27 @@ def test_compute_fails_loudly_without_gpu(built_lib, oracle_built, gmm_golden):
     rows = (C.POINTER(C.c_double) * len(X))(*[C.cast(X[i].ctypes.data, C.POINTER(C.c_double)) for i in range(len(X))])
     v = built_lib.score_all(m.gmm, rows, len(X), X.shape[1], 1)
     assert np.isnan(v) and b"no HIP device" in built_lib.sr_last_error()
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "speaker-recognition_amd", "lib")
+    exe = str(tmp_path / "predict_pcm")
+    cmd = [shutil.which("gcc") or "gcc", "-std=c99", "-D_DEFAULT_SOURCE", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+           os.path.join(root, "examples", "predict_pcm.c"), "-o", exe, "-L" + libdir, "-l:pygmm.so",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lm"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_header_is_plain_c_and_example_links(built_lib, tmp_path):
+    """include/pygmm_hip.h compiles as C99 (no C++ or HIP types at the boundary) and a plain-C host
+    (examples/predict_pcm.c) links against lib/pygmm.so; without a GPU it reports so and exits 2."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    import ctypes
+    if built_lib.sr_device_count() <= 0:
+        assert r.returncode == 2 and "no HIP device" in r.stderr

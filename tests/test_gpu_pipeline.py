@@ -225,3 +225,14 @@ def test_model_interface_default_mix_feature_roundtrip(built_lib, tmp_path):
     assert one == ["spk0", "spk9", "spk18"]
     assert m2.predict_many(tests) == one
     assert m2.predict(fs, np.zeros(100, np.int16)) is None          # too short: the reference swallows it (interface.py:89-93)
+
+
+def test_plain_c_host_example(built_lib, tmp_path):
+    """examples/predict_pcm.c -- the ABI driven from C99: models through the reference's text format,
+    PCM -> MFCC -> all speakers -> decisions in one call."""
+    import subprocess
+    from test_abi_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("-> speaker") == 3 and "kernel:" in r.stdout
