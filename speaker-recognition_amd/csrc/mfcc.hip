@@ -315,6 +315,7 @@ struct MelRuns {
     int pass_len[4];        // padded run length of the pass (multiple of 16)
 };
 
+constexpr int MFCC_DCT_LD = 68;     // row stride of the zero-padded DCT table in LDS (64 would put all 16 rows on the same banks)
 constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
 
 // One wave = one contiguous range of frames (binary search for the utterance once, then walk);
@@ -331,7 +332,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_2048^k, k < 1024
     float *s_melval = reinterpret_cast<float *>(s_tw + NC);
     float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
-    constexpr int DCT_LD = 64;
+    constexpr int DCT_LD = MFCC_DCT_LD;   // 68: rows 4 banks apart -> the 16 coefficient rows x 4 parts read 64 distinct banks
     const int dct_pad = 16 * DCT_LD;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -497,14 +498,18 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             const int len = mr.pass_len[ps];
-            const float *mv = s_melval + mr.pass_base[ps] + lane;     // step-major: 64 consecutive floats per step
-            const float *pp = pbuf + m_c0[ps] + m_part;
+            // one ds_read_b128 of weights and one of the power spectrum per 4 FMAs: lane (band, part)
+            // takes bins c0 + 16 it + 4 part + {0..3}; c0 is a multiple of 4, so both are 16-byte aligned
+            const float4 *mv4 = reinterpret_cast<const float4 *>(s_melval + mr.pass_base[ps]) + lane;
+            const float4 *pp4 = reinterpret_cast<const float4 *>(pbuf + m_c0[ps]) + m_part;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int i = 0; i < len; i += 16) {     // zero-padded runs: no bounds logic in the loop
-                a0 = fmaf(mv[16 * i], pp[i], a0);
-                a1 = fmaf(mv[16 * i + 64], pp[i + 4], a1);
-                a2 = fmaf(mv[16 * i + 128], pp[i + 8], a2);
-                a3 = fmaf(mv[16 * i + 192], pp[i + 12], a3);
+            for (int it = 0; it < (len >> 4); it++) {     // zero-padded runs: no bounds logic in the loop
+                const float4 wv = mv4[it * 64];
+                const float4 xv = pp4[it * 4];
+                a0 = fmaf(wv.x, xv.x, a0);
+                a1 = fmaf(wv.y, xv.y, a1);
+                a2 = fmaf(wv.z, xv.z, a2);
+                a3 = fmaf(wv.w, xv.w, a3);
             }
             float acc = (a0 + a1) + (a2 + a3);
             acc += __shfl_xor(acc, 1, 64);
@@ -693,7 +698,7 @@ static MfccDev upload_tables(SRMfcc &m) {
             const int ps = b / 16, bl = b % 16;
             for (int i = 0; i < cnt[b]; i++) {
                 const int e = lead[b] + i;
-                padv[(size_t)t->pass_base[ps] + (size_t)(e >> 2) * 64 + (size_t)bl * 4 + (e & 3)] = val[row[b] + i];
+                padv[(size_t)t->pass_base[ps] + (size_t)(e >> 4) * 256 + ((size_t)bl * 4 + ((e >> 2) & 3)) * 4 + (e & 3)] = val[row[b] + i];
             }
             if (start[b] + t->pass_len[ps] + 3 > 1100) t->runs_contiguous = false;   // padded sweep must stay inside the slab's power-spectrum region
         }
@@ -797,7 +802,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
                 mr.pass_len[ps] = tabs.pass_len[ps];
             }
             const size_t lds = (size_t)1024 * sizeof(float2) +
-                               (size_t)(tabs.pad_floats + 16 * 64) * sizeof(float) +
+                               (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
                                (size_t)4 * WAVE_SLAB_C * sizeof(float2);
             // one contiguous frame range per wave; enough waves to fill the chip a few times over
             const int blocks_per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
