@@ -480,14 +480,16 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             const int k = lane + 64 * j;
             const float2 zk = v[j];                              // Z[lane + 64 j] is this lane's own output
             const float2 zr = slab[(NC - k) & (NC - 1)];
-            const float2 e = make_float2(0.5f * (zk.x + zr.x), 0.5f * (zk.y - zr.y));
-            const float2 o = make_float2(0.5f * (zk.y + zr.y), -0.5f * (zk.x - zr.x));
-            const float2 xo = cmul(utw[j], o);
-            const float xr = e.x + xo.x, xi = e.y + xo.y;
-            pw[j] = xr * xr + xi * xi;
+            // 2 X[k] = (Zk + conj Zr) - i W^k (Zk - conj Zr): the factor 1/2 is left out here and the
+            // resulting 4x in the power is folded into the mel weights on the host (x 0.25)
+            const float ex = zk.x + zr.x, ey = zk.y - zr.y;
+            const float ox = zk.y + zr.y, oy = zr.x - zk.x;
+            const float xr = fmaf(-utw[j].y, oy, fmaf(utw[j].x, ox, ex));
+            const float xi = fmaf(utw[j].y, ox, fmaf(utw[j].x, oy, ey));
+            pw[j] = fmaf(xr, xr, xi * xi);
         }
         const float2 z0 = slab[0];
-        const float nyq = (z0.x - z0.y) * (z0.x - z0.y);       // X[1024] = Re Z0 - Im Z0
+        const float nyq = 4.0f * (z0.x - z0.y) * (z0.x - z0.y);   // X[1024] = Re Z0 - Im Z0 (x4: same scale as the other bins)
         wave_sync();
 #pragma unroll
         for (int j = 0; j < 16; j++) pbuf[lane + 64 * j] = pw[j];
@@ -698,7 +700,7 @@ static MfccDev upload_tables(SRMfcc &m) {
             const int ps = b / 16, bl = b % 16;
             for (int i = 0; i < cnt[b]; i++) {
                 const int e = lead[b] + i;
-                padv[(size_t)t->pass_base[ps] + (size_t)(e >> 4) * 256 + ((size_t)bl * 4 + ((e >> 2) & 3)) * 4 + (e & 3)] = val[row[b] + i];
+                padv[(size_t)t->pass_base[ps] + (size_t)(e >> 4) * 256 + ((size_t)bl * 4 + ((e >> 2) & 3)) * 4 + (e & 3)] = 0.25f * val[row[b] + i];   // the fast kernel's power spectrum is 4 |X|^2
             }
             if (start[b] + t->pass_len[ps] + 3 > 1100) t->runs_contiguous = false;   // padded sweep must stay inside the slab's power-spectrum region
         }
