@@ -322,7 +322,16 @@ constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17,
 // per-lane constants (window taps, pass-1/2 twiddles) live in registers, the untangle twiddles
 // and the mel / DCT tables in LDS; the next frame's samples are prefetched while the current
 // frame is transformed.
-template <typename PcmT, int NZ1>
+// Mel sweep lengths (16-bin steps per pass of 16 bands) of the two common filterbanks, known at
+// compile time so that the sweep unrolls completely and its LDS reads are issued ahead of their use;
+// preset 0 takes the lengths from MelRuns at run time (any other fs / n_filters).
+__host__ __device__ constexpr int mel_preset_steps(int preset, int pass) {
+    return preset == 1 ? (pass == 0 ? 2 : pass == 1 ? 3 : pass == 2 ? 6 : 7)      // fs 16 kHz, 50 filters, FFT 2048
+         : preset == 2 ? (pass == 0 ? 2 : pass == 1 ? 4 : 6)                       // fs  8 kHz, 50 filters, FFT 2048
+                       : 0;
+}
+
+template <typename PcmT, int NZ1, int MP>
 __global__ __launch_bounds__(256)
 void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
                                 const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
@@ -505,13 +514,25 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             const float4 *mv4 = reinterpret_cast<const float4 *>(s_melval + mr.pass_base[ps]) + lane;
             const float4 *pp4 = reinterpret_cast<const float4 *>(pbuf + m_c0[ps]) + m_part;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int it = 0; it < (len >> 4); it++) {     // zero-padded runs: no bounds logic in the loop
-                const float4 wv = mv4[it * 64];
-                const float4 xv = pp4[it * 4];
-                a0 = fmaf(wv.x, xv.x, a0);
-                a1 = fmaf(wv.y, xv.y, a1);
-                a2 = fmaf(wv.z, xv.z, a2);
-                a3 = fmaf(wv.w, xv.w, a3);
+            if constexpr (MP != 0) {
+#pragma unroll
+                for (int it = 0; it < mel_preset_steps(MP, ps); it++) {
+                    const float4 wv = mv4[it * 64];
+                    const float4 xv = pp4[it * 4];
+                    a0 = fmaf(wv.x, xv.x, a0);
+                    a1 = fmaf(wv.y, xv.y, a1);
+                    a2 = fmaf(wv.z, xv.z, a2);
+                    a3 = fmaf(wv.w, xv.w, a3);
+                }
+            } else {
+                for (int it = 0; it < (len >> 4); it++) {     // zero-padded runs: no bounds logic in the loop
+                    const float4 wv = mv4[it * 64];
+                    const float4 xv = pp4[it * 4];
+                    a0 = fmaf(wv.x, xv.x, a0);
+                    a1 = fmaf(wv.y, xv.y, a1);
+                    a2 = fmaf(wv.z, xv.z, a2);
+                    a3 = fmaf(wv.w, xv.w, a3);
+                }
             }
             float acc = (a0 + a1) + (a2 + a3);
             acc += __shfl_xor(acc, 1, 64);
@@ -813,9 +834,21 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
             const int64_t n_waves = (NF + frames_per_wave - 1) / frames_per_wave;
             const int grid = (int)((n_waves + 3) / 4);
             const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
+            int preset = 0;
+            for (int pr = 1; pr <= 2 && !preset; pr++) {
+                bool same = true;
+                for (int ps = 0; ps < 4; ps++) same = same && tabs.pass_len[ps] == 16 * mel_preset_steps(pr, ps);
+                if (same) preset = pr;
+            }
 #define SR_LAUNCH_FAST(PT, NZ, PCMPTR)                                                              \
     do {                                                                                             \
-        auto kern = mfcc_frames_fft2048_kernel<PT, NZ>;                                              \
+        if (preset == 1) SR_LAUNCH_FAST_P(PT, NZ, 1, PCMPTR);                                        \
+        else if (preset == 2) SR_LAUNCH_FAST_P(PT, NZ, 2, PCMPTR);                                   \
+        else SR_LAUNCH_FAST_P(PT, NZ, 0, PCMPTR);                                                    \
+    } while (0)
+#define SR_LAUNCH_FAST_P(PT, NZ, MPV, PCMPTR)                                                       \
+    do {                                                                                             \
+        auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV>;                                         \
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, PCMPTR, pcm.d_offsets.p,  \
@@ -827,6 +860,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
                 if (nz1 <= 4) SR_LAUNCH_FAST(float, 4, pcm.data.p); else SR_LAUNCH_FAST(float, 16, pcm.data.p);
             }
 #undef SR_LAUNCH_FAST
+#undef SR_LAUNCH_FAST_P
         } else {
             const int nc = m.fft_size / 2;
             const size_t lds = (size_t)nc * sizeof(float2) * (1 + 4 * 2) + 4 * 64 * sizeof(float);
