@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "pygmm.so")
+# SR_PYGMM_LIB points at another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SR_PYGMM_LIB") or os.path.join(_HERE, "lib", "pygmm.so")
 
 LEGACY_SYMBOLS = ["new_gmm", "load", "dump", "train_model", "train_model_from_ubm", "score_all",
                   "score_batch", "score_instance", "get_dim", "get_nr_mixtures"]

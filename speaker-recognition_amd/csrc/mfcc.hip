@@ -315,7 +315,9 @@ struct MelRuns {
     int pass_len[4];        // padded run length of the pass (multiple of 16)
 };
 
-constexpr int MFCC_DCT_LD = 68;     // row stride of the zero-padded DCT table in LDS (64 would put all 16 rows on the same banks)
+constexpr int MFCC_DCT_LD = 80;     // row stride of the zero-padded DCT table in LDS: 320 B = 64 B mod 256, so the 4 rows x 4
+                                    // parts of a 16-lane ds_read_b128 phase cover 16 distinct 16-byte windows (64 floats would put
+                                    // all 16 rows on the same banks)
 constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
 
 // One wave = one contiguous range of frames (binary search for the utterance once, then walk);
@@ -341,7 +343,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_2048^k, k < 1024
     float *s_melval = reinterpret_cast<float *>(s_tw + NC);
     float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
-    constexpr int DCT_LD = MFCC_DCT_LD;   // 68: rows 4 banks apart -> the 16 coefficient rows x 4 parts read 64 distinct banks
+    constexpr int DCT_LD = MFCC_DCT_LD;
     const int dct_pad = 16 * DCT_LD;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -548,13 +550,19 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         // ---- DCT-II rows 1..n_ceps: 4 lanes per coefficient, zero-padded table [16][64] ----
         {
             const int cidx = lane >> 2;
-            const float *drow = s_dct + cidx * DCT_LD + m_part;
-            const float *lp = s_lm + m_part;
+            // lane (coefficient, part) takes bands 16 it + 4 part + {0..3}: one 16-byte read of the row
+            // and one of the log-mel vector per 4 FMAs
+            const float4 *drow = reinterpret_cast<const float4 *>(s_dct + cidx * DCT_LD) + m_part;
+            const float4 *lp = reinterpret_cast<const float4 *>(s_lm) + m_part;
             float o0 = 0.f, o1 = 0.f;
 #pragma unroll
-            for (int b = 0; b < 64; b += 8) {
-                o0 = fmaf(drow[b], lp[b], o0);
-                o1 = fmaf(drow[b + 4], lp[b + 4], o1);
+            for (int it = 0; it < 4; it++) {
+                const float4 dv = drow[it * 4];
+                const float4 lv = lp[it * 4];
+                o0 = fmaf(dv.x, lv.x, o0);
+                o1 = fmaf(dv.y, lv.y, o1);
+                o0 = fmaf(dv.z, lv.z, o0);
+                o1 = fmaf(dv.w, lv.w, o1);
             }
             float o = o0 + o1;
             o += __shfl_xor(o, 1, 64);
