@@ -541,6 +541,8 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");
         score_options().mfma_ft = (int)value;
+    } else if (k == "mfcc_waves_per_block") {
+        mfcc_set_waves_per_block((int)value);
     } else if (k == "mfcc_generic") {
         mfcc_set_force_generic(value != 0);
     } else {

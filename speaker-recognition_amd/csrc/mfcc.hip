@@ -99,6 +99,7 @@ struct MfccDev {
 };
 
 bool mfcc_force_generic();
+int mfcc_waves_per_block();
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -333,8 +334,11 @@ __host__ __device__ constexpr int mel_preset_steps(int preset, int pass) {
                        : 0;
 }
 
-template <typename PcmT, int NZ1, int MP>
-__global__ __launch_bounds__(256)
+// WPB = waves per workgroup: 4 (per-lane twiddle constants in registers, 2 waves/SIMD) or 12 (the
+// pass-1 and untangle twiddles read from LDS instead: <= 168 VGPRs, 3 waves/SIMD; one workgroup per
+// CU, its tables shared by 12 waves).
+template <typename PcmT, int NZ1, int MP, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 3)
 void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
                                 const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
                                 int64_t frames_per_wave, MfccDev p, MelRuns mr, float *__restrict__ raw) {
@@ -345,31 +349,41 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
     constexpr int DCT_LD = MFCC_DCT_LD;
     const int dct_pad = 16 * DCT_LD;
+    constexpr bool LDS_TW = WPB != 4;                                // twiddle constants in LDS, not registers
+    float2 *s_wk = reinterpret_cast<float2 *>(s_dct + dct_pad);      // [16][64] W_1024^(lane*k1) (LDS_TW only)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float2 *slab = reinterpret_cast<float2 *>(s_dct + dct_pad) + (size_t)wave * WAVE_SLAB_C;
+    float2 *slab = s_wk + (LDS_TW ? 16 * 64 : 0) + (size_t)wave * WAVE_SLAB_C;
     float *pbuf = reinterpret_cast<float *>(slab);          // power spectrum, 1025 floats
     float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
 
-    for (int i = threadIdx.x; i < NC; i += 256) s_tw[i] = p.twiddle[i];
-    for (int i = threadIdx.x; i < mr.pad_floats; i += 256) s_melval[i] = mr.pad_val[i];
-    for (int i = threadIdx.x; i < 16 * DCT_LD; i += 256) {
+    for (int i = threadIdx.x; i < NC; i += 64 * WPB) s_tw[i] = p.twiddle[i];
+    for (int i = threadIdx.x; i < mr.pad_floats; i += 64 * WPB) s_melval[i] = mr.pad_val[i];
+    for (int i = threadIdx.x; i < 16 * DCT_LD; i += 64 * WPB) {
         const int c = i / DCT_LD, b = i - c * DCT_LD;
         s_dct[i] = (c < p.n_ceps && b < p.n_filters) ? p.dct[c * p.n_filters + b] : 0.f;
     }
     __syncthreads();
+    if (LDS_TW) {
+        for (int i = threadIdx.x; i < 16 * 64; i += 64 * WPB) s_wk[i] = tw(s_tw, (2 * (i & 63) * (i >> 6)) & 2047, NC);
+        __syncthreads();
+    }
 
     // ---- per-lane constants ----
-    float2 wk[16];        // W_1024^(lane*k1)
+    float2 wk[LDS_TW ? 1 : 16];        // W_1024^(lane*k1)
+    if (!LDS_TW) {
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(s_tw, (2 * lane * k1) & 2047, NC);
+        for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(s_tw, (2 * lane * k1) & 2047, NC);
+    }
     const int bb = lane & 15, gg = lane >> 4;
     float2 w64[4];        // W_64^(b*c)
 #pragma unroll
     for (int c = 0; c < 4; c++) w64[c] = tw(s_tw, (32 * bb * c) & 2047, NC);
-    float2 utw[16];       // untangle twiddles W_2048^(lane + 64 j)
+    float2 utw[LDS_TW ? 1 : 16];       // untangle twiddles W_2048^(lane + 64 j)
+    if (!LDS_TW) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) utw[j] = s_tw[lane + 64 * j];
+        for (int j = 0; j < 16; j++) utw[j] = s_tw[lane + 64 * j];
+    }
     const int L = p.frame_len;
     // window taps of this lane's samples: y[i0] = w0 x[i0] - wm x[i0-1], y[i0+1] = w1 x[i0+1] - w0p x[i0]
     float win_m[NZ1], win_0[NZ1], win_1[NZ1], win_0p[NZ1];
@@ -392,7 +406,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         m_floor[ps] = band < p.n_filters ? p.mel_floor[band] : 0.f;
     }
 
-    const int64_t gwave = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t gwave = (int64_t)blockIdx.x * WPB + wave;
     const int64_t f_begin = gwave * frames_per_wave;
     const int64_t f_end = f_begin + frames_per_wave < n_frames ? f_begin + frames_per_wave : n_frames;
     if (f_begin >= f_end) return;      // whole wave idle (no workgroup barrier below this point)
@@ -456,7 +470,7 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         // ---- pass 1: 16-point DFT over n1, twiddle, exchange ----
         dft16<(NZ1 <= 4 ? 4 : 16)>(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], wk[k1]);
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], LDS_TW ? s_wk[k1 * 64 + lane] : wk[k1]);
         wave_sync();      // previous frame's readers are done with the slab
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) slab[k1 * 68 + lane] = v[k1];
@@ -495,8 +509,9 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             // resulting 4x in the power is folded into the mel weights on the host (x 0.25)
             const float ex = zk.x + zr.x, ey = zk.y - zr.y;
             const float ox = zk.y + zr.y, oy = zr.x - zk.x;
-            const float xr = fmaf(-utw[j].y, oy, fmaf(utw[j].x, ox, ex));
-            const float xi = fmaf(utw[j].y, ox, fmaf(utw[j].x, oy, ey));
+            const float2 ut = LDS_TW ? s_tw[lane + 64 * j] : utw[j];
+            const float xr = fmaf(-ut.y, oy, fmaf(ut.x, ox, ex));
+            const float xi = fmaf(ut.y, ox, fmaf(ut.x, oy, ey));
             pw[j] = fmaf(xr, xr, xi * xi);
         }
         const float2 z0 = slab[0];
@@ -769,6 +784,12 @@ static bool &mfcc_force_generic_flag() {
     return f;
 }
 bool mfcc_force_generic() { return mfcc_force_generic_flag(); }
+static int &mfcc_wpb_flag() {
+    static int v = 12;   // measured on cfg-1: 1.885 ms against 1.975 ms with 4 (scripts/time_mfcc.py)
+    return v;
+}
+int mfcc_waves_per_block() { return mfcc_wpb_flag(); }
+void mfcc_set_waves_per_block(int w) { mfcc_wpb_flag() = (w == 12) ? 12 : 4; }
 void mfcc_set_force_generic(bool on) { mfcc_force_generic_flag() = on; }
 
 struct MfccWorkspace {
@@ -832,15 +853,19 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
                 mr.pass_base[ps] = tabs.pass_base[ps];
                 mr.pass_len[ps] = tabs.pass_len[ps];
             }
-            const size_t lds = (size_t)1024 * sizeof(float2) +
-                               (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
-                               (size_t)4 * WAVE_SLAB_C * sizeof(float2);
+            auto lds_for = [&](int w) {
+                return (size_t)1024 * sizeof(float2) + (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
+                       (w == 4 ? 0 : (size_t)16 * 64 * sizeof(float2)) + (size_t)w * WAVE_SLAB_C * sizeof(float2);
+            };
+            int wpb = mfcc_waves_per_block();
+            if (wpb == 12 && lds_for(12) > (size_t)160 * 1024) wpb = 4;      // a very wide filterbank: tables too big for one 12-wave workgroup
+            const size_t lds = lds_for(wpb);
             // one contiguous frame range per wave; enough waves to fill the chip a few times over
             const int blocks_per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
-            const int64_t max_waves = (int64_t)ctx().n_cu * blocks_per_cu * 4 * 4;
+            const int64_t max_waves = (int64_t)ctx().n_cu * blocks_per_cu * wpb * 4;
             const int64_t frames_per_wave = std::max<int64_t>(8, (NF + max_waves - 1) / max_waves);
             const int64_t n_waves = (NF + frames_per_wave - 1) / frames_per_wave;
-            const int grid = (int)((n_waves + 3) / 4);
+            const int grid = (int)((n_waves + wpb - 1) / wpb);
             const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
             int preset = 0;
             for (int pr = 1; pr <= 2 && !preset; pr++) {
@@ -856,10 +881,14 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     } while (0)
 #define SR_LAUNCH_FAST_P(PT, NZ, MPV, PCMPTR)                                                       \
     do {                                                                                             \
-        auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV>;                                         \
+        if (wpb == 12) SR_LAUNCH_FAST_W(PT, NZ, MPV, 12, PCMPTR); else SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, PCMPTR); \
+    } while (0)
+#define SR_LAUNCH_FAST_W(PT, NZ, MPV, W, PCMPTR)                                                    \
+    do {                                                                                             \
+        auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV, W>;                                      \
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, PCMPTR, pcm.d_offsets.p,  \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, ctx().stream, PCMPTR, pcm.d_offsets.p, \
                            w.raw_off.p, U, NF, frames_per_wave, dev, mr, w.raw.p);                   \
     } while (0)
             if (pcm.kind == SRBatch::PCM16) {
@@ -869,6 +898,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
             }
 #undef SR_LAUNCH_FAST
 #undef SR_LAUNCH_FAST_P
+#undef SR_LAUNCH_FAST_W
         } else {
             const int nc = m.fft_size / 2;
             const size_t lds = (size_t)nc * sizeof(float2) * (1 + 4 * 2) + 4 * 64 * sizeof(float);
