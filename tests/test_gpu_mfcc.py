@@ -97,3 +97,42 @@ def test_lpc_and_mix_feature_vs_oracle(built_lib):
         assert np.array_equal(only, mix[:, 13:])
         assert np.all(only[np.all(ref_l == 0, axis=1)] == 0)
     assert mix_feature((16000, synth.synth_speech(1, 0.5, 16000)), lpc=False).shape[1] == 13
+
+
+def test_full_size_cfg1_feature_properties(built_lib):
+    """The feature side of BASELINE configs[1] at full size (1000 utterances x 1000 frames, 16 kHz,
+    25/10 ms, 39 dims): too large for the float64 oracle, so size-independent properties -- an
+    utterance's features do not depend on where it sits in the batch (bit-identical after a
+    permutation), the delta columns are exactly the first and second differences of the static ones,
+    every static column is standardised (CMVN: mean 0, population variance 1), a gain on the waveform
+    moves nothing after CMVN, and a strided sample of utterances agrees with the oracle."""
+    import bench
+    from oracle import mfcc_oracle as mo
+    from speaker_recognition_amd.core import Batch, MfccExtractor
+    clips, _ = bench.build_workload(0, 1000, 1000)
+    ex = MfccExtractor(bench.FS, **bench.MFCC_KW)
+    got = ex.extract_batch(Batch.from_pcm(clips), nd=2)
+    X, off = got.download(), got.offsets()
+    assert X.shape == (1000 * 1000, 39) and np.all(np.isfinite(X))
+    assert np.all(np.diff(off) == 1000)
+    perm = np.random.default_rng(0).permutation(1000)
+    got2 = ex.extract_batch(Batch.from_pcm([clips[i] for i in perm]), nd=2)
+    X2 = got2.download()
+    for j in (0, 1, 500, 999):
+        assert np.array_equal(X2[j * 1000:(j + 1) * 1000], X[perm[j] * 1000:(perm[j] + 1) * 1000])
+    # deltas are taken after CMVN on rows t-1, t-2 of the normalised statics (utils.py:24-31); the first
+    # two normalised rows of an utterance are not emitted, so check from the third emitted row on
+    U = X.reshape(1000, 1000, 39)
+    s, d1, d2 = U[:, :, :13], U[:, :, 13:26], U[:, :, 26:]
+    assert np.max(np.abs(d1[:, 1:] - (s[:, 1:] - s[:, :-1]))) < 2e-6
+    assert np.max(np.abs(d2[:, 1:] - (d1[:, 1:] - d1[:, :-1]))) < 4e-6
+    raw = ex.extract_batch(Batch.from_pcm(clips[:50]), nd=0).download().reshape(50, 1002, 13)
+    assert np.max(np.abs(raw.mean(axis=1))) < 2e-5 and np.max(np.abs(raw.var(axis=1) - 1.0)) < 2e-4
+    loud = [np.clip(c.astype(np.float32) * 1.9, -32768, 32767) for c in clips[:20]]
+    soft = [c.astype(np.float32) for c in clips[:20]]
+    a = ex.extract_batch(Batch.from_pcm(loud), nd=2).download()
+    b = ex.extract_batch(Batch.from_pcm(soft), nd=2).download()
+    assert np.max(np.abs(a - b)) < 2e-3              # ln(gain^2) is a constant per band: CMVN removes it
+    for u in (0, 499, 998):
+        ref = mo.extract(bench.FS, clips[u], diff=True, nd=2, **bench.MFCC_KW)
+        assert np.max(np.abs(X[off[u]:off[u + 1]] - ref)) < 1e-3
