@@ -32,7 +32,7 @@ constexpr float M_LN_1E_15_F = -34.538776394910684f;
 
 __host__ __device__ constexpr int mfma_waves_per_eu(int dp, int ft) {
     const int regs = ft * (((dp + 1 + 3) & ~3) + 16) + 72;
-    return regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
+    return regs <= 128 ? 4 : regs <= 140 ? 3 : regs <= 256 ? 2 : 1;
 }
 
 template <int DP, int FT>
