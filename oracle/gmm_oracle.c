@@ -133,7 +133,7 @@ static double gaussian_logprob(const double *x, const double *mean, const double
  *   mode 1: GMM::log_probability_of, src/gmm/src/gmm.cc:229-235 (libm exp, linear domain).
  *   mode 2: float64 log-sum-exp over per-mixture log densities (gmm.cc:78-99 for the
  *           density) -- the formulation the HIP kernel uses; `clamp_compat` applies the
- *           reference's underflow behaviour (LL < -708.396 -> ln(1e-15)).
+ *           reference's underflow behaviour (terms < DBL_MIN are 0; none left -> ln(1e-15)).
  * Layout: weights[K], mean[K*D], sigma[K*D] (sigma = standard deviations, gmm.hh:24-46),
  * X[n*D] row-major, out[n].
  */
@@ -160,12 +160,21 @@ void oracle_gmm_score_batch(const double *weights, const double *mean, const dou
                        gaussian_logprob(x, mean + (long)k * D, sigma + (long)k * D, D);
                 if (v[k] > m) m = v[k];
             }
+            /* The reference's sum (gmm.cc:237-244) runs in the LINEAR domain under the FTZ
+             * arithmetic its -ffast-math DSO switches on: a term w_k p_k below DBL_MIN =
+             * exp(-708.396...) is exactly 0 there.  So with `clamp_compat` such terms are left out
+             * of the sum, and when none survives -- the largest term below DBL_MIN -- the result is
+             * safe_log's ln(1e-15), gmm.cc:34-38.  (Mode 0 additionally reproduces the flush of
+             * partial products in dimension order and the per-dimension exponent floor of
+             * fastexp.cc:104-131, which no log-domain formulation can.) */
+            const double minlog = -7.08396418532264106224e2;
             double s = 0;
             for (int k = 0; k < K; k++)
-                s += exp(v[k] - m);
+                if (!clamp_compat || v[k] >= minlog)
+                    s += exp(v[k] - m);
             double ll = m + log(s);
             free(v);
-            if (clamp_compat && ll < -7.08396418532264106224e2)
+            if (clamp_compat && m < minlog)
                 ll = log(1e-15);
             out[t] = ll;
         }

@@ -22,7 +22,8 @@ X = np.concatenate(utts).astype(np.float64)
 want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=False) for m in models])
 ms = ModelSet([GMM.from_arrays(*m) for m in models])
 out = {"frames": int(X.shape[0]), "models": S, "mixtures": K, "dim": D}
-for name, eng in (("vector_alu_direct_form", 1), ("fp32_mfma_expanded_form", 2), ("split_bf16_mfma_expanded_form", 3)):
+for name, eng in (("vector_alu_direct_form", 1), ("fp32_mfma_expanded_form", 2), ("split_bf16_mfma_expanded_form", 3),
+                  ("split_fp16_mfma_expanded_form", 5)):
     _lib.set_option("score_engine", eng)
     sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
     rel = np.abs(fll - want) / np.maximum(1.0, np.abs(want))

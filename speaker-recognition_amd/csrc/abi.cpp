@@ -460,8 +460,13 @@ int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, doubl
     static SRBatch *feat_ws = new SRBatch();   // reused across steps: the serving loop allocates nothing
     mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
     const ScoreResult r = score_device(*set, *feat_ws, false, flags);
-    fetch_results(r, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
-                  argmax_out, nullptr);
+    if (!fetch_results(r, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
+                       argmax_out, nullptr)) {
+        // a frame left the fp16 engine's range: score the batch again on the fp32-grade engines
+        const ScoreResult r2 = score_device(*set, *feat_ws, false, flags | SCORE_PRECISE);
+        fetch_results(r2, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
+                      argmax_out, nullptr);
+    }
     return 0;
     SR_CATCH(-1)
 }
@@ -534,9 +539,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_packed") {
         score_options().packed = (int)value;
     } else if (k == "score_engine") {
-        if (value < 0 || value > 4)
-            fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores) "
-                 "or 4 (split-bf16, shared-sigma form)");
+        if (value < 0 || value > 6)
+            fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores), "
+                 "4 (split-bf16, shared-sigma form), 5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form)");
         score_options().engine = (int)value;
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");

@@ -274,7 +274,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         const int n_records = (K + KB - 1) / KB;
         const int K_pad = n_records * KB;
         const int REC = 2 * DP + 1;
-        const ScoreResult sres = score_device(set, feat, true, 0);
+        const ScoreResult sres = score_device(set, feat, true, SCORE_PRECISE);
         std::vector<float> mean_f32((size_t)K_pad * DP, 0.f);
         for (int k = 0; k < K; k++)
             for (int d = 0; d < dim; d++) mean_f32[(size_t)k * DP + d] = (float)gmm.mean[(size_t)k * dim + d];
@@ -338,7 +338,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         set2.host = pack_models({&gmm});
         upload_model_set(set2);
         double ll = 0.0;
-        score_batch_set(set2, feat, &ll, nullptr, nullptr, SR_CLAMP_COMPAT);
+        score_batch_set(set2, feat, &ll, nullptr, nullptr, SR_CLAMP_COMPAT | SCORE_PRECISE);
         if (param.verbosity >= 1) printf("iter %d: ll %lf\n", it, ll);
         const double ll_diff = ll - last_ll;
         if (std::fabs(ll_diff) / std::fabs(ll) < param.threshold && ll_diff < param.threshold) {

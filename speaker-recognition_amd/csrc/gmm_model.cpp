@@ -254,24 +254,83 @@ void split_bf16x3(float v, uint16_t out[3]) {
     out[2] = (uint16_t)(l >> 16);
 }
 
-PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models) {
-    PackedBf16x3 pm;
+// IEEE binary16 <-> binary32 on the host (round-to-nearest-even, gradual underflow, saturating to
+// +-inf like v_cvt_f16_f32); the packers must produce exactly what the device conversion would.
+uint16_t f32_to_f16_rne(float v) {
+    const uint32_t u = f32_bits(v);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((a > 0x7F800000u) ? 0x200u : 0u));
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);           // rounds to >= 65520 -> inf
+    if (a < 0x33000001u) return (uint16_t)sign;                         // <= 2^-25 -> 0 (ties to even)
+    int e = (int)(a >> 23) - 127;
+    uint32_t mant = (a & 0x7FFFFFu) | 0x800000u;                        // 24 bits
+    int shift = (e >= -14) ? 13 : (13 + (-14 - e));                     // bits dropped
+    uint32_t q = mant >> shift;
+    const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    uint32_t out;
+    if (e >= -14)
+        out = ((uint32_t)(e + 15) << 10) + (q - 0x400u);                // a carry out of q bumps the exponent
+    else
+        out = q;                                                        // subnormal (q == 0x400 becomes the smallest normal)
+    return (uint16_t)(sign | out);
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0x1F) return bits_f32(sign | 0x7F800000u | (m << 13));
+    if (e == 0) {
+        const float v = (float)m * 5.9604644775390625e-08f;            // m * 2^-24
+        return sign ? -v : v;
+    }
+    return bits_f32(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+void split_f16x2(float v, uint16_t out[2]) {
+    out[0] = f32_to_f16_rne(v);
+    const float r = v - f16_to_f32(out[0]);      // exact in fp32
+    out[1] = f32_to_f16_rne(r);
+}
+
+PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme) {
+    PackedSplit pm;
+    pm.scheme = scheme;
+    pm.parts = scheme == SPLIT_F16X2 ? 2 : 3;
+    const int P = pm.parts;
     const int dim = models[0]->dim;
     pm.ks = (dim + 1 + 7) / 8;
     const int KS = pm.ks;
-    const size_t tile_u16 = (size_t)KS * 3 * 64 * 8;
+    const size_t tile_u16 = (size_t)KS * P * 64 * 8;
     const double LOG2E = 1.4426950408889634073599;
     const double SQRT_2_PI = 2.5066282746310002;
+    const float dead = scheme == SPLIT_F16X2 ? F16_NEG_BIG : NEG_BIG;
     pm.center.assign(dim, 0.0f);
+    pm.scale.assign(dim, 1.0f);
     {
-        std::vector<double> acc(dim, 0.0);
+        std::vector<double> acc(dim, 0.0), lsum(dim, 0.0), smin(dim, INFINITY), smax(dim, 0.0);
         size_t cnt = 0;
         for (const GMM *g : models) {
             for (int k = 0; k < g->nr_mixtures; k++)
-                for (int d = 0; d < dim; d++) acc[d] += g->mean[(size_t)k * dim + d];
+                for (int d = 0; d < dim; d++) {
+                    const double sg = g->sigma[(size_t)k * dim + d];
+                    acc[d] += g->mean[(size_t)k * dim + d];
+                    lsum[d] += std::log2(sg);
+                    smin[d] = std::min(smin[d], sg);
+                    smax[d] = std::max(smax[d], sg);
+                }
             cnt += (size_t)g->nr_mixtures;
         }
-        for (int d = 0; d < dim; d++) pm.center[d] = (float)(acc[d] / (double)cnt);
+        for (int d = 0; d < dim; d++) {
+            pm.center[d] = (float)(acc[d] / (double)cnt);
+            pm.sigma_ratio = std::max(pm.sigma_ratio, smax[d] / smin[d]);
+            if (scheme == SPLIT_F16X2) {
+                int e = (int)std::lround(lsum[d] / (double)cnt);          // log2 of the geometric-mean sigma
+                e = std::max(-40, std::min(40, e));
+                pm.scale[d] = (float)std::ldexp(1.0, -e);
+            }
+        }
     }
     size_t live = 0, padded = 0;
     pm.model_chunk_begin.push_back(0);
@@ -292,7 +351,7 @@ PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models) {
                 const int k = t * MT + i;
                 std::fill(sq.begin(), sq.end(), 0.0f);
                 std::fill(lin.begin(), lin.end(), 0.0f);
-                float cst_f = NEG_BIG;
+                float cst_f = dead;
                 if (k < K) {
                     double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
                     double a = 0.0;
@@ -300,24 +359,30 @@ PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models) {
                         const double sg = g.sigma[(size_t)k * dim + d];
                         const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
                         const double iv = 1.0 / (sg * sg);
-                        sq[d] = (float)(-0.5 * LOG2E * iv);
-                        lin[d] = (float)(LOG2E * mu * iv);
+                        const double us = 1.0 / (double)pm.scale[d];      // x' = z / scale: powers of two, exact
+                        sq[d] = (float)(-0.5 * LOG2E * iv * us * us);
+                        lin[d] = (float)(LOG2E * mu * iv * us);
                         cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
                         a += mu * mu * iv;
+                        pm.coef_max = std::max(pm.coef_max, std::max((double)std::fabs(sq[d]), (double)std::fabs(lin[d])));
                     }
                     pm.amp = std::max(pm.amp, a);
                     cst *= LOG2E;
-                    if (std::isfinite(cst) && cst > (double)NEG_BIG) cst_f = (float)cst;
+                    if (std::isfinite(cst) && cst > (double)dead) cst_f = (float)cst;
+                    if (cst_f != dead) pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
                 }
                 lin[(size_t)KS * 8 - 1] = cst_f;
                 for (int d = 0; d < KS * 8; d++) {
                     const int ks = d >> 3, j = d & 7;
                     for (int hh = 0; hh < 2; hh++) {
                         uint16_t parts[3];
-                        split_bf16x3(hh ? lin[d] : sq[d], parts);
+                        if (scheme == SPLIT_F16X2)
+                            split_f16x2(hh ? lin[d] : sq[d], parts);
+                        else
+                            split_bf16x3(hh ? lin[d] : sq[d], parts);
                         const int lane = i + 32 * hh;
-                        for (int p = 0; p < 3; p++)
-                            tile[(((size_t)ks * 3 + p) * 64 + lane) * 8 + j] = parts[p];
+                        for (int p = 0; p < P; p++)
+                            tile[(((size_t)ks * P + p) * 64 + lane) * 8 + j] = parts[p];
                     }
                 }
             }

@@ -92,16 +92,28 @@ PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp);
 // (d = 8 KS - 1 >= D) holds C_k against the constant 1.  A mixture tile = 32 mixtures; its image is
 // [ks][part][lane][8 bf16]: lane l supplies mixture l & 31, hh = l >> 5, j = 0..7 (one 16-byte LDS
 // read per lane and part).
-struct PackedBf16x3 {
+// The same layout serves the two-part fp16 scheme (gmm_score_split.hip: [ks][part][lane][8 x fp16],
+// two parts, three part products).  fp16 has a 5-bit exponent, so that scheme works on
+// x' = (x - center) * scale with a per-dimension power-of-two `scale` ~ 1 / (geometric mean of the
+// dimension's sigmas) folded into the coefficients (exact), pads dead mixtures with C = -60000
+// instead of -1e30, and is only offered when every dimension's sigma range is moderate (`sigma_ratio`).
+constexpr int SPLIT_BF16X3 = 0, SPLIT_F16X2 = 1;
+constexpr float F16_NEG_BIG = -60000.0f;
+struct PackedSplit {
+    int scheme = SPLIT_BF16X3, parts = 3;
     int ks = 0;
-    std::vector<uint16_t> params;    // 16-byte granular (8 bf16)
+    std::vector<uint16_t> params;    // 16-byte granular (8 x 16 bit)
     std::vector<ChunkDesc> chunks;   // one mixture tile per chunk; offset in 16-byte units
     std::vector<int> model_chunk_begin;
     std::vector<float> center;       // [dim]
+    std::vector<float> scale;        // [dim], powers of two (all 1 for bf16x3)
     double amp = 0.0;
     double pad_waste = 0.0;
+    double sigma_ratio = 1.0;        // max over dims of (max sigma / min sigma) across all mixtures
+    double coef_max = 0.0;           // largest |coefficient| after scaling (fp16 range check)
 };
-PackedBf16x3 pack_models_bf16x3(const std::vector<const GMM *> &models);
+typedef PackedSplit PackedBf16x3;
+PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme);
 
 // ---- fourth layout: speaker sets that share sigma and weights (MAP adaptation moves the means only,
 // gmmubm.cc:40-81 -- a UBM and every speaker adapted from it).  The quadratic half of the
@@ -130,6 +142,9 @@ struct PackedBx3Shared {
 bool models_share_sigma_and_weights(const std::vector<const GMM *> &models);
 PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models);
 void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts
+void split_f16x2(float v, uint16_t out[2]);    // round-to-nearest-even hi/lo fp16 parts (gradual underflow)
+uint16_t f32_to_f16_rne(float v);
+float f16_to_f32(uint16_t h);
 
 }  // namespace sr
 
@@ -141,10 +156,14 @@ struct SRModelSet {
     sr::PackedMfma mfma;             // expanded-form layout for the matrix-core engine
     sr::DevBuf<float> d_mfma_params, d_center;
     sr::DevBuf<sr::ChunkDesc> d_mfma_chunks;
-    sr::PackedBf16x3 bx3;            // split-bf16 layout for the bf16 matrix-core engine
+    sr::PackedSplit bx3;             // split-bf16 layout for the bf16 matrix-core engine
     sr::DevBuf<uint16_t> d_bx3_params;
     sr::DevBuf<float> d_bx3_center;
     sr::DevBuf<sr::ChunkDesc> d_bx3_chunks;
+    sr::PackedSplit h2;              // two-part fp16 layout (three part products)
+    sr::DevBuf<uint16_t> d_h2_params;
+    sr::DevBuf<float> d_h2_center, d_h2_scale;
+    sr::DevBuf<sr::ChunkDesc> d_h2_chunks;
     sr::PackedBx3Shared shared;      // shared-sigma layout (empty unless the set qualifies)
     sr::DevBuf<uint16_t> d_shared_params;
     sr::DevBuf<sr::SharedBlock> d_shared_blocks;

@@ -13,6 +13,7 @@
 // buffered by LDS-DMA); all lanes read the same LDS address (broadcast),
 // two ds_read_b128 feed 8*F FMAs.  The log-sum-exp is online per lane, in the log2 domain
 // (v_exp_f32 / v_log_f32 are base-2).  No MFMA: the 2-FMA distance form is not a contraction.
+#include "lse.hpp"
 #include "score.hpp"
 #include "wave_ops.hpp"
 
@@ -36,9 +37,6 @@ struct ScoreArgs {
     int clamp;
 };
 
-constexpr float LN2_F = 0.69314718055994530942f;
-constexpr float MINLOG_F = -708.396418532264f;     // fastexp.cc:93,105
-constexpr float LN_1E_15_F = -34.538776394910684f;  // safe_log floor, gmm.cc:34-38
 
 __host__ __device__ constexpr int score_waves_per_eu(int dp, int f) {
     return (dp * f + 44 <= 128) ? 4 : (dp * f + 44 <= 168) ? 3 : 2;
@@ -147,6 +145,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
         m[f] = NEG_BIG;
         ssum[f] = 0.0f;
     }
+    const float near_thr = lse_near_threshold(clamp);
     __syncthreads();   // drains the LDS-DMA of chunk 0 (hipcc emits vmcnt(0) before the barrier)
 
     // One chunk: stage the next one into `other`, run all records of `cur`, close the model
@@ -188,9 +187,18 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                 const float v3 = cc.w - L::get(acc[f / W][3], f % W);
                 const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
                 const float mn = fmaxf(m[f], mx);
-                const float e = __builtin_amdgcn_exp2f(v0 - mn) + __builtin_amdgcn_exp2f(v1 - mn) +
-                                __builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn);
-                ssum[f] = fmaf(ssum[f], __builtin_amdgcn_exp2f(m[f] - mn), e);
+                float e0 = __builtin_amdgcn_exp2f(v0 - mn), e1 = __builtin_amdgcn_exp2f(v1 - mn);
+                float e2 = __builtin_amdgcn_exp2f(v2 - mn), e3 = __builtin_amdgcn_exp2f(v3 - mn);
+                float keep = ssum[f];
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mn < near_thr) != 0, 0)) {
+                    // next to DBL_MIN the reference's sub-DBL_MIN terms are exactly 0 (lse.hpp)
+                    e0 = v0 >= LSE_MINLOG2 ? e0 : 0.0f;
+                    e1 = v1 >= LSE_MINLOG2 ? e1 : 0.0f;
+                    e2 = v2 >= LSE_MINLOG2 ? e2 : 0.0f;
+                    e3 = v3 >= LSE_MINLOG2 ? e3 : 0.0f;
+                    keep = m[f] >= LSE_MINLOG2 ? keep : 0.0f;
+                }
+                ssum[f] = fmaf(keep, __builtin_amdgcn_exp2f(m[f] - mn), (e0 + e1) + (e2 + e3));
                 m[f] = mn;
             }
         }
@@ -200,8 +208,8 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
             double mine = 0.0;
 #pragma unroll
             for (int f = 0; f < F; f++) {
-                float ll = LN2_F * (m[f] + log2f(ssum[f]));
-                if (clamp && ll < MINLOG_F) ll = LN_1E_15_F;
+                // the reference's underflow behaviour (safe_log -> ln 1e-15, gmm.cc:34-38, :237-244): lse.hpp
+                const float ll = lse_close1(m[f], ssum[f], clamp);
                 if (valid[f]) {
                     mine += (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[f]] = ll;
@@ -279,6 +287,7 @@ struct ScoreWorkspace {
     DevBuf<int> argmax;
     DevBuf<int> group_chunk_begin;
     DevBuf<float> frame_ll;
+    DevBuf<int> oor;                     // saturation flag of the fp16 engines
 };
 static ScoreWorkspace &ws() {
     static ScoreWorkspace *w = new ScoreWorkspace();   // leaked on purpose: no hipFree at exit
@@ -363,7 +372,8 @@ void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
                            models_share_sigma_and_weights(models);
     if (shared_ok && (small || forced == 0 || forced == 4)) s.shared = pack_models_bx3_shared(models);
     if (small || forced == 2) s.mfma = pack_models_mfma(models, s.host.dp);
-    if (small || forced == 3 || (forced == 0 && !shared_ok)) s.bx3 = pack_models_bf16x3(models);
+    if (small || forced == 3 || (forced == 0 && !shared_ok)) s.bx3 = pack_models_split(models, SPLIT_BF16X3);
+    if (small || forced == 5 || (forced == 0 && !shared_ok)) s.h2 = pack_models_split(models, SPLIT_F16X2);
 }
 
 static void ensure_shared_layout(SRModelSet &s) {
@@ -372,6 +382,20 @@ static void ensure_shared_layout(SRModelSet &s) {
     s.d_shared_blocks.upload(s.shared.blocks.data(), s.shared.blocks.size());
     s.d_shared_center.upload(s.shared.center.data(), s.shared.center.size());
     sync_stream();
+}
+
+static void ensure_h2_layout(SRModelSet &s) {
+    if (s.d_h2_params.p) return;
+    s.d_h2_params.upload(s.h2.params.data(), s.h2.params.size());
+    s.d_h2_chunks.upload(s.h2.chunks.data(), s.h2.chunks.size());
+    s.d_h2_center.upload(s.h2.center.data(), s.h2.center.size());
+    s.d_h2_scale.upload(s.h2.scale.data(), s.h2.scale.size());
+    sync_stream();
+}
+
+static bool f16_ok(const PackedSplit &p) {
+    return !p.params.empty() && p.amp <= F16_MAX_AMP && p.pad_waste <= MFMA_MAX_PAD_WASTE &&
+           p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
 }
 
 static void ensure_bx3_layout(SRModelSet &s) {
@@ -395,8 +419,16 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     const bool mfma_ok = !set.mfma.params.empty();
     const bool bx3_ok = !set.bx3.params.empty();
     const bool shared_ok = !set.shared.params.empty();
-    bool use_mfma = false, use_bx3 = false, use_shared = false;
-    if (opt.engine == 4) {
+    const bool h2_ok = !set.h2.params.empty();
+    const bool precise = (flags & SCORE_PRECISE) != 0;
+    bool use_mfma = false, use_bx3 = false, use_shared = false, use_h2 = false;
+    if (opt.engine == 5 && !precise) {
+        if (!h2_ok) fail("split-fp16 engine requested but the set has no fp16 layout (sets of more than 65536 mixtures pack "
+                        "only the layouts selected by score_engine when they are created)");
+        use_h2 = true;
+    } else if (opt.engine == 5) {
+        use_bx3 = bx3_ok;             // the precise re-run of a forced fp16 engine
+    } else if (opt.engine == 4) {
         if (!shared_ok) fail("shared-sigma engine requested but the set does not qualify (>= %d models with "
                              "identical sigma and weights, packed with that engine available)", SHARED_MIN_MODELS);
         use_shared = true;
@@ -412,10 +444,13 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
         // shape swept (profiles/r01_tune_score.log); the fp32 one stays selectable (score_engine = 2)
         use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
-        if (!use_shared)
+        if (!use_shared) use_h2 = !precise && f16_ok(set.h2);
+        if (!use_shared && !use_h2)
             use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
     }
-    const bool use_mat = use_mfma || use_bx3 || use_shared;
+    const bool use_split = use_bx3 || use_h2;
+    const PackedSplit &split = use_h2 ? set.h2 : set.bx3;
+    const bool use_mat = use_mfma || use_split || use_shared;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     int FT = opt.mfma_ft;
@@ -430,11 +465,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     }
     if (DP > 40 && FT > 3) FT = 3;
     if (use_shared) FT = 1;
-    if (use_bx3) FT = opt.mfma_ft ? std::min(opt.mfma_ft, bx3_max_ft(set.bx3.ks)) : 1;   // one column tile per wave won or tied every sweep
+    if (use_split) FT = opt.mfma_ft ? std::min(opt.mfma_ft, split_max_ft(split.ks)) : 1;   // one column tile per wave won or tied every sweep
     TileTable &tt = feat.tiles_for(use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
+    bool used_oor = false;
     w.sums.ensure((size_t)std::max(1, U) * S);
     w.argmax.ensure((size_t)std::max(1, U));
     if (tt.n_tiles > 0) {
@@ -444,7 +480,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // enough workgroups for a short tail: >= ~16 rounds of resident ones for the vector and
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
-            const int target = use_shared ? ctx().n_cu * 2 * 6 : use_bx3 ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
+            const int target = use_shared ? ctx().n_cu * 2 * 6 : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
         const int n_units = use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of
@@ -453,7 +489,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         if (use_shared) {
             for (int g = 0; g <= G; g++) gcb[g] = (int)(((int64_t)g * n_units) / G);
         } else {
-            const std::vector<int> &mcb = use_bx3 ? set.bx3.model_chunk_begin
+            const std::vector<int> &mcb = use_split ? split.model_chunk_begin
                                           : use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
             for (int g = 0; g <= G; g++) {
                 const int model = (int)(((int64_t)g * S) / G);
@@ -493,15 +529,23 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             ScopedKernelTimer t(T_SCORE);
             launch_score_bx3_shared(a, set.shared.kq, set.shared.kl);
         } else if (use_mat) {
-            if (use_bx3) ensure_bx3_layout(set); else ensure_mfma_layout(set);
+            if (use_h2) ensure_h2_layout(set); else if (use_bx3) ensure_bx3_layout(set); else ensure_mfma_layout(set);
             MfmaLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
-            a.params = use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
-                               : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
-            a.chunks = use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
+            a.params = use_h2 ? reinterpret_cast<const float4 *>(set.d_h2_params.p)
+                       : use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
+                                 : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
+            a.chunks = use_h2 ? set.d_h2_chunks.p : use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
             a.group_chunk_begin = w.group_chunk_begin.p;
-            a.center = use_bx3 ? set.d_bx3_center.p : set.d_center.p;
+            a.center = use_h2 ? set.d_h2_center.p : use_bx3 ? set.d_bx3_center.p : set.d_center.p;
+            if (use_h2) {
+                w.oor.ensure(1);
+                SR_HIP(hipMemsetAsync(w.oor.p, 0, sizeof(int), ctx().stream));
+                a.scale = set.d_h2_scale.p;
+                a.oor_flag = w.oor.p;
+                used_oor = true;
+            }
             a.partial = w.partial.p;
             a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
             a.n_frames = feat.n_rows;
@@ -511,10 +555,14 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
             ScopedKernelTimer t(T_SCORE);
-            if (use_bx3) {
+            if (use_h2) {
                 snprintf(g_last_kernel, sizeof g_last_kernel,
-                         "gmm_score_bf16x3_kernel<%d,%d> (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)", set.bx3.ks, FT);
-                launch_score_bf16x3(a, set.bx3.ks, FT);
+                         "gmm_score_split_kernel<f16x2,%d,%d> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)", split.ks, FT);
+                launch_score_split(a, SPLIT_F16X2, split.ks, FT);
+            } else if (use_bx3) {
+                snprintf(g_last_kernel, sizeof g_last_kernel,
+                         "gmm_score_split_kernel<bf16x3,%d,%d> (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)", split.ks, FT);
+                launch_score_split(a, SPLIT_BF16X3, split.ks, FT);
             } else {
                 snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
                 launch_score_mfma(a, DP, FT);
@@ -543,13 +591,14 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_bx3 || use_shared) ? 1 : 4, w.sums.p, w.argmax.p);
+                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared) ? 1 : 4, w.sums.p, w.argmax.p);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;
     r.d_sums = w.sums.p;
     r.d_argmax = w.argmax.p;
     r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? w.frame_ll.p : nullptr;
+    r.d_oor = used_oor ? w.oor.p : nullptr;
     return r;
 }
 
@@ -557,6 +606,7 @@ struct ResultStaging {
     PinnedBuf<double> sums;
     PinnedBuf<int> argmax;
     PinnedBuf<float> frame_ll;
+    PinnedBuf<int> oor;
 };
 static ResultStaging &staging() {
     static ResultStaging *s = new ResultStaging();   // leaked on purpose (no hipHostFree at exit)
@@ -564,9 +614,13 @@ static ResultStaging &staging() {
 }
 
 // Copies the last scoring call's results to host memory through pinned staging.
-void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
+bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
                    int *argmax_out, float *frame_ll_out) {
     auto &st = staging();
+    if (r.d_oor) {
+        st.oor.ensure(1);
+        SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    }
     const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
     const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
     if (sums_out && U) {
@@ -586,15 +640,22 @@ void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, do
         }
     }
     sync_stream();
+    if (r.d_oor && st.oor.p[0] != 0) return false;
     if (sums_out && U) std::memcpy(sums_out, st.sums.p, U * S * sizeof(double));
     if (argmax_out && U) std::memcpy(argmax_out, st.argmax.p, U * sizeof(int));
     if (stage_fll) std::memcpy(frame_ll_out, st.frame_ll.p, fll_n * sizeof(float));
+    return true;
 }
 
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags) {
     const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags);
-    fetch_results(r, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
+    if (fetch_results(r, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
+                      frame_ll_out))
+        return;
+    // a frame left the fp16 engine's range: the whole batch again on the fp32-grade engines
+    const ScoreResult r2 = score_device(set, feat, frame_ll_out != nullptr, flags | SCORE_PRECISE);
+    fetch_results(r2, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
                   frame_ll_out);
 }
 

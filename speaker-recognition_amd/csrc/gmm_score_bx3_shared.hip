@@ -14,6 +14,7 @@
 // Stream order (gmm_model.hpp): per block, per mixture tile: [Q][L_0]...[L_14] -- 16 images, so the
 // two LDS buffers alternate statically (hipcc keeps an LDS-DMA in flight only across separately
 // named arrays); the walk is fully unrolled over the 15 models.
+#include "lse.hpp"
 #include "score.hpp"
 #include "wave_ops.hpp"
 
@@ -24,9 +25,6 @@ namespace sr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr float SH_LN2_F = 0.69314718055994530942f;
-constexpr float SH_MINLOG_F = -708.396418532264f;
-constexpr float SH_LN_1E_15_F = -34.538776394910684f;
 
 __device__ __forceinline__ uint32_t sh_rne(float v) {
     const uint32_t u = __float_as_uint(v);
@@ -163,6 +161,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
     }
 
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float near_thr = lse_near_threshold(clamp);
     for (int blk = blk_begin; blk < blk_end; blk++) {
         const SharedBlock sb = blocks[blk];
         const uint4 *stream = params + sb.offset_u4;
@@ -194,15 +193,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
                     stage(other, tsrc + STRIDE_U4, Q_U4);           // next tile's quadratic image -> lds_a
                 f32x16 acc;
                 sh_chain<KL>(acc, qacc, cur + lane, bl);
-                float mx = acc[0];
-#pragma unroll
-                for (int r = 1; r < 16; r++) mx = fmaxf(mx, acc[r]);
-                const float mn = fmaxf(m[si], mx);
-                float e = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) e += __builtin_amdgcn_exp2f(acc[r] - mn);
-                ssum[si] = fmaf(ssum[si], __builtin_amdgcn_exp2f(m[si] - mn), e);
-                m[si] = mn;
+                lse_update16(acc, m[si], ssum[si], near_thr);
                 // the model loop is unrolled and s_barrier orders memory, not ALU work: without pinning
                 // the epilogue here the optimiser sinks all 15 of them below the last chain and keeps
                 // 15 accumulators live (256 VGPRs + scratch)
@@ -214,12 +205,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
         // ---- close the block's models ----
 #pragma unroll
         for (int si = 0; si < SB; si++) {
-            const float om = other_half(m[si]);
-            const float os = other_half(ssum[si]);
-            const float mn = fmaxf(m[si], om);
-            const float tot = ssum[si] * __builtin_amdgcn_exp2f(m[si] - mn) + os * __builtin_amdgcn_exp2f(om - mn);
-            float ll = SH_LN2_F * (mn + log2f(tot));
-            if (clamp && ll < SH_MINLOG_F) ll = SH_LN_1E_15_F;
+            const float ll = lse_close2(m[si], ssum[si], other_half(m[si]), other_half(ssum[si]), clamp);
             double mine = 0.0;
             if (valid && hh == 0 && si < sb.n_models) {
                 mine = (double)ll;

@@ -17,6 +17,7 @@
 // A wave owns FT column tiles (32*FT frames); a workgroup = 4 waves = 128*FT frames of one
 // utterance.  The accumulator layout puts a frame's 16 mixture rows in one lane, so the online
 // log-sum-exp is lane-local; the two half-waves (other 16 rows) merge once per model.
+#include "lse.hpp"
 #include "score.hpp"
 #include "wave_ops.hpp"
 
@@ -26,9 +27,6 @@ namespace sr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr float M_LN2_F = 0.69314718055994530942f;
-constexpr float M_MINLOG_F = -708.396418532264f;
-constexpr float M_LN_1E_15_F = -34.538776394910684f;
 
 __host__ __device__ constexpr int mfma_waves_per_eu(int dp, int ft) {
     const int regs = ft * (((dp + 1 + 3) & ~3) + 16) + 72;
@@ -110,6 +108,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
         m[ft] = NEG_BIG;
         ssum[ft] = 0.0f;
     }
+    const float near_thr = lse_near_threshold(clamp);
     __syncthreads();
 
     auto do_chunk = [&](const float4 *cur, float4 *other, int c) {
@@ -144,6 +143,10 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
 #pragma unroll
                 for (int r = 1; r < 16; r++) mx = fmaxf(mx, acc[ft][r]);
                 const float mn = fmaxf(m[ft], mx);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mn < near_thr) != 0, 0)) {
+                    lse_update16(acc[ft], m[ft], ssum[ft], near_thr);     // per-term flush next to DBL_MIN (lse.hpp)
+                    continue;
+                }
                 // rows two at a time: the subtraction and the running sum as packed fp32 ops (fewer
                 // vector-ALU instructions next to the MFMA stream; v_exp_f32 has no packed form)
                 typedef float v2 __attribute__((ext_vector_type(2)));
@@ -165,13 +168,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
 #pragma unroll
             for (int ft = 0; ft < FT; ft++) {
                 // merge the two half-waves (the other 16 mixture rows of the same frame)
-                const float om = other_half(m[ft]);
-                const float os = other_half(ssum[ft]);
-                const float mn = fmaxf(m[ft], om);
-                const float tot = ssum[ft] * __builtin_amdgcn_exp2f(m[ft] - mn) +
-                                  os * __builtin_amdgcn_exp2f(om - mn);
-                float ll = M_LN2_F * (mn + log2f(tot));
-                if (clamp && ll < M_MINLOG_F) ll = M_LN_1E_15_F;
+                const float ll = lse_close2(m[ft], ssum[ft], other_half(m[ft]), other_half(ssum[ft]), clamp);
                 if (valid[ft] && hh == 0) {
                     mine += (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;

@@ -1,0 +1,320 @@
+// gmm_score_split.hip -- matrix-core engines for the scoring math of gmm.cc:176-202, :237-244, :533-569:
+// the expanded quadratic form of gmm_score_mfma.hip
+//   log2 density_k(x) = sum_d ( A2_kd x'_d^2 + A1_kd x'_d ) + C_k ,   x' = (x - centre) * scale
+// evaluated on the 16-bit matrix cores at (near-)fp32 accuracy by splitting every fp32 operand into
+// 16-bit parts whose part products are exact in fp32, accumulated in fp32 by the MFMA:
+//
+//   scheme bf16x3 (score_engine 3): three bf16 parts (8+8+8 = all 24 significand bits, bf16 has
+//       fp32's exponent range), six part products a0b0 + (a0b1 + a1b0) + (a1b1 + a0b2 + a2b0);
+//       dropped products < 2^-24 each: fp32-grade, no range restrictions.
+//   scheme f16x2  (score_engine 5): two fp16 parts (11+11 = 22 bits), three part products
+//       a0b0 + a0b1 + a1b0; dropped a1b1 < 2^-22 -- half the MFMAs.  fp16's narrow exponent range is
+//       handled by a per-dimension power-of-two scale folded into both operands (exact), gradual
+//       underflow of the low parts (fp16 subnormals are honoured by v_mfma_f32_32x32x16_f16), and a
+//       saturation flag: a frame whose scaled |x'| reaches 255 is clamped and reported, and the
+//       host re-scores the batch with the bf16x3 engine (score.hpp).
+//
+// Why: gfx950 has no tf32/xf32 and its fp32 MFMA runs at the vector rate (157 TFLOP/s); the 16-bit
+// MFMA is 16x that, so 6 (3) part products cost 6/16 (3/16) of one fp32 MFMA pass over the tile.
+//
+// Mapping: MFMA rows = 32 mixtures, A fragments streamed through LDS by LDS-DMA (one 32-mixture
+// tile = KS*PARTS fragments of 1 KiB per chunk, double-buffered); MFMA columns = 32 frames, B
+// fragments (the parts of the frame's (x'^2, x', 1) vector) resident in VGPRs for the whole kernel.
+// A wave owns FT column tiles; the accumulator layout keeps a frame's 16 mixture rows in one lane,
+// so the online log-sum-exp is lane-local and the two half-waves merge once per model.
+#include "lse.hpp"
+#include "score.hpp"
+#include "wave_ops.hpp"
+
+#include <algorithm>
+
+namespace sr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct bf16x3 {
+    static constexpr int PARTS = 3, NPROD = 6;
+    typedef bf16x8 frag;
+    // small products first, and consecutive MFMAs share one operand
+    static constexpr int AI[6] = {2, 1, 1, 0, 0, 0};
+    static constexpr int BI[6] = {0, 0, 1, 1, 2, 0};
+    static constexpr bool SCALED = false;
+    __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    // 16-bit patterns of the parts of v (round-to-nearest-even at each step: the split is exact)
+    __device__ static __forceinline__ void split(float v, uint32_t (&p)[3]) {
+        auto rne = [](float f) {
+            const uint32_t u = __float_as_uint(f);
+            return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+        };
+        const uint32_t p0 = rne(v);
+        const float r1 = v - __uint_as_float(p0);
+        const uint32_t p1 = rne(r1);
+        const float r2 = r1 - __uint_as_float(p1);
+        p[0] = p0 >> 16;
+        p[1] = p1 >> 16;
+        p[2] = rne(r2) >> 16;
+    }
+};
+
+struct f16x2 {
+    static constexpr int PARTS = 2, NPROD = 3;
+    typedef f16x8 frag;
+    static constexpr int AI[3] = {1, 0, 0};
+    static constexpr int BI[3] = {0, 1, 0};
+    static constexpr bool SCALED = true;
+    __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ void split(float v, uint32_t (&p)[2]) {
+        const _Float16 h = (_Float16)v;                    // v_cvt_f16_f32, RNE, gradual underflow
+        const _Float16 l = (_Float16)(v - (float)h);
+        p[0] = (uint32_t)__builtin_bit_cast(unsigned short, h);
+        p[1] = (uint32_t)__builtin_bit_cast(unsigned short, l);
+    }
+};
+
+__host__ __device__ constexpr int split_waves_per_eu(int parts, int ks, int ft) {
+    const int regs = ft * (ks * parts * 4 + 16) + 24 + 12 * parts;
+    return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
+}
+
+template <typename SC, int KS, int FT>
+__global__ __launch_bounds__(256, split_waves_per_eu(SC::PARTS, KS, FT))
+void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restrict__ tiles,
+                            const uint4 *__restrict__ params, const ChunkDesc *__restrict__ chunks,
+                            const int *__restrict__ group_chunk_begin,
+                            const float *__restrict__ center, const float *__restrict__ scale,
+                            double *__restrict__ partial, float *__restrict__ frame_ll,
+                            int *__restrict__ oor_flag, int64_t n_frames, int dim, int n_models,
+                            int clamp, int n_groups, int n_tiles) {
+    constexpr int P = SC::PARTS;
+    constexpr int TILE_U4 = KS * P * 64;       // 16-byte fragments-per-lane of one 32-mixture tile
+    constexpr int PF = (TILE_U4 + 255) / 256;
+    typedef typename SC::frag frag;
+    __shared__ uint4 lds_a[TILE_U4];
+    __shared__ uint4 lds_b[TILE_U4];
+    __shared__ double close_slot[2][4];        // the four waves' sums of a closed model, two generations
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31;                 // frame column inside a 32-frame tile
+    const int hh = lane >> 5;                  // which 8 of the 16 contraction indices of a step
+    const int tile_lo = blockIdx.x & 7;        // XCD-aware order, as gmm_score_kernel
+    const int q = blockIdx.x >> 3;
+    const int g = q % n_groups;
+    const int tile_id = (q / n_groups) * 8 + tile_lo;
+    if (tile_id >= n_tiles) return;
+    const TileDesc tile = tiles[tile_id];
+    const int chunk_begin = group_chunk_begin[g];
+    const int chunk_end = group_chunk_begin[g + 1];
+
+    // every chunk of this layout is one mixture tile of TILE_U4 fragments: chunk c starts at c * TILE_U4
+    auto stage = [&](uint4 *dst, int c) {
+        const uint4 *src = params + (size_t)c * TILE_U4;
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int base = (i * 4 + wave) * 64;
+            if (base + lane < TILE_U4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + base + lane),
+                    (__attribute__((address_space(3))) void *)(dst + base), 16, 0, 0);
+        }
+    };
+    stage(lds_a, chunk_begin);
+    int done_next = chunks[chunk_begin].model_done;   // fetched one chunk ahead of its use
+
+    // ---- resident B fragments.  Contraction slot (ks, hh, j) is feature d = 8 ks + j: its square in
+    //      the lower half-wave (hh = 0), the value itself in the upper one (hh = 1); the very last
+    //      upper slot carries the constant 1 that picks up C_k (8 KS > dim, so it is free).
+    //      breg[ft][ks][part] = the 16-bit parts of this lane's 8 slots of step ks. ----
+    frag breg[FT][KS][P];
+    bool valid[FT];
+    int64_t row[FT];
+    float zmax = 0.0f;
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++) {
+        const int local = (wave * FT + ft) * 32 + col;
+        valid[ft] = local < tile.count;
+        row[ft] = tile.start + (valid[ft] ? local : 0);
+        const float *src = X + row[ft] * dim;
+        float xs[8 * KS];
+#pragma unroll
+        for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < dim ? d : dim - 1];
+        // keep the loads unconditional and batched: without this the compiler sinks each one into
+        // its own `d < dim` branch with a full wait
+#pragma unroll
+        for (int d = 0; d < 8 * KS; d++) asm volatile("" : "+v"(xs[d]));
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            uint32_t w[P][4];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int d = ks * 8 + j;
+                const int dc = d < dim ? d : dim - 1;
+                float xc = xs[d] - center[dc];
+                if constexpr (SC::SCALED) {
+                    xc *= scale[dc];
+                    if (d < dim) zmax = fmaxf(zmax, fabsf(xc));
+                    xc = fminf(fmaxf(xc, -255.0f), 255.0f);    // x'^2 stays below fp16's 65504
+                }
+                float v = hh ? xc : xc * xc;
+                v = d < dim ? v : 0.0f;
+                if (d == 8 * KS - 1) v = hh ? 1.0f : v;
+                uint32_t p[P];
+                SC::split(v, p);
+#pragma unroll
+                for (int pi = 0; pi < P; pi++) {
+                    if (j & 1)
+                        w[pi][j >> 1] |= p[pi] << 16;
+                    else
+                        w[pi][j >> 1] = p[pi];
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < P; pi++) {
+                const uint4 u = make_uint4(w[pi][0], w[pi][1], w[pi][2], w[pi][3]);
+                breg[ft][ks][pi] = __builtin_bit_cast(frag, u);
+            }
+        }
+    }
+    if constexpr (SC::SCALED) {
+        // NaN features compare false and fall through to the arithmetic, which propagates them
+        if (zmax >= 255.0f) atomicOr(oor_flag, 1);
+    }
+
+    float m[FT], ssum[FT];
+#pragma unroll
+    for (int ft = 0; ft < FT; ft++) {
+        m[ft] = NEG_BIG;
+        ssum[ft] = 0.0f;
+    }
+    const float near_thr = lse_near_threshold(clamp);
+    __syncthreads();
+
+    // A model's four wave sums meet in LDS and leave as ONE double per (tile, model): the store
+    // happens after the chunk's closing barrier, at the top of the next chunk (or after the loop).
+    int pending_model = -1, pending_gen = 0, gen = 0;
+    auto flush_pending = [&]() {
+        if (pending_model >= 0 && tid == 0) {
+            const double *p = close_slot[pending_gen];
+            partial[(int64_t)tile_id * n_models + pending_model] = ((p[0] + p[1]) + p[2]) + p[3];
+        }
+        pending_model = -1;
+    };
+
+    auto do_chunk = [&](const uint4 *cur, uint4 *other, int c) {
+        flush_pending();
+        const int model_done = done_next;
+        if (c + 1 < chunk_end) {
+            stage(other, c + 1);
+            done_next = chunks[c + 1].model_done;
+        }
+
+        const uint4 *at = cur + lane;
+        f32x16 acc[FT];
+        const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // A parts are fetched one contraction step ahead of the MFMAs that consume them; the first
+        // MFMA of each chain takes the inline-constant zero as C.
+        uint4 nx[P];
+#pragma unroll
+        for (int pi = 0; pi < P; pi++) nx[pi] = at[pi * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            frag a[P];
+#pragma unroll
+            for (int pi = 0; pi < P; pi++) a[pi] = __builtin_bit_cast(frag, nx[pi]);
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int pi = 0; pi < P; pi++) nx[pi] = at[((ks + 1) * P + pi) * 64];
+            }
+#pragma unroll
+            for (int pr = 0; pr < SC::NPROD; pr++)
+#pragma unroll
+                for (int ft = 0; ft < FT; ft++)
+                    acc[ft] = SC::mfma(a[SC::AI[pr]], breg[ft][ks][SC::BI[pr]],
+                                       (ks == 0 && pr == 0) ? zero16 : acc[ft]);
+        }
+        // online log2-sum-exp over this lane's 16 mixture rows of each frame column (lse.hpp)
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++) lse_update16(acc[ft], m[ft], ssum[ft], near_thr);
+
+        if (model_done >= 0) {
+            const int s = model_done;
+            double mine = 0.0;
+#pragma unroll
+            for (int ft = 0; ft < FT; ft++) {
+                // merge the two half-waves (the other 16 mixture rows of the same frame); the
+                // reference's underflow behaviour (safe_log, gmm.cc:34-38) is in lse.hpp
+                const float ll = lse_close2(m[ft], ssum[ft], other_half(m[ft]), other_half(ssum[ft]), clamp);
+                if (valid[ft] && hh == 0) {
+                    mine += (double)ll;
+                    if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;
+                }
+                m[ft] = NEG_BIG;
+                ssum[ft] = 0.0f;
+            }
+            mine = wave_sum_f64(mine);
+            if (lane == 0) close_slot[gen][wave] = mine;
+            pending_model = s;
+            pending_gen = gen;
+            gen ^= 1;
+        }
+        __syncthreads();
+    };
+
+    for (int c = chunk_begin; c < chunk_end; c += 2) {
+        do_chunk(lds_a, lds_b, c);
+        if (c + 1 < chunk_end) do_chunk(lds_b, lds_a, c + 1);
+    }
+    flush_pending();
+}
+
+template <typename SC, int KS, int FT>
+static void launch_split(const MfmaLaunch &a) {
+    dim3 grid((unsigned)((int64_t)a.n_groups * ((a.n_tiles + 7) / 8) * 8));
+    hipLaunchKernelGGL((gmm_score_split_kernel<SC, KS, FT>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
+                       reinterpret_cast<const uint4 *>(a.params), a.chunks, a.group_chunk_begin, a.center,
+                       a.scale, a.partial, a.frame_ll, a.oor_flag, a.n_frames, a.dim, a.n_models, a.clamp,
+                       a.n_groups, a.n_tiles);
+}
+
+template <typename SC, int KS>
+static void dispatch_split_ft(const MfmaLaunch &a, int FT) {
+    if (FT == 1) return launch_split<SC, KS, 1>(a);
+    if constexpr (KS <= 6) {
+        if (FT == 2) return launch_split<SC, KS, 2>(a);
+    }
+    fail("split engine: %d column tiles per wave not instantiated for %d contraction steps", FT, KS);
+}
+
+int split_max_ft(int ks) { return ks <= 6 ? 2 : 1; }
+
+template <typename SC>
+static void dispatch_split(const MfmaLaunch &a, int KS, int FT) {
+    switch (KS) {
+        case 1: dispatch_split_ft<SC, 1>(a, FT); break;
+        case 2: dispatch_split_ft<SC, 2>(a, FT); break;
+        case 3: dispatch_split_ft<SC, 3>(a, FT); break;
+        case 4: dispatch_split_ft<SC, 4>(a, FT); break;
+        case 5: dispatch_split_ft<SC, 5>(a, FT); break;
+        case 6: dispatch_split_ft<SC, 6>(a, FT); break;
+        case 7: dispatch_split_ft<SC, 7>(a, FT); break;
+        case 8: dispatch_split_ft<SC, 8>(a, FT); break;
+        case 9: dispatch_split_ft<SC, 9>(a, FT); break;
+        default: fail("no split scoring kernel for %d contraction steps", KS);
+    }
+}
+
+void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT) {
+    if (scheme == SPLIT_F16X2)
+        dispatch_split<f16x2>(a, KS, FT);
+    else
+        dispatch_split<bf16x3>(a, KS, FT);
+}
+
+}  // namespace sr

@@ -13,6 +13,8 @@ struct ScoreOptions {
     int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel;
                                // 3 = split-bf16 (3 parts, 6 products) matrix-core kernel;
                                // 4 = split-bf16, shared-sigma form (sets whose models share sigma and weights)
+                               // 5 = split-fp16 (2 parts, 3 products) matrix-core kernel;
+                               // 6 = split-fp16, shared-sigma form
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
 };
 
@@ -20,6 +22,15 @@ struct ScoreOptions {
 // 32-mixture tiles are not mostly padding; otherwise the 2-FMA vector kernel (direct form).
 constexpr double MFMA_MAX_AMP = 2000.0;      // max_k sum_d (mu'_d/sigma_d)^2
 constexpr double MFMA_MAX_PAD_WASTE = 0.25;
+// The two-part fp16 engines carry 22 significand bits per operand (error ~4x an fp32 FMA chain's per
+// term, scripts/emulate_split.py) and fp16's 5-bit exponent: offered when the cancellation is
+// moderate, every dimension's sigmas stay within a factor the gradual-underflow error analysis
+// covers, and the scaled coefficients fit fp16.
+constexpr double F16_MAX_AMP = 1000.0;
+constexpr double F16_MAX_SIGMA_RATIO = 256.0;
+constexpr double F16_MAX_COEF = 30000.0;
+// internal scoring flag (beside SR_CLAMP_COMPAT): keep to the fp32-grade engines (EM, serving stream)
+constexpr int SCORE_PRECISE = 0x200;
 
 struct MfmaLaunch {
     const float *X;
@@ -28,8 +39,10 @@ struct MfmaLaunch {
     const ChunkDesc *chunks;
     const int *group_chunk_begin;
     const float *center;
+    const float *scale = nullptr;   // fp16 scheme: per-dimension power-of-two scale of x - center
     double *partial;
     float *frame_ll;
+    int *oor_flag = nullptr;        // fp16 scheme: set when a frame saturated (|scaled x'| >= 255)
     int64_t n_frames;
     int dim, n_models, clamp, n_groups, n_tiles;
 };
@@ -50,8 +63,8 @@ void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL);
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;
-void launch_score_bf16x3(const MfmaLaunch &a, int KS, int FT);   // a.params = the bf16x3 image
-int bx3_max_ft(int ks);
+void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT);   // a.params = the split image
+int split_max_ft(int ks);
 ScoreOptions &score_options();
 const char *last_score_kernel();   // name of the kernel variant the last scoring call launched
 
@@ -60,6 +73,7 @@ struct ScoreResult {
     const double *d_sums = nullptr;    // [U][S]
     const int *d_argmax = nullptr;     // [U]
     const float *d_frame_ll = nullptr; // [S][n_frames] when requested
+    const int *d_oor = nullptr;        // fp16 engines: nonzero when a frame saturated -> results must be redone
 };
 
 // Scores every utterance of `feat` against every model of `set`; leaves results on the device.
@@ -68,7 +82,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags);
 // Results of the last scoring call -> host memory, through pinned staging buffers.
-void fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
+// Returns false when the fp16 engine reported saturated frames (nothing was copied out: score again
+// with SCORE_PRECISE).
+bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
                    int *argmax_out, float *frame_ll_out);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);

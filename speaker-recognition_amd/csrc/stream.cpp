@@ -61,7 +61,7 @@ void stream_destroy(SRStream *s) {
 // pinned buffers.  Launches only (every table is cached after the first pass over this shape).
 void enqueue_tick(SRStream *s, SRStream::Slot &sl) {
     mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);
-    const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags & 0xff);
+    const ScoreResult r = score_device(*s->set, sl.feat, false, (s->flags & 0xff) | SCORE_PRECISE);
     SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
                           hipMemcpyDeviceToHost, ctx().stream));
     SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
@@ -139,7 +139,7 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
             // one synchronous pass per slot builds every table / workspace for this shape, so the
             // steady state launches kernels only
             mfcc_extract_batch(*m, sl.pcm, nd, 1, sl.feat);
-            (void)score_device(*set, sl.feat, false, flags & 0xff);
+            (void)score_device(*set, sl.feat, false, (flags & 0xff) | SCORE_PRECISE);
             sync_stream();
         }
         return s;

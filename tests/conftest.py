@@ -19,6 +19,12 @@ def gmm_golden():
 
 
 @pytest.fixture(scope="session")
+def clamp_golden():
+    """Reference-DSO answers around its underflow clamp (tests/golden/make_clamp_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "clamp_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def mfcc_golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "mfcc_golden.npz"))
 

@@ -34,10 +34,10 @@ def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
         m = _gmm(g, c)
         ref = g[c + "_ll"]
         for F, pk, eng, ft in ((0, 0, 1, 0), (1, 0, 1, 0), (2, -1, 1, 0), (4, -1, 1, 0), (2, 1, 1, 0), (4, 1, 1, 0),
-                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 3, 1), (0, 0, 3, 2), (0, 0, 0, 0)):
+                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 3, 1), (0, 0, 3, 2), (0, 0, 5, 1), (0, 0, 5, 2), (0, 0, 0, 0)):
             _lib.set_option("score_frames_per_lane", F)
             _lib.set_option("score_packed", pk)
-            _lib.set_option("score_engine", eng)      # 1: vector ALU, 2: fp32 matrix cores, 3: split-bf16 matrix cores, 0: auto
+            _lib.set_option("score_engine", eng)      # 1: vector ALU, 2: fp32 matrix cores, 3: split-bf16, 5: split-fp16 matrix cores, 0: auto
             _lib.set_option("score_mfma_ft", ft)
             ll = m.score(g[c + "_X"])
             assert ll_close(ll, ref) < TOL, (c, F, pk, eng, ft, ll_close(ll, ref))
@@ -304,13 +304,14 @@ def test_engine_selection_and_split_bf16_accuracy(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=False) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     err = {}
-    for eng in (1, 2, 3, 0):
+    for eng in (1, 2, 3, 5, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         err[eng] = float(np.max(np.abs(fll - want) / np.maximum(1.0, np.abs(want))))
         if eng == 0:
-            assert "bf16x3" in _lib.last_score_kernel()
+            assert "f16x2" in _lib.last_score_kernel()     # well conditioned, moderate sigma range: 3 products
     assert err[3] < 5e-6 and err[3] <= 2.0 * max(err[1], err[2]) + 1e-7, err
+    assert err[5] < 1e-5 and err[0] == err[5], err            # two fp16 parts: 22 bits per operand
     _lib.set_option("score_engine", 0)
     # ill-conditioned expanded form: means ~30 sigma apart -> direct form on the vector ALU
     far = []
@@ -351,7 +352,7 @@ def test_random_shapes_all_engines(built_lib, oracle_built):
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
         off = np.concatenate([[0], np.cumsum(lens)])
         ms = ModelSet([GMM.from_arrays(*m) for m in models])
-        for eng in (1, 2, 3, 0):
+        for eng in (1, 2, 3, 5, 0):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_model_groups", int(rng.integers(0, 4)))
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
@@ -444,3 +445,53 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
     _lib.set_option("score_engine", 0)
     ms.score(Batch.from_features([synth.draw_frames(other[0], 50, 1)]))
     assert "shared" not in _lib.last_score_kernel()
+
+
+def test_fp16_engine_range_fallback(built_lib, oracle_built):
+    """The split-fp16 engine works on x' = (x - centre) * 2^-e per dimension; a frame whose scaled
+    |x'| reaches 255 saturates, is reported by the kernel, and the batch is re-scored by the
+    fp32-grade engines: results equal engine 3's bit for bit, and frames inside the range are
+    untouched by the presence of the flag logic."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    S, K, D = 3, 64, 20
+    models = [synth.synth_gmm(K, D, 900 + s) for s in range(S)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    utts = [synth.draw_frames(models[u % S], 200, 5 + u) for u in range(3)]
+    far = [u.copy() for u in utts]
+    far[1][17, 3] += 5000.0                       # one coordinate of one frame far outside fp16's reach
+    for compat in (True, False):                  # with and without the reference's clamp
+        _lib.set_option("score_engine", 3)
+        want = ms.score(Batch.from_features(far), frame_ll=True, clamp_compat=compat)
+        _lib.set_option("score_engine", 0)
+        got = ms.score(Batch.from_features(far), frame_ll=True, clamp_compat=compat)
+        assert "bf16x3" in _lib.last_score_kernel()           # the re-run
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b)
+        got = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+        assert "f16x2" in _lib.last_score_kernel()
+        X = np.concatenate(utts).astype(np.float64)
+        ref = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
+        assert ll_close(got[2], ref) < TOL
+
+
+def test_clamp_band_matches_reference_all_engines(built_lib, clamp_golden):
+    """SURVEY 8a-12 at the boundary: frames whose largest term w_k p_k walks through DBL_MIN
+    (goldens from the reference DSO, tests/golden/make_clamp_golden.py).  Every engine returns
+    exactly ln(1e-15) where the reference does -- including the ln K wide band where the log of the
+    SUM is still above -708.396 -- and the true value (1e-4 relative) elsewhere."""
+    from speaker_recognition_amd import _lib
+    g = clamp_golden
+    floor32 = np.float32(np.log(1e-15))
+    for c in g["cases"]:
+        m = _gmm(g, c)
+        X, ref = g[c + "_X"], g[c + "_ll"]
+        clamped = ref == np.log(1e-15)
+        for eng in (1, 2, 3, 5, 0):
+            _lib.set_option("score_engine", eng)
+            ll = m.score(X)
+            assert np.array_equal(ll == floor32, clamped), (c, eng, _lib.last_score_kernel())
+            assert ll_close(ll[~clamped], ref[~clamped]) < TOL, (c, eng)
+            assert abs(m.score_all(X) - float(np.sum(ref))) < TOL * abs(float(np.sum(ref)))

@@ -36,6 +36,31 @@ def test_gmm_oracle_modes_agree_and_clamp(oracle_built, gmm_golden):
         assert np.all(true_ll[-2:] < go.MINLOG)
 
 
+def test_gmm_oracle_clamp_band_matches_reference(oracle_built, clamp_golden):
+    """Frames that walk the largest term w_k p_k through DBL_MIN: the reference DSO returns
+    ln(1e-15) exactly when every term flushed (gmm.cc:34-38, :237-244 under FTZ).  Mode 0 (the
+    restated linear-domain arithmetic) reproduces the DSO to rounding order; mode 2 (log-sum-exp,
+    the kernels' formulation) reproduces the clamp pattern exactly and the values to the remez5
+    error -- including the ln K wide band where the log of the SUM is still above -708.396."""
+    go, g = oracle_built, clamp_golden
+    in_band = 0
+    for c in g["cases"]:
+        p = _params(go, g, c)
+        X, ref, tm = g[c + "_X"], g[c + "_ll"], g[c + "_termmax"]
+        clamped = ref == go.LN_1E_15
+        assert np.array_equal(clamped, tm < go.MINLOG), c
+        fast = go.score_batch(p, X, go.MODE_FASTEXP)
+        assert np.array_equal(fast == go.LN_1E_15, clamped), c
+        # just above DBL_MIN the reference's partial sums lose bits to FTZ: compare loosely there
+        assert np.max(np.abs(fast - ref)) < 1e-9, c
+        lse = go.score_batch(p, X, go.MODE_LOGSUMEXP)
+        assert np.array_equal(lse == go.LN_1E_15, clamped), c
+        assert np.max(np.abs(lse - ref) / np.maximum(1, np.abs(ref))) < 1e-7, c
+        unclamped = go.score_batch(p, X, go.MODE_LOGSUMEXP, clamp_compat=False)
+        in_band += int(np.sum(clamped & (unclamped >= go.MINLOG)))
+    assert in_band >= 40          # the band the sum-rule would have got wrong is populated
+
+
 def test_model_text_roundtrip(oracle_built, gmm_golden):
     go, g = oracle_built, gmm_golden
     p = _params(go, g, "syn16x13")
