@@ -181,7 +181,8 @@ int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
 #define SR_T_CMVN 2
 #define SR_T_FINALIZE 3
 #define SR_T_ESTEP 4
-#define SR_T_COUNT 5
+#define SR_T_SCORE_REF 5   /* reference-offset pre-pass of the split-fp16 shared-sigma engine */
+#define SR_T_COUNT 6
 int sr_profile_enable(int on);
 int sr_profile_reset(void);
 int sr_profile_get(int kind, double *total_ms, long *launches);

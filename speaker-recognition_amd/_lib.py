@@ -33,7 +33,7 @@ EXT_SYMBOLS = [
 
 SR_CLAMP_COMPAT = 1
 SR_STREAM_GRAPH = 0x100
-T_SCORE, T_MFCC, T_CMVN, T_FINALIZE, T_ESTEP = 0, 1, 2, 3, 4
+T_SCORE, T_MFCC, T_CMVN, T_FINALIZE, T_ESTEP, T_SCORE_REF = 0, 1, 2, 3, 4, 5
 
 
 class Parameter(C.Structure):

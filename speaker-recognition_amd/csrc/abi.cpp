@@ -543,6 +543,8 @@ int sr_set_option(const char *key, long value) {
             fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores), "
                  "4 (split-bf16, shared-sigma form), 5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form)");
         score_options().engine = (int)value;
+    } else if (k == "score_h2s_force_exc") {
+        score_options().h2s_force_exc = value != 0;
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");
         score_options().mfma_ft = (int)value;

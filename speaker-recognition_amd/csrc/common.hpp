@@ -50,7 +50,7 @@ Ctx &ctx();
 void ensure_device();   // throws sr::Error when no usable GPU: the product has no CPU path
 
 // ---- kernel timing with HIP events on OUR stream ----
-enum TimerKind { T_SCORE = 0, T_MFCC = 1, T_CMVN = 2, T_FINALIZE = 3, T_ESTEP = 4, T_COUNT = 5 };
+enum TimerKind { T_SCORE = 0, T_MFCC = 1, T_CMVN = 2, T_FINALIZE = 3, T_ESTEP = 4, T_SCORE_REF = 5, T_COUNT = 6 };
 struct ScopedKernelTimer {
     explicit ScopedKernelTimer(TimerKind k);
     ~ScopedKernelTimer();

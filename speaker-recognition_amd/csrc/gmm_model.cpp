@@ -505,4 +505,152 @@ PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models) {
     return pm;
 }
 
+// ---- shared-sigma layout on two fp16 parts (gmm_score_h2_shared.hip) ----
+namespace {
+
+// flat image [ks][lane][8]: row i of the tile, slot c = 16 ks + 8 hh + j -> lane i + 32 hh, element j
+void put_flat_row(uint16_t *img, int ksteps, int i, const std::vector<uint16_t> &slots) {
+    for (int c = 0; c < ksteps * 16; c++) {
+        const int ks = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+        img[((size_t)ks * 64 + i + 32 * hh) * 8 + j] = slots[c];
+    }
+}
+
+}  // namespace
+
+PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
+    PackedH2Shared pm;
+    const GMM &g0 = *models[0];
+    const int dim = g0.dim, K = g0.nr_mixtures;
+    const int S = (int)models.size();
+    pm.kqf = (3 * dim + 15) / 16;
+    pm.klf = (3 * dim + 2 + 15) / 16;
+    pm.n_tiles = (K + MT - 1) / MT;
+    const int kimg = std::max(pm.kqf, pm.klf);
+    const size_t img_u16 = (size_t)kimg * 64 * 8;
+    const double LOG2E = 1.4426950408889634073599;
+    const double SQRT_2_PI = 2.5066282746310002;
+    // the reference model alone, generic two-part layout: fixes center and scale for the whole set
+    // from the SET's statistics (pack_models_split over all models would be wasteful for 1000
+    // speakers, and sigma is common anyway: take the means of all models for the centre)
+    pm.center.assign(dim, 0.0f);
+    pm.scale.assign(dim, 1.0f);
+    {
+        std::vector<double> acc(dim, 0.0), lsum(dim, 0.0), smin(dim, INFINITY), smax(dim, 0.0);
+        for (const GMM *g : models)
+            for (int k = 0; k < K; k++)
+                for (int d = 0; d < dim; d++) acc[d] += g->mean[(size_t)k * dim + d];
+        for (int k = 0; k < K; k++)
+            for (int d = 0; d < dim; d++) {
+                const double sg = g0.sigma[(size_t)k * dim + d];
+                lsum[d] += std::log2(sg);
+                smin[d] = std::min(smin[d], sg);
+                smax[d] = std::max(smax[d], sg);
+            }
+        for (int d = 0; d < dim; d++) {
+            pm.center[d] = (float)(acc[d] / ((double)K * S));
+            pm.sigma_ratio = std::max(pm.sigma_ratio, smax[d] / smin[d]);
+            int e = (int)std::lround(lsum[d] / (double)K);
+            e = std::max(-40, std::min(40, e));
+            pm.scale[d] = (float)std::ldexp(1.0, -e);
+        }
+    }
+    // slot tables (frame side)
+    pm.q_desc.assign((size_t)pm.kqf * 16, 0);
+    pm.l_desc.assign((size_t)pm.klf * 16, 0);
+    for (int d = 0; d < dim; d++) {
+        pm.q_desc[d] = (uint16_t)(d | (1 << 8));                    // lo(A2) x hi(z^2)
+        pm.q_desc[dim + d] = (uint16_t)(d | (2 << 8));              // hi(A2) x lo(z^2)
+        pm.q_desc[2 * dim + d] = (uint16_t)(d | (1 << 8));          // hi(A2) x hi(z^2)
+        pm.l_desc[d] = (uint16_t)(d | (1 << 8));                    // lo(A1) x hi(z)
+        pm.l_desc[(dim + 1) + d] = (uint16_t)(d | (2 << 8));        // hi(A1) x lo(z)
+        pm.l_desc[(2 * dim + 1) + d] = (uint16_t)(d | (1 << 8));    // hi(A1) x hi(z)
+    }
+    pm.l_desc[dim] = (uint16_t)(3 << 8);                            // lo(C) x 1
+    pm.l_desc[3 * dim + 1] = (uint16_t)(3 << 8);                    // hi(C) x 1
+    const int n_blocks = (S + SHARED_SB - 1) / SHARED_SB;
+    const size_t block_u16 = (size_t)pm.n_tiles * (1 + SHARED_SB) * img_u16;
+    pm.params.assign((size_t)n_blocks * block_u16, 0);
+    // the quadratic images are the same in every block
+    std::vector<uint16_t> qimg((size_t)pm.n_tiles * img_u16, 0);
+    {
+        std::vector<uint16_t> slots((size_t)pm.kqf * 16);
+        for (int t = 0; t < pm.n_tiles; t++)
+            for (int i = 0; i < MT; i++) {
+                const int k = t * MT + i;
+                std::fill(slots.begin(), slots.end(), 0);
+                if (k < K)
+                    for (int d = 0; d < dim; d++) {
+                        const double sg = g0.sigma[(size_t)k * dim + d];
+                        const double us = 1.0 / (double)pm.scale[d];
+                        const float a2 = (float)(-0.5 * LOG2E / (sg * sg) * us * us);
+                        pm.coef_max = std::max(pm.coef_max, (double)std::fabs(a2));
+                        uint16_t parts[2];
+                        split_f16x2(a2, parts);
+                        slots[d] = parts[1];
+                        slots[dim + d] = parts[0];
+                        slots[2 * dim + d] = parts[0];
+                    }
+                put_flat_row(qimg.data() + (size_t)t * img_u16, pm.kqf, i, slots);
+            }
+    }
+    std::vector<uint16_t> slots((size_t)pm.klf * 16);
+    for (int b = 0; b < n_blocks; b++) {
+        uint16_t *bp = pm.params.data() + (size_t)b * block_u16;
+        SharedBlock sb;
+        sb.offset_u4 = (uint32_t)(((size_t)b * block_u16) / 8);
+        sb.first_model = b * SHARED_SB;
+        sb.n_models = std::min(SHARED_SB, S - b * SHARED_SB);
+        sb.pad = 0;
+        pm.blocks.push_back(sb);
+        for (int t = 0; t < pm.n_tiles; t++) {
+            uint16_t *tp = bp + (size_t)t * (1 + SHARED_SB) * img_u16;
+            std::memcpy(tp, qimg.data() + (size_t)t * img_u16, img_u16 * sizeof(uint16_t));
+            for (int si = 0; si < SHARED_SB; si++) {
+                uint16_t *lt = tp + (size_t)(1 + si) * img_u16;
+                const int s = b * SHARED_SB + si;
+                for (int i = 0; i < MT; i++) {
+                    const int k = t * MT + i;
+                    std::fill(slots.begin(), slots.end(), 0);
+                    float cst_f = F16_NEG_BIG;
+                    if (s < S && k < K) {
+                        const GMM &g = *models[s];
+                        double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                        double a = 0.0;
+                        for (int d = 0; d < dim; d++) {
+                            const double sg = g.sigma[(size_t)k * dim + d];
+                            const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
+                            const double iv = 1.0 / (sg * sg);
+                            const double us = 1.0 / (double)pm.scale[d];
+                            const float a1 = (float)(LOG2E * mu * iv * us);
+                            pm.coef_max = std::max(pm.coef_max, (double)std::fabs(a1));
+                            uint16_t parts[2];
+                            split_f16x2(a1, parts);
+                            slots[d] = parts[1];
+                            slots[(dim + 1) + d] = parts[0];
+                            slots[(2 * dim + 1) + d] = parts[0];
+                            cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
+                            a += mu * mu * iv;
+                        }
+                        pm.amp = std::max(pm.amp, a);
+                        cst *= LOG2E;
+                        if (std::isfinite(cst) && cst > (double)F16_NEG_BIG) {
+                            cst_f = (float)cst;
+                            pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
+                        }
+                    }
+                    uint16_t parts[2];
+                    split_f16x2(cst_f, parts);
+                    slots[dim] = parts[1];
+                    slots[3 * dim + 1] = parts[0];
+                    put_flat_row(lt, pm.klf, i, slots);
+                }
+            }
+        }
+    }
+    pm.pad_waste = 1.0 - ((double)K * S) / ((double)pm.n_tiles * MT * n_blocks * SHARED_SB);
+    pm.ref = pack_models_split({models[0]}, SPLIT_F16X2);
+    return pm;
+}
+
 }  // namespace sr

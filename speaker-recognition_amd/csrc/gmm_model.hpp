@@ -139,6 +139,26 @@ struct PackedBx3Shared {
     std::vector<float> center;
     double amp = 0.0, pad_waste = 0.0;
 };
+// ---- fifth layout: the shared-sigma form on two fp16 parts (gmm_score_h2_shared.hip).  The three
+// part products of a half are laid end to end as one contraction:
+//   quadratic: [lo(A2_d) x hi(z_d^2) | hi(A2_d) x lo(z_d^2) | hi(A2_d) x hi(z_d^2)]          3D slots
+//   linear:    [lo(A1_d, C) x hi(z_d, 1) | hi(A1_d) x lo(z_d) | hi(A1_d, C) x hi(z_d, 1)]     3D+2 slots
+// (z = (x - center) * scale, per-dimension power-of-two scale as PackedSplit), each padded to a
+// multiple of 16 once.  `q_desc` / `l_desc` tell the kernel what the frame side of slot c is:
+// d | op << 8 with op 0 = zero, 1 = high part, 2 = low part, 3 = the constant 1.
+// An image is [ks][lane][8 x fp16] with lane l = mixture l & 31, slots 16 ks + 8 (l >> 5) + j, padded
+// to max(KQF, KLF) KiB; stream order as PackedBx3Shared.  `ref` is the set's first model alone in
+// the generic two-part layout: its per-frame log-likelihood is the kernel's log-sum-exp offset.
+struct PackedH2Shared {
+    int kqf = 0, klf = 0, n_tiles = 0;
+    std::vector<uint16_t> params;
+    std::vector<SharedBlock> blocks;
+    std::vector<float> center, scale;
+    std::vector<uint16_t> q_desc, l_desc;
+    double amp = 0.0, pad_waste = 0.0, sigma_ratio = 1.0, coef_max = 0.0;
+    PackedSplit ref;
+};
+PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models);
 bool models_share_sigma_and_weights(const std::vector<const GMM *> &models);
 PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models);
 void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts
@@ -168,5 +188,11 @@ struct SRModelSet {
     sr::DevBuf<uint16_t> d_shared_params;
     sr::DevBuf<sr::SharedBlock> d_shared_blocks;
     sr::DevBuf<float> d_shared_center;
+    sr::PackedH2Shared h2s;          // shared-sigma layout on two fp16 parts (empty unless the set qualifies)
+    sr::DevBuf<uint16_t> d_h2s_params, d_h2s_qdesc, d_h2s_ldesc, d_h2s_ref_params;
+    sr::DevBuf<sr::SharedBlock> d_h2s_blocks;
+    sr::DevBuf<float> d_h2s_center, d_h2s_scale, d_h2s_ref_center, d_h2s_ref_scale;
+    sr::DevBuf<sr::ChunkDesc> d_h2s_ref_chunks;
+    sr::DevBuf<int> d_h2s_ref_gcb;
     int device = -1;
 };

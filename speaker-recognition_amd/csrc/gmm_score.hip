@@ -146,7 +146,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
         ssum[f] = 0.0f;
     }
     const float near_thr = lse_near_threshold(clamp);
-    __syncthreads();   // drains the LDS-DMA of chunk 0 (hipcc emits vmcnt(0) before the barrier)
+    dma_publish_barrier();   // drains the LDS-DMA of chunk 0 (hipcc emits vmcnt(0) before the barrier)
 
     // One chunk: stage the next one into `other`, run all records of `cur`, close the model
     // if the chunk is its last, then barrier (next chunk landed; everyone is done with `cur`).
@@ -220,7 +220,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
             mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
-        __syncthreads();
+        dma_publish_barrier();
     };
 
     for (int c = chunk_begin; c < chunk_end; c += 2) {
@@ -288,6 +288,9 @@ struct ScoreWorkspace {
     DevBuf<int> group_chunk_begin;
     DevBuf<float> frame_ll;
     DevBuf<int> oor;                     // saturation flag of the fp16 engines
+    DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
+    DevBuf<double> ref_partial;
+    DevBuf<int> exc_list, exc_count;     // ... and its (tile, block) exception list
 };
 static ScoreWorkspace &ws() {
     static ScoreWorkspace *w = new ScoreWorkspace();   // leaked on purpose: no hipFree at exit
@@ -362,6 +365,11 @@ static void ensure_mfma_layout(SRModelSet &s) {
     sync_stream();
 }
 
+static bool h2s_ok(const PackedH2Shared &p) {
+    return !p.params.empty() && p.amp <= F16_MAX_AMP && p.pad_waste <= MFMA_MAX_PAD_WASTE &&
+           p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
+}
+
 void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
     s.host = pack_models(models);
     size_t n_mix = 0;
@@ -370,7 +378,15 @@ void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
     const int forced = score_options().engine;
     const bool shared_ok = (int)models.size() >= SHARED_MIN_MODELS && models[0]->dim <= 48 &&   // <= 3 + 4 contraction steps: no scratch
                            models_share_sigma_and_weights(models);
-    if (shared_ok && (small || forced == 0 || forced == 4)) s.shared = pack_models_bx3_shared(models);
+    // the shared-sigma forms: the split-fp16 one when the set is within its range, else split-bf16
+    // (small sets carry both, so that either can be forced and the precise re-run has its layout)
+    bool h2s_fits = false;
+    if (shared_ok && (small || forced == 0 || forced == 6)) {
+        s.h2s = pack_models_h2_shared(models);
+        h2s_fits = h2s_ok(s.h2s);
+        if (!small && forced == 0 && !h2s_fits) s.h2s = PackedH2Shared();
+    }
+    if (shared_ok && (small || forced == 4 || (forced == 0 && !h2s_fits))) s.shared = pack_models_bx3_shared(models);
     if (small || forced == 2) s.mfma = pack_models_mfma(models, s.host.dp);
     if (small || forced == 3 || (forced == 0 && !shared_ok)) s.bx3 = pack_models_split(models, SPLIT_BF16X3);
     if (small || forced == 5 || (forced == 0 && !shared_ok)) s.h2 = pack_models_split(models, SPLIT_F16X2);
@@ -381,6 +397,25 @@ static void ensure_shared_layout(SRModelSet &s) {
     s.d_shared_params.upload(s.shared.params.data(), s.shared.params.size());
     s.d_shared_blocks.upload(s.shared.blocks.data(), s.shared.blocks.size());
     s.d_shared_center.upload(s.shared.center.data(), s.shared.center.size());
+    sync_stream();
+}
+
+static void ensure_h2s_layout(SRModelSet &s) {
+    if (s.d_h2s_params.p) return;
+    const PackedH2Shared &h = s.h2s;
+    s.d_h2s_params.upload(h.params.data(), h.params.size());
+    s.d_h2s_blocks.upload(h.blocks.data(), h.blocks.size());
+    s.d_h2s_center.upload(h.center.data(), h.center.size());
+    s.d_h2s_scale.upload(h.scale.data(), h.scale.size());
+    s.d_h2s_qdesc.upload(h.q_desc.data(), h.q_desc.size());
+    s.d_h2s_ldesc.upload(h.l_desc.data(), h.l_desc.size());
+    s.d_h2s_ref_params.upload(h.ref.params.data(), h.ref.params.size());
+    s.d_h2s_ref_chunks.upload(h.ref.chunks.data(), h.ref.chunks.size());
+    // the reference pre-pass: one model, one group; its center and scale follow the set's (appended)
+    const int gcb[2] = {0, (int)h.ref.chunks.size()};
+    s.d_h2s_ref_gcb.upload(gcb, 2);
+    s.d_h2s_ref_center.upload(h.ref.center.data(), h.ref.center.size());
+    s.d_h2s_ref_scale.upload(h.ref.scale.data(), h.ref.scale.size());
     sync_stream();
 }
 
@@ -420,9 +455,20 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     const bool bx3_ok = !set.bx3.params.empty();
     const bool shared_ok = !set.shared.params.empty();
     const bool h2_ok = !set.h2.params.empty();
+    const bool h2s_present = !set.h2s.params.empty();
     const bool precise = (flags & SCORE_PRECISE) != 0;
-    bool use_mfma = false, use_bx3 = false, use_shared = false, use_h2 = false;
-    if (opt.engine == 5 && !precise) {
+    bool use_mfma = false, use_bx3 = false, use_shared = false, use_h2 = false, use_h2s = false;
+    auto precise_fallback = [&]() {      // best fp32-grade engine whose layout this set carries
+        use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
+        if (!use_shared) use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
+    };
+    if (opt.engine == 6 && !precise) {
+        if (!h2s_present) fail("split-fp16 shared-sigma engine requested but the set does not qualify (>= %d models with "
+                               "identical sigma and weights, packed with that engine available)", SHARED_MIN_MODELS);
+        use_h2s = true;
+    } else if (opt.engine == 6) {
+        precise_fallback();
+    } else if (opt.engine == 5 && !precise) {
         if (!h2_ok) fail("split-fp16 engine requested but the set has no fp16 layout (sets of more than 65536 mixtures pack "
                         "only the layouts selected by score_engine when they are created)");
         use_h2 = true;
@@ -443,14 +489,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     } else if (opt.engine == 0) {
         // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
         // shape swept (profiles/r01_tune_score.log); the fp32 one stays selectable (score_engine = 2)
-        use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
-        if (!use_shared) use_h2 = !precise && f16_ok(set.h2);
-        if (!use_shared && !use_h2)
+        use_h2s = !precise && h2s_ok(set.h2s);
+        if (!use_h2s) use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
+        if (!use_h2s && !use_shared) use_h2 = !precise && f16_ok(set.h2);
+        if (!use_h2s && !use_shared && !use_h2)
             use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
     }
     const bool use_split = use_bx3 || use_h2;
     const PackedSplit &split = use_h2 ? set.h2 : set.bx3;
-    const bool use_mat = use_mfma || use_split || use_shared;
+    const bool use_mat = use_mfma || use_split || use_shared || use_h2s;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     int FT = opt.mfma_ft;
@@ -464,7 +511,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         FT = ((S >= 8 && tiles_per_model >= 4.0) || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
     }
     if (DP > 40 && FT > 3) FT = 3;
-    if (use_shared) FT = 1;
+    if (use_shared || use_h2s) FT = 1;
     if (use_split) FT = opt.mfma_ft ? std::min(opt.mfma_ft, split_max_ft(split.ks)) : 1;   // one column tile per wave won or tied every sweep
     TileTable &tt = feat.tiles_for(use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
@@ -480,13 +527,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // enough workgroups for a short tail: >= ~16 rounds of resident ones for the vector and
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
-            const int target = use_shared ? ctx().n_cu * 2 * 6 : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
+            const int target = use_h2s ? ctx().n_cu * 3 * 6 : use_shared ? ctx().n_cu * 2 * 6
+                               : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
             G = (target + tt.n_tiles - 1) / tt.n_tiles;
         }
-        const int n_units = use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of
+        const int n_units = use_h2s ? (int)set.h2s.blocks.size()
+                            : use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of
         G = std::max(1, std::min(G, n_units));
         std::vector<int> gcb(G + 1);
-        if (use_shared) {
+        if (use_shared || use_h2s) {
             for (int g = 0; g <= G; g++) gcb[g] = (int)(((int64_t)g * n_units) / G);
         } else {
             const std::vector<int> &mcb = use_split ? split.model_chunk_begin
@@ -505,7 +554,73 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         w.partial.ensure((size_t)tt.n_tiles * S * 4);
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
-        if (use_shared) {
+        if (use_h2s) {
+            ensure_h2s_layout(set);
+            const PackedH2Shared &h = set.h2s;
+            w.oor.ensure(1);
+            SR_HIP(hipMemsetAsync(w.oor.p, 0, sizeof(int), ctx().stream));
+            used_oor = true;
+            // pre-pass: the reference model's per-frame LL (natural log, no clamp) = the offset
+            w.ref_ll.ensure((size_t)std::max<int64_t>(1, feat.n_rows));
+            w.ref_partial.ensure((size_t)tt.n_tiles);
+            {
+                MfmaLaunch r;
+                r.X = feat.data.p;
+                r.tiles = tt.d_tiles.p;
+                r.params = reinterpret_cast<const float4 *>(set.d_h2s_ref_params.p);
+                r.chunks = set.d_h2s_ref_chunks.p;
+                r.group_chunk_begin = set.d_h2s_ref_gcb.p;
+                r.center = set.d_h2s_ref_center.p;
+                r.scale = set.d_h2s_ref_scale.p;
+                r.partial = w.ref_partial.p;
+                r.frame_ll = w.ref_ll.p;
+                r.oor_flag = w.oor.p;
+                r.n_frames = feat.n_rows;
+                r.dim = feat.dim;
+                r.n_models = 1;
+                r.clamp = 0;
+                r.n_groups = 1;
+                r.n_tiles = tt.n_tiles;
+                ScopedKernelTimer t(T_SCORE_REF);
+                launch_score_split(r, SPLIT_F16X2, h.ref.ks, 1);
+            }
+            const int n_blocks = (int)h.blocks.size();
+            const size_t cap = (size_t)tt.n_tiles * n_blocks;
+            w.exc_list.ensure(2 * cap);
+            w.exc_count.ensure(1);
+            SR_HIP(hipMemsetAsync(w.exc_count.p, 0, sizeof(int), ctx().stream));
+            H2sLaunch a;
+            a.X = feat.data.p;
+            a.tiles = tt.d_tiles.p;
+            a.params = set.d_h2s_params.p;
+            a.blocks = set.d_h2s_blocks.p;
+            a.group_block_begin = w.group_chunk_begin.p;
+            a.center = set.d_h2s_center.p;
+            a.scale = set.d_h2s_scale.p;
+            a.q_desc = set.d_h2s_qdesc.p;
+            a.l_desc = set.d_h2s_ldesc.p;
+            a.ref_ll = w.ref_ll.p;
+            a.partial = w.partial.p;
+            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.oor_flag = w.oor.p;
+            a.exc_list = w.exc_list.p;
+            a.exc_count = w.exc_count.p;
+            a.exc_cap = (int)std::min<size_t>(cap, 0x7fffffff);
+            a.n_frames = feat.n_rows;
+            a.dim = feat.dim;
+            a.n_models = S;
+            a.n_mix_tiles = h.n_tiles;
+            a.clamp = (flags & 1) ? 1 : 0;
+            a.n_groups = G;
+            a.n_tiles = tt.n_tiles;
+            a.log2_k = (float)std::log2((double)h.n_tiles * MT);
+            a.force_exc = opt.h2s_force_exc;
+            snprintf(g_last_kernel, sizeof g_last_kernel,
+                     "gmm_score_h2s_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
+                     "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf, SHARED_SB);
+            ScopedKernelTimer t(T_SCORE);
+            launch_score_h2_shared(a, h.kqf, h.klf);
+        } else if (use_shared) {
             ensure_shared_layout(set);
             SharedLaunch a;
             a.X = feat.data.p;
@@ -591,7 +706,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared) ? 1 : 4, w.sums.p, w.argmax.p);
+                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums.p, w.argmax.p);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;

@@ -173,7 +173,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
         }
         __syncthreads();                      // previous block's readers are done with lds_a
         stage(lds_a, stream, Q_U4);
-        __syncthreads();
+        dma_publish_barrier();
         for (int t = 0; t < n_mix_tiles; t++) {
             const uint4 *tsrc = stream + (size_t)t * STRIDE_U4;
             // image 0 (lds_a): the shared quadratic half of this mixture tile
@@ -181,7 +181,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
             f32x16 qacc;
             sh_chain<KQ>(qacc, zero16, lds_a + lane, bq);
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            dma_publish_barrier();
             // images 1..15: one model each, alternating lds_b / lds_a
 #pragma unroll
             for (int si = 0; si < SB; si++) {
@@ -199,7 +199,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
                 // 15 accumulators live (256 VGPRs + scratch)
                 asm volatile("" : "+v"(m[si]), "+v"(ssum[si]));
                 __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
+                dma_publish_barrier();
             }
         }
         // ---- close the block's models ----

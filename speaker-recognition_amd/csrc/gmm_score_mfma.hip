@@ -109,7 +109,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
         ssum[ft] = 0.0f;
     }
     const float near_thr = lse_near_threshold(clamp);
-    __syncthreads();
+    dma_publish_barrier();
 
     auto do_chunk = [&](const float4 *cur, float4 *other, int c) {
         const ChunkDesc cd = chunks[c];
@@ -179,7 +179,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
             mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
-        __syncthreads();
+        dma_publish_barrier();
     };
 
     for (int c = chunk_begin; c < chunk_end; c += 2) {

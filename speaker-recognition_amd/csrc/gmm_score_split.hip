@@ -194,7 +194,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         ssum[ft] = 0.0f;
     }
     const float near_thr = lse_near_threshold(clamp);
-    __syncthreads();
+    dma_publish_barrier();
 
     // A model's four wave sums meet in LDS and leave as ONE double per (tile, model): the store
     // happens after the chunk's closing barrier, at the top of the next chunk (or after the loop).
@@ -264,7 +264,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
             pending_gen = gen;
             gen ^= 1;
         }
-        __syncthreads();
+        dma_publish_barrier();
     };
 
     for (int c = chunk_begin; c < chunk_end; c += 2) {

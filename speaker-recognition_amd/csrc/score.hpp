@@ -16,6 +16,7 @@ struct ScoreOptions {
                                // 5 = split-fp16 (2 parts, 3 products) matrix-core kernel;
                                // 6 = split-fp16, shared-sigma form
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
+    int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
 };
 
 // The matrix-core engines are used when the expanded form is well conditioned in fp32 and the
@@ -60,6 +61,27 @@ struct SharedLaunch {
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
 };
 void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL);
+struct H2sLaunch {
+    const float *X;
+    const TileDesc *tiles;
+    const uint16_t *params;
+    const SharedBlock *blocks;
+    const int *group_block_begin;
+    const float *center, *scale;
+    const uint16_t *q_desc, *l_desc;
+    const float *ref_ll;
+    double *partial;
+    float *frame_ll;
+    int *oor_flag;
+    int *exc_list;      // int2 pairs
+    int *exc_count;
+    int exc_cap;
+    int64_t n_frames;
+    int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
+    float log2_k;
+    int force_exc;
+};
+void launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;

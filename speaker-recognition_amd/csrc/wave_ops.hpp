@@ -15,6 +15,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Barrier that publishes LDS-DMA (global_load_lds) data to the other waves of the workgroup: this
+// wave's pieces must have LANDED before it arrives.  hipcc tracks LDS-DMA by alias analysis and puts
+// its vmcnt wait in front of this wave's own ds_reads -- possibly behind the barrier, and (seen in
+// gmm_score_h2_shared.hip) not at all for a DMA issued in the previous iteration of a loop -- so the
+// wait is spelled out.
+__device__ __forceinline__ void dma_publish_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Sum of `v` over the 64 lanes of the wave; the result is valid in every lane (it comes back
 // through SGPRs).  float64, fixed order: row-wise prefix sums by DPP row_shr 1/2/4/8, then the
 // four row totals.

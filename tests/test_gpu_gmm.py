@@ -21,7 +21,8 @@ def _gmm(g, c):
 def _reset_options(built_lib):
     from speaker_recognition_amd import _lib
     yield
-    for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic"):
+    for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic",
+              "score_h2s_force_exc"):
         _lib.set_option(k, 0)
 
 
@@ -207,7 +208,7 @@ def test_cfg2_ubm_map_speakers_vs_oracle(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
-    for eng in (1, 2, 3, 0):
+    for eng in (1, 2, 3, 5, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         assert ll_close(fll, want) < TOL, (eng, ll_close(fll, want))
@@ -422,12 +423,18 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
         off = np.concatenate([[0], np.cumsum(lens)])
         ms = ModelSet([GMM.from_arrays(*m) for m in models])
-        for eng, G in ((0, 0), (4, 1), (4, 2), (4, 3), (3, 0), (1, 0)):
+        # engine 6 = the split-fp16 shared-sigma kernel (reference-offset log-sum-exp); its third
+        # entry forces every workgroup through the exception (online) pass
+        for eng, G, force in ((0, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (6, 1, 0), (6, 2, 0), (6, 3, 0), (6, 0, 1),
+                              (3, 0, 0), (1, 0, 0)):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_model_groups", G)
+            _lib.set_option("score_h2s_force_exc", force)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
-            if eng == 4 or (eng == 0 and (K, S) == (64, 14)):      # auto also weighs the padding (phantom models, K % 32)
+            if eng in (4, 6) or (eng == 0 and (K, S) == (64, 14)):      # auto also weighs the padding (phantom models, K % 32)
                 assert "shared" in _lib.last_score_kernel(), (K, D, S, eng)
+            if eng == 6 or (eng == 0 and (K, S) == (64, 14)):
+                assert "h2s" in _lib.last_score_kernel(), (K, D, S, eng)
             assert ll_close(fll, want) < TOL, (K, D, S, eng, G, ll_close(fll, want))
             for u, n in enumerate(lens):
                 if n == 0:
@@ -436,6 +443,7 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
                 w = want[:, off[u]:off[u + 1]].sum(axis=1)
                 assert np.max(np.abs(sums[u] - w)) < 2e-5 * n * 60 + 1e-3, (K, D, S, eng, u)
     _lib.set_option("score_model_groups", 0)
+    _lib.set_option("score_h2s_force_exc", 0)
     # different sigmas -> not eligible
     other = [synth.synth_gmm(64, 39, 900 + s) for s in range(14)]
     ms = ModelSet([GMM.from_arrays(*m) for m in other])
@@ -495,3 +503,41 @@ def test_clamp_band_matches_reference_all_engines(built_lib, clamp_golden):
             assert np.array_equal(ll == floor32, clamped), (c, eng, _lib.last_score_kernel())
             assert ll_close(ll[~clamped], ref[~clamped]) < TOL, (c, eng)
             assert abs(m.score_all(X) - float(np.sum(ref))) < TOL * abs(float(np.sum(ref)))
+
+
+def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):
+    """The split-fp16 shared-sigma engine (score_engine 6, the configs[2]/[3] default): per-frame
+    error against the float64 oracle on a 512-mixture UBM + 30 MAP speakers stays at the fp32 engines'
+    level; frames the reference-offset form cannot vouch for -- +60 sigma outliers (clamped by the
+    reference), a speaker model far from the UBM -- travel through the exception pass and come out
+    right; results are bit-identical across reruns and do not depend on the batch around an utterance."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    K, D, S = 512, 39, 28            # + UBM + rogue = 30 models = two full blocks of 15
+    ubm = synth.synth_gmm(K, D, 4242)
+    spk = [synth.synth_map_speaker(ubm, 600 + s) for s in range(S)]
+    # one "speaker" that is NOT close to the UBM (same sigma and weights, means moved by 3 sigma): its
+    # likelihoods sit hundreds of nats away from the offset
+    w, mu, sg = ubm
+    rogue = (w, np.vectorize(lambda v: float("%g" % v))(mu + 3.0 * sg), sg)
+    models = [ubm] + spk + [rogue]
+    utts = [synth.draw_frames(spk[u % S], 260 + 11 * u, 31 + u, outlier_frac=0.01 if u % 2 else 0.0) for u in range(6)]
+    X = np.concatenate(utts).astype(np.float64)
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    for compat in (True, False):
+        want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
+        _lib.set_option("score_engine", 0)
+        sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+        assert "h2s" in _lib.last_score_kernel()
+        rel = np.abs(fll - want) / np.maximum(1.0, np.abs(want))
+        assert rel.max() < 1e-5, (compat, rel.max())
+        again = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+        assert np.array_equal(again[0], sums) and np.array_equal(again[2], fll)
+        alone = ms.score(Batch.from_features([utts[3]]), clamp_compat=compat)
+        assert np.array_equal(alone[0][0], sums[3])
+        _lib.set_option("score_engine", 4)
+        s4, a4, f4 = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+        assert np.array_equal(a4, arg)
+        assert np.max(np.abs(f4 - fll) / np.maximum(1.0, np.abs(want))) < 1e-5
