@@ -1,15 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s scored (MFCC + GMM) on MI355X, BASELINE.json configs[1]:
-39-dim MFCC+delta+delta-delta, 64-mixture diagonal GMMs, 100 speakers, 1 M synthetic frames.
+"""bench.py -- frames/s scored (MFCC + GMM) on MI355X.
+
+HEADLINE = BASELINE.json configs[2], the largest single-GPU configuration: 16 kHz synthetic PCM ->
+13 MFCC (25/10 ms frames, FFT 2048, 50 filters) + CMVN + delta + delta-delta = 39 dims, scored
+against a 512-mixture diagonal UBM + 200 speaker GMMs MAP-adapted from it (201 models x 512
+mixtures per frame), 10 M frames per GPU.  Models are SURVEY.md 8d's synthetic ones (UBM: mu ~ N(0,1),
+sigma ~ U(0.2,1.5), w ~ Dirichlet(1); speakers: means moved by alpha_k N(0, 0.3^2), sigma and weights
+shared -- what gmmubm.cc:40-81 produces), written through the reference's 6-digit text format.  (A set
+trained by EM + MAP on the device from this audio is the `trained_ubm_map` block.)
 
 One step = one pass of the hot path over the batch, inputs already resident in HBM:
-int16 PCM (1000 utterances x ~10 s, 16 kHz) -> MFCC (25 ms / 10 ms frames, reference defaults
-otherwise: FFT 2048, 50 filters, 13 ceps) -> CMVN -> delta/delta-delta -> all 100 speaker GMMs
--> per-utterance sums + argmax copied back to the host.
+int16 PCM -> MFCC -> CMVN -> delta/delta-delta -> all 201 models -> per-utterance sums + argmax
+copied back to the host.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): utterances shard by rank, models
-replicated, no data-path collective; per-GPU work is fixed ("weak").  torch is
-used only for the gloo barrier / max-over-ranks of the elapsed time -- never for device work.
+`--gpus N`: one rank per GPU, utterances shard by rank, models replicated, no data-path collective
+(SURVEY.md 8e); per-GPU work is fixed ("weak").  Launched by torch.distributed.run the ranks come
+with RANK/LOCAL_RANK/WORLD_SIZE set; launched plainly with --gpus N > 1 this script spawns the N
+ranks itself (gloo rendezvous on 127.0.0.1).  torch is used only for the barrier / max-over-ranks of
+the elapsed time -- never for device work.
+
+Beside the headline the JSON line carries a `configs` block (N = 1 only, outside the timed region):
+configs[1], a stated sub-sample of one rank's configs[3] shard, configs[4] latencies, and the
+256-mixture x 39-dim point of BASELINE.json's north_star, each with its own roofline and parity sample.
+
+oracle/ is never imported by this process: the CPU baseline (oracle/cpu_baseline.py) and the parity
+samples (oracle/parity_check.py) run as subprocesses, outside every timed region, as checkers.
 
 Prints ONE JSON line on rank 0.
 """
@@ -18,6 +33,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,163 +44,445 @@ sys.path.insert(0, ROOT)
 FS = 16000
 MFCC_KW = dict(win_length_ms=25, win_shift_ms=10)      # cfg-0 framing; FFT 2048 / 50 filters / 13 ceps defaults
 ND = 2                                                  # 13 -> 39 dims
-N_MODELS, N_MIX, DIM = 100, 64, 39
-N_UTT, FRAMES_PER_UTT = 1000, 1000
-MODEL_SEED, AUDIO_SEED = 7, 2000
+DIM = 39
+FRAMES_PER_UTT = 1000
+CFG2_SPEAKERS, CFG2_MIX, CFG2_UTTS = 200, 512, 10000
+CFG1_MODELS, CFG1_MIX, CFG1_UTTS = 100, 64, 1000
+AUDIO_SEED, MODEL_SEED = 2000, 7
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector peak == fp32 dense MFMA peak
+MFMA16_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32 dense MFMA peak
+MFCC_FLOPS_PER_FRAME = 2.5 * 2048 * 11 + 3 * 1025 + 2 * 1989 + 50 + 2 * 13 * 50     # ~64.7 kflop
+MFCC_BYTES_PER_FRAME = 2 * 160 + 4 * 13                                            # 372 B
+
+
+# ------------------------------------------------------------------ multi-rank launch
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks ourselves."""
+    from speaker_recognition_amd import _lib
+    n = args.gpus
+    have = _lib.device_count()
+    if args.device_override < 0 and have < n:
+        sys.exit("bench.py: --gpus %d but only %d GPU(s) visible (use --device-override D to stack ranks on one device for testing)" % (n, have))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the JSON line
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------ workload construction
+def base_clips(n_speakers, n_samples):
+    """One unique clip per synthetic speaker (the same on every rank)."""
+    from speaker_recognition_amd import synth
+    return [synth.synth_speech(s, n_samples / FS + 0.01, FS, seed=AUDIO_SEED + s)[:n_samples] for s in range(n_speakers)]
+
+
+def make_pcm(base, n_utt, rank):
+    """Concatenated int16 PCM of n_utt utterances: speaker u % S's clip under a per-utterance gain, so
+    that no two utterances are byte-identical.  -> (cat, offsets)"""
+    n = len(base[0])
+    rng = np.random.default_rng(AUDIO_SEED + 7919 * (rank + 1))
+    cat = np.empty(n_utt * n, dtype=np.int16)
+    for u in range(n_utt):
+        gain = 0.5 + 0.5 * rng.random()
+        np.rint(base[u % len(base)] * gain, out=cat[u * n:(u + 1) * n], casting="unsafe")
+    return cat, np.arange(n_utt + 1, dtype=np.int64) * n
 
 
 def build_workload(rank, n_utt, frames_per_utt):
-    """Synthetic speaker-like audio: one unique 10 s clip per speaker, repeated across the rank's
-    utterances with a per-utterance gain so that no two clips are byte-identical."""
+    """The configs[1] audio as a list of clips (tests/test_gpu_mfcc.py, scripts/time_mfcc.py) + its models."""
     from speaker_recognition_amd import synth
     L, shift = int(MFCC_KW["win_length_ms"] / 1000 * FS), int(MFCC_KW["win_shift_ms"] / 1000 * FS)
     n_samples = (frames_per_utt + ND - 1) * shift + L
-    base = {}
-    clips = []
-    rng = np.random.default_rng(AUDIO_SEED + 7919 * rank)
-    for u in range(n_utt):
-        s = u % N_MODELS
-        if s not in base:
-            base[s] = synth.synth_speech(s, n_samples / FS + 0.01, FS, seed=AUDIO_SEED + 1000 * rank + s)[:n_samples]
-        gain = 0.5 + 0.5 * rng.random()
-        clips.append(np.round(base[s] * gain).astype(np.int16))
-    models = [synth.synth_gmm(N_MIX, DIM, MODEL_SEED + s) for s in range(N_MODELS)]
-    return clips, models
+    cat, off = make_pcm(base_clips(min(CFG1_MODELS, n_utt), n_samples), n_utt, rank)
+    clips = [cat[off[u]:off[u + 1]] for u in range(n_utt)]
+    return clips, [synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s) for s in range(CFG1_MODELS)]
 
 
-def cpu_baseline_leg(n_utt_sample, seconds):
-    spec = dict(fs=FS, mfcc_kw=MFCC_KW, nd=ND, n_utt=n_utt_sample, seconds=seconds, n_models=N_MODELS,
-                n_mix=N_MIX, dim=DIM, seed=AUDIO_SEED + 500000, model_seed=MODEL_SEED)
+def train_cfg2_models(ex, base, n_mix, em_iters=12):
+    """UBM by EM on the speakers' own features, speakers by means-only MAP (gmmubm.cc:29-81), on the
+    device, from two differently scaled renditions of every speaker's clip."""
+    from speaker_recognition_amd.core import Batch
+    from speaker_recognition_amd.pygmm import GMM
+    rend = []
+    for s, c in enumerate(base):
+        rend.append(c)
+        rend.append(np.rint(c * 0.7).astype(np.int16))
+    fb = ex.extract_batch(Batch.from_pcm(rend), nd=ND)
+    X = fb.download()
+    off = fb.offsets()
+    ubm = GMM(nr_mixture=n_mix, nr_iteration=em_iters, init_with_kmeans=1, seed=MODEL_SEED)
+    ubm.fit(X[::2])
+    spk = []
+    for s in range(len(base)):
+        g = GMM(nr_mixture=n_mix, nr_iteration=2)
+        g.fit(X[off[2 * s]:off[2 * s + 2]], ubm=ubm)
+        spk.append(g)
+    return ubm, spk
+
+
+# ------------------------------------------------------------------ rooflines
+def executed_over_algorithmic(kname, S, K, D):
+    """16-bit MFMA flops the scoring kernel executes per algorithmic flop S*K*(4D+6), from its name."""
+    alg = float(S) * K * (4 * D + 6)
+    tiles = (K + 31) // 32
+    mfma_flops = 2.0 * 32 * 32 * 16 / 32.0          # per frame column: one 32x32x16 MFMA covers 32 frames
+    if "h2s" in kname:
+        kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(","))
+        blocks = (S + 14) // 15
+        return blocks * tiles * (kq + 15 * kl) * mfma_flops / alg
+    if "bx3_shared" in kname:
+        kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(","))
+        blocks = (S + 14) // 15
+        return blocks * tiles * 6 * (kq + 15 * kl) * mfma_flops / alg
+    if "split_kernel<f16x2" in kname or "split_kernel<bf16x3" in kname:
+        ks = int(kname.split("<")[1].split(",")[1])
+        prod = 3 if "f16x2" in kname else 6
+        return S * tiles * prod * ks * mfma_flops / alg
+    return None
+
+
+def score_roofline(kname, n_frames, S, K, D, avg_s, hbm_measured):
+    flops = float(n_frames) * S * K * (4 * D + 6)          # SURVEY.md 8d
+    byts = float(n_frames) * 4 * D                         # fp32 frame read once
+    ach = flops / avg_s / 1e12 if avg_s > 0 else 0.0
+    ratio = executed_over_algorithmic(kname, S, K, D)
+    if ratio:
+        peak = MFMA16_PEAK_TFLOPS / ratio
+        note = ("compute-bound (%.0f flop/B vs machine balance ~20).  achieved = algorithmic S*K*(4D+6) flops per frame / "
+                "HIP-event launch time.  The kernel evaluates each fp32 product as exact 16-bit part products on the "
+                "matrix cores (fp32 accumulate) and executes %.2fx the algorithmic flops; peak = dense 16-bit MFMA "
+                "%.0f TFLOP/s / %.2f.  fp32 MFMA / vector peak for scale: %.1f TFLOP/s." % (flops / byts, ratio, MFMA16_PEAK_TFLOPS, ratio, FP32_PEAK_TFLOPS))
+    else:
+        peak, note = FP32_PEAK_TFLOPS, "compute-bound; fp32 engine: peak = fp32 MFMA = fp32 vector peak"
+    r = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0.0,
+         "note": note, "avg_launch_ms": 1e3 * avg_s,
+         "traffic": None, "traffic_note": "PMC passes are separate runs: see profiles/ (FETCH_SIZE x2 + WRITE_SIZE per launch)",
+         "achieved_over_fp32_peak": ach / FP32_PEAK_TFLOPS,
+         "hbm": {"achieved_GBps": byts / avg_s / 1e9 if avg_s > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS,
+                 "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
+                 "measured_copy_ceiling_GBps": hbm_measured,
+                 "note": "north_star's HBM roofline: the path moves 4D B per frame against S*K*(4D+6) flops, so HBM "
+                         "is not the active bound for any K*S > ~5 (SURVEY.md 7)"}}
+    if ratio:
+        r["executed_16bit_tflops"] = ach * ratio
+        r["executed_over_algorithmic"] = ratio
+    return r
+
+
+def mfcc_roofline(n_raw_frames, avg_s, hbm_measured):
+    fl = MFCC_FLOPS_PER_FRAME * n_raw_frames
+    by = MFCC_BYTES_PER_FRAME * n_raw_frames
+    return {"kernel": "mfcc_frames_fft2048_kernel", "bound": "valu (fp32 vector ALU: an FFT is not a contraction)",
+            "achieved": fl / avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP32_PEAK_TFLOPS,
+            "avg_launch_ms": 1e3 * avg_s, "flops_per_frame": MFCC_FLOPS_PER_FRAME, "bytes_per_frame": MFCC_BYTES_PER_FRAME,
+            "hbm": {"achieved_GBps": by / avg_s / 1e9, "peak_GBps": HBM_PEAK_GBS, "frac": by / avg_s / 1e9 / HBM_PEAK_GBS,
+                    "measured_copy_ceiling_GBps": hbm_measured},
+            "note": "1- and 2-flop butterflies on the vector ALU: issue-bound well below the FMA peak; see DESIGN.md 2.2 "
+                    "and profiles/ for the instruction-mix evidence"}
+
+
+def kernel_times(_lib, steps):
+    out = {}
+    for name, kind in (("mfcc_frames", _lib.T_MFCC), ("cmvn_delta", _lib.T_CMVN), ("gmm_score", _lib.T_SCORE),
+                       ("gmm_score_ref_prepass", _lib.T_SCORE_REF), ("finalize", _lib.T_FINALIZE)):
+        ms, n = _lib.profile_get(kind)
+        out[name] = {"ms_per_step": ms / max(1, steps), "launches": n}
+    return out
+
+
+def timed(fn, warmup, steps, barrier=None):
+    for _ in range(warmup):
+        fn()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, r
+
+
+# ------------------------------------------------------------------ secondary configs (rank 0, N = 1)
+def block_cfg1(_lib, ex, base, hbm, preq):
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    raw = [synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s) for s in range(CFG1_MODELS)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in raw])
+    cat, off = make_pcm(base[:CFG1_MODELS], CFG1_UTTS, 0)
+    pcm = Batch.from_pcm((cat, off))
+    n_frames = CFG1_UTTS * FRAMES_PER_UTT
+    step = lambda: ex.predict_batch(ms, pcm, nd=ND)
+    step(); step()
+    _lib.profile_reset()
+    _lib.synchronize()
+    el, (sums, arg) = timed(step, 0, 10, _lib.synchronize)
+    kt = kernel_times(_lib, 10)
+    kname = _lib.last_score_kernel()
+    # parity sample (checked by the oracle subprocess): 2 utterances x 6 models on the device's own features
+    fb = ex.extract_batch(Batch.from_pcm([cat[off[u]:off[u + 1]] for u in (0, 1)]), nd=ND)
+    preq["configs[1]"] = {"models": raw[:6], "X": fb.download().astype(np.float64), "offsets": fb.offsets(),
+                          "device_sums": sums[:2, :6]}
+    return {"workload": "BASELINE.json configs[1]: 39-dim MFCC+delta+delta-delta, 100 speaker GMMs x 64 mixtures, %d utterances x %d frames" % (CFG1_UTTS, FRAMES_PER_UTT),
+            "frames_per_s": n_frames * 10 / el, "ms_per_step": 1e3 * el / 10, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
+            "roofline": score_roofline(kname, n_frames, CFG1_MODELS, CFG1_MIX, DIM, kt["gmm_score"]["ms_per_step"] * 1e-3, hbm),
+            "mfcc_roofline": mfcc_roofline(CFG1_UTTS * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
+            "parity": None}
+
+
+def block_cfg3(_lib, hbm, preq):
+    """One rank's shard of configs[3], sub-sampled: the full 2048-mixture UBM + 1000 MAP speakers, 250 k of
+    the shard's 12.5 M frames (features drawn from the models)."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    S, K, U, T = 1000, 2048, 250, 1000
+    ubm = synth.synth_gmm(K, DIM, 99)
+    w, mean, sigma = ubm
+    alpha = ((w * 40.0 * K) / (w * 40.0 * K + 16.0))[:, None]
+    spk = []
+    for s in range(S):
+        rng = np.random.default_rng(500 + s)
+        spk.append((w, mean + alpha * 0.3 * rng.standard_normal(mean.shape), sigma))
+    t0 = time.perf_counter()
+    ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + spk])
+    t_pack = time.perf_counter() - t0
+    utts = [synth.draw_frames(spk[u % S], T, 9000 + u) for u in range(U)]
+    feats = Batch.from_features(utts)
+    step = lambda: ms.score(feats)
+    step()
+    _lib.profile_reset()
+    el, (sums, arg) = timed(step, 0, 2, _lib.synchronize)
+    ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
+    ms_r, _ = _lib.profile_get(_lib.T_SCORE_REF)
+    kname = _lib.last_score_kernel()
+    n = U * T
+    sub = [0, 1, 2, 500, 1000]
+    allm = [ubm] + spk
+    preq["configs[3]_rank_shard_subsample"] = {"models": [allm[i] for i in sub], "X": utts[0].astype(np.float64),
+                                                "offsets": [0, T], "device_sums": sums[:1, sub]}
+    return {"workload": "BASELINE.json configs[3], one of 8 ranks, SUB-SAMPLED: 2048-mixture UBM + 1000 MAP speakers (all of them), "
+                        "%d of the rank's 12.5 M frames; full-shard time = this x %.0f (linear in frames)" % (n, 12.5e6 / n),
+            "frames_per_s": n * 2 / el, "s_per_pass": el / 2, "extrapolated_full_shard_s": el / 2 * 12.5e6 / n,
+            "model_pack_upload_s": t_pack,
+            "roofline": score_roofline(kname, n, S + 1, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm),
+            "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), np.arange(U) % S))}}
+
+
+def block_point256(_lib, hbm, preq):
+    """north_star's '256 mixtures x 39-dim' point: ONE 256-mixture model, 2 M frames."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    m = synth.synth_gmm(256, DIM, 77)
+    ms = ModelSet([GMM.from_arrays(*m)])
+    utts = [synth.draw_frames(m, 1000, 100 + u) for u in range(100)]
+    feats = Batch.from_features([utts[u % 100] for u in range(2000)])
+    step = lambda: ms.score(feats)
+    step()
+    _lib.profile_reset()
+    el, (sums, arg) = timed(step, 0, 5, _lib.synchronize)
+    ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
+    preq["north_star_256x39"] = {"models": [m], "X": utts[3].astype(np.float64), "offsets": [0, 1000], "device_sums": sums[3:4, :1]}
+    return {"workload": "north_star point: 1 model x 256 mixtures x 39 dims, 2 M frames resident",
+            "frames_per_s": 2e6 * 5 / el,
+            "roofline": score_roofline(_lib.last_score_kernel(), 2000000, 1, 256, DIM, ms_k / max(1, n_k) * 1e-3, hbm),
+            "parity": None}
+
+
+def block_stream(_lib):
+    """configs[4]: 1 s windows of 8 kHz audio -> (LTSD VAD ->) MFCC -> 256-mixture speaker set -> decision;
+    host-observed latency per window, H2D and D2H included."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, ServingStream
+    from speaker_recognition_amd.filters import VAD
+    from speaker_recognition_amd.pygmm import GMM
+    fs, S, K = 8000, 20, 256
+    ex = MfccExtractor(fs)
+    models = ModelSet([GMM.from_arrays(*synth.synth_gmm(K, 13, 7 + s)) for s in range(S)])
+    audio = synth.synth_speech(3, 40.0, fs)
+    win = Batch.from_pcm([audio[:fs]])
+    lat = []
+    for i in range(330):
+        chunk = audio[(i % 39) * fs // 2:(i % 39) * fs // 2 + fs]
+        t0 = time.perf_counter()
+        win.update_pcm(chunk)
+        ex.predict_batch(models, win, nd=0)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.array(lat[30:])
+    rng = np.random.default_rng(5)
+    floor = rng.normal(0, 60, len(audio)).astype(np.int16)
+    gate = (np.arange(len(audio)) // (fs * 3 // 2)) % 2 == 0
+    scene = (np.where(gate, audio // 2, 0) + floor).astype(np.int16)
+    vad = VAD()
+    vad.init_noise(fs, rng.normal(0, 60, 3 * fs).astype(np.int16))
+    vwin = Batch.from_pcm([scene[:fs]])
+    lv = []
+    for i in range(330):
+        chunk = scene[(i % 70) * fs // 2:(i % 70) * fs // 2 + fs]
+        t0 = time.perf_counter()
+        voiced, _ = vad.filter(fs, chunk)
+        if len(voiced) > len(chunk) / 3 and ex.num_frames(len(voiced)) > 0:
+            vwin.reset_pcm([voiced])
+            ex.predict_batch(models, vwin, nd=0)
+        lv.append((time.perf_counter() - t0) * 1e3)
+    lv = np.array(lv[30:])
+    st = ServingStream(ex, models, 1024, fs)
+    cat = np.stack([audio[(j % 39) * fs // 2:(j % 39) * fs // 2 + fs] for j in range(1024)])
+    st.submit(cat)
+    t0 = time.perf_counter()
+    for i in range(40):
+        st.submit(cat)
+        st.collect()
+    st.collect()
+    dt = (time.perf_counter() - t0) / 40
+    pc = lambda a, q: float(np.percentile(a, q))
+    return {"workload": "BASELINE.json configs[4]: 8 kHz, 1 s windows (61 frames at the reference's 32/16 ms framing), 13 MFCC, "
+                        "20 speakers x 256 mixtures; one window per call, H2D + kernels + D2H, 300 windows",
+            "mfcc_gmm_decision_latency_ms": {"p50": pc(lat, 50), "p99": pc(lat, 99)},
+            "ltsd_vad_mfcc_gmm_decision_latency_ms": {"p50": pc(lv, 50), "p99": pc(lv, 99),
+                                                      "note": "VAD = the published LTSD measure (pyssp is third-party and absent: parity unpinned)"},
+            "double_buffered_1024_streams": {"tick_ms": dt * 1e3, "windows_per_s": 1024 / dt}}
+
+
+def block_trained(_lib, ex, base):
+    """The enroll path on the device: a 64-mixture UBM by EM and 40 speakers by means-only MAP
+    (train_model / train_model_from_ubm, gmm.cc:581-653, gmmubm.cc:29-81) from this bench's own audio, then
+    identification of held-out renditions of every speaker's clip."""
+    from speaker_recognition_amd.core import Batch, ModelSet
+    n_spk, K = 40, 64
+    t0 = time.perf_counter()
+    ubm, spk = train_cfg2_models(ex, base[:n_spk], K)
+    t_train = time.perf_counter() - t0
+    ms = ModelSet([ubm] + spk)
+    test = [np.rint(base[s] * g).astype(np.int16) for g in (0.55, 0.9) for s in range(n_spk)]
+    sums, arg = ex.predict_batch(ms, Batch.from_pcm(test), nd=ND)
+    best = np.argmax(sums[:, 1:], axis=1)
+    return {"workload": "EM (12 iterations, k-means++ start) of a %d-mixture UBM on %d frames + means-only MAP of %d speakers, on the device; "
+                        "then %d held-out utterances identified" % (K, n_spk * 1000, n_spk, len(test)),
+            "train_s": t_train, "scoring_kernel": _lib.last_score_kernel(), "model_set": ms.info(),
+            "identification_accuracy": float(np.mean(best == np.arange(len(test)) % n_spk)),
+            "best_speaker_beats_ubm_fraction": float(np.mean(sums[:, 1:].max(axis=1) > sums[:, 0]))}
+
+
+def cpu_baseline_leg(spec):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), json.dumps(spec)],
-                         capture_output=True, text=True, timeout=1200)
+                         capture_output=True, text=True, timeout=1500)
     if out.returncode != 0:
         return None, "cpu baseline failed: " + out.stderr[-400:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line), spec
+    return json.loads(line), None
 
 
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--utts", type=int, default=N_UTT, help="utterances per GPU (default: the cfg-1 size)")
+    ap.add_argument("--utts", type=int, default=CFG2_UTTS, help="utterances per GPU (default: the configs[2] size, 10 M frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-utts", type=int, default=12)
+    ap.add_argument("--no-config-blocks", action="store_true", help="headline only (PMC / rocprof passes)")
+    ap.add_argument("--cpu-sample-utts", type=int, default=4)
     ap.add_argument("--device-override", type=int, default=-1,
                     help="testing only: put every rank on this device (N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and rank == 0:
+        print("bench.py: note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")          # host-side barrier / reduction only
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)                                    # gloo announces its connections on stdout: ONE JSON line is the contract
+        try:
+            dist.init_process_group(backend="gloo")      # host-side barrier / reduction only
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     from speaker_recognition_amd import _lib
     from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
-    from speaker_recognition_amd.pygmm import GMM
 
-    _lib.set_device(local_rank if args.device_override < 0 else args.device_override)
-    clips, models = build_workload(rank, args.utts, FRAMES_PER_UTT)
-    pcm = Batch.from_pcm(clips)                           # resident in HBM before the timed region
+    dev = local_rank if args.device_override < 0 else args.device_override
+    if dev >= _lib.device_count():
+        sys.exit("bench.py: rank %d wants device %d but only %d visible" % (rank, dev, _lib.device_count()))
+    _lib.set_device(dev)
     ex = MfccExtractor(FS, **MFCC_KW)
-    ms = ModelSet([GMM.from_arrays(*m) for m in models])
-    n_frames = sum(max(0, ex.num_frames(len(c)) - ND) for c in clips)
+    L, shift = ex.FRAME_LEN, ex.FRAME_SHIFT
+    n_samples = (FRAMES_PER_UTT + ND - 1) * shift + L
+    base = base_clips(CFG2_SPEAKERS, n_samples)
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.pygmm import GMM
+    ubm_raw = synth.synth_gmm(CFG2_MIX, DIM, 99)
+    raw_models = [ubm_raw] + [synth.synth_map_speaker(ubm_raw, 500 + s) for s in range(CFG2_SPEAKERS)]
+    models = [GMM.from_arrays(*m) for m in raw_models]
+    ms = ModelSet(models)
+    cat, off = make_pcm(base, args.utts, rank)
+    pcm = Batch.from_pcm((cat, off))                      # resident in HBM before the timed region
+    n_frames = args.utts * FRAMES_PER_UTT
+    S = len(models)
 
     def barrier():
         _lib.synchronize()
         if dist is not None:
             dist.barrier()
 
+    step = lambda: ex.predict_batch(ms, pcm, nd=ND)
     _lib.profile_enable(True)      # HIP-event kernel timers (pre-warms the runtime's event pool once)
     for _ in range(args.warmup):
-        sums, arg = ex.predict_batch(ms, pcm, nd=ND)
+        step()
     _lib.profile_reset()           # timed region starts with zeroed timers
     barrier()
     t0 = time.perf_counter()
-    marks = []
+    prev = None
     for _ in range(args.steps):
-        sums, arg = ex.predict_batch(ms, pcm, nd=ND)
-        marks.append(time.perf_counter())
+        if prev is None and _ == args.steps - 1 and args.steps > 1:
+            prev = sums.copy()
+        sums, arg = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("SR_BENCH_DEBUG"):
-        print("step ends (ms since t0):", [round((m - t0) * 1e3, 2) for m in marks], "total", round(elapsed * 1e3, 2), file=sys.stderr)
-    _lib.profile_enable(False)
+    rank_rate = n_frames * args.steps / elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
-
+        rates = [None] * world
+        dist.all_gather_object(rates, rank_rate)
+    else:
+        rates = [rank_rate]
     if rank != 0:
         if dist is not None:
             dist.barrier()
         return
 
-    ms_score, n_score = _lib.profile_get(_lib.T_SCORE)
-    ms_mfcc, n_mfcc = _lib.profile_get(_lib.T_MFCC)
-    ms_cmvn, n_cmvn = _lib.profile_get(_lib.T_CMVN)
-    ms_fin, n_fin = _lib.profile_get(_lib.T_FINALIZE)
-    avg_score_s = (ms_score / max(1, n_score)) * 1e-3
-    flops_per_launch = float(n_frames) * N_MODELS * N_MIX * (4 * DIM + 6)      # SURVEY.md 8d
-    bytes_per_launch = float(n_frames) * 4 * DIM                               # fp32 frame read once
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("gmm_score_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    achieved_tf = flops_per_launch / avg_score_s / 1e12 if avg_score_s > 0 else 0.0
+    kt = kernel_times(_lib, args.steps)
     kname = _lib.last_score_kernel()
-    intensity = flops_per_launch / bytes_per_launch
-    if "bf16x3" in kname:
-        # split-bf16 engine: every fp32 product is six bf16 part products on the bf16 matrix cores
-        ks = int(kname.split("<")[1].split(",")[0])
-        executed = float(n_frames) * N_MODELS * ((N_MIX + 31) // 32) * (6 * ks) * (2 * 32 * 32 * 16) / 32.0
-        ratio = executed / flops_per_launch
-        peak = BF16_PEAK_TFLOPS / ratio
-        roof = {
-            "kernel": kname + "; auto-selected engine",
-            "bound": "mfma",
-            "note": "compute-bound (%.0f flop/B vs machine balance ~20).  achieved = the algorithmic S*K*(4D+6) flops per "
-                    "frame / launch time.  The kernel evaluates each fp32 product as six bf16 part products "
-                    "(3-way exact split of both operands, fp32 accumulate) on the bf16 matrix cores, so it executes "
-                    "%.2fx the algorithmic flops (6 products, contraction padded to 16*%d); peak = dense bf16 MFMA "
-                    "%.0f TFLOP/s / %.2f.  For scale: the fp32 MFMA / fp32 vector peak is %.1f TFLOP/s."
-                    % (intensity, ratio, ks, BF16_PEAK_TFLOPS, ratio, FP32_PEAK_TFLOPS),
-            "achieved": achieved_tf, "peak": peak, "unit": "TFLOP/s", "frac": achieved_tf / peak,
-            "executed_bf16_tflops": executed / avg_score_s / 1e12 if avg_score_s > 0 else 0.0,
-            "bf16_dense_peak": BF16_PEAK_TFLOPS, "fp32_peak": FP32_PEAK_TFLOPS,
-            "achieved_over_fp32_peak": achieved_tf / FP32_PEAK_TFLOPS,
-        }
-        dtype = "f32 (operands split exactly into 3 bf16 parts, 6 part products on the bf16 matrix cores, fp32 accumulate)"
-    else:
-        roof = {
-            "kernel": kname + "; auto-selected engine",
-            "bound": "mfma",
-            "note": "compute-bound: arithmetic intensity S*K*(4D+6)/(4D) = %.0f flop/B vs machine balance ~20, so "
-                    "HBM cannot be the bound; peak = dense fp32 MFMA = fp32 vector peak = 157.3 TFLOP/s; flops are "
-                    "the algorithmic S*K*(4D+6) per frame" % intensity,
-            "achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tf / FP32_PEAK_TFLOPS,
-        }
-        dtype = "f32"
-    roof.update({
-        "traffic": traffic,
-        "avg_launch_ms": 1e3 * avg_score_s, "launches": n_score,
-        "hbm": {"achieved_GBps": bytes_per_launch / avg_score_s / 1e9 if avg_score_s > 0 else 0.0,
-                "peak_GBps": HBM_PEAK_GBS,
-                "frac": (bytes_per_launch / avg_score_s / 1e9 / HBM_PEAK_GBS) if avg_score_s > 0 else 0.0},
-    })
+    hbm = _lib.hbm_copy_gbps(1 << 30, 10)
+    score_s = (kt["gmm_score"]["ms_per_step"] + kt["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
     result = {
         "metric": "frames/sec scored (MFCC+GMM)",
         "value": world * n_frames * args.steps / elapsed,
@@ -197,56 +495,84 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": dtype,
+        "dtype": "f32 (operands split exactly into 2 fp16 parts, 3 part products on the fp16 matrix cores, fp32 accumulate; "
+                 "MFCC in fp32, CMVN statistics in f64)",
         "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: 16 kHz synthetic PCM -> 13 MFCC (25/10 ms, FFT 2048, "
-                               "50 filters) + CMVN + delta + delta-delta = 39 dims; 100 speaker GMMs x 64 "
-                               "diagonal mixtures; %d utterances x %d frames per GPU" % (args.utts, FRAMES_PER_UTT),
-                   "frames_per_gpu": n_frames, "speakers": N_MODELS, "mixtures": N_MIX, "dim": DIM,
+        "config": {"workload": "BASELINE.json configs[2]: 16 kHz synthetic PCM -> 13 MFCC (25/10 ms, FFT 2048, 50 filters) + CMVN + "
+                               "delta + delta-delta = 39 dims; 512-mixture diagonal UBM (EM on the device) + %d MAP-adapted speaker "
+                               "GMMs = %d models x 512 mixtures per frame; %d utterances x %d frames per GPU"
+                               % (CFG2_SPEAKERS, S, args.utts, FRAMES_PER_UTT),
+                   "frames_per_gpu": n_frames, "models": S, "mixtures": CFG2_MIX, "dim": DIM,
                    "sharding": "utterances/%d ranks, models replicated, no collective" % world},
-        "roofline": roof,
-        "kernel_ms_per_step": {"mfcc_frames": ms_mfcc / max(1, args.steps), "cmvn_delta": ms_cmvn / max(1, args.steps),
-                               "gmm_score": ms_score / max(1, args.steps), "finalize": ms_fin / max(1, args.steps)},
+        "rank_frames_per_s": rates,
+        "scaling_efficiency_vs_rank0_alone": None,
+        "roofline": score_roofline(kname, n_frames, S, CFG2_MIX, DIM, score_s, hbm),
+        "mfcc_roofline": mfcc_roofline(args.utts * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
+        "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
+        "hbm_copy_ceiling_GBps": hbm,
         "device": _lib.device_name(),
+        "model_set": ms.info(),
+        "parity": {"all_sums_finite": bool(np.all(np.isfinite(sums))),
+                   "last_two_steps_bit_identical": bool(np.array_equal(prev, sums)) if prev is not None else None},
     }
-    if world == 1:
-        # the other engines on the same batch, outside the timed region (HIP-event time per launch)
-        alt = {}
-        _lib.profile_enable(True)
-        for name, eng in (("fp32_mfma", 2), ("vector_alu", 1)):
-            _lib.set_option("score_engine", eng)
-            ex.predict_batch(ms, pcm, nd=ND)
-            _lib.profile_reset()
-            for _ in range(3):
-                ex.predict_batch(ms, pcm, nd=ND)
-            t_alt, n_alt = _lib.profile_get(_lib.T_SCORE)
-            alt[name] = {"kernel": _lib.last_score_kernel(), "ms_per_launch": t_alt / max(1, n_alt),
-                         "frac_of_fp32_peak": flops_per_launch / (t_alt / max(1, n_alt) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
-        _lib.set_option("score_engine", 0)
-        _lib.profile_enable(False)
-        result["roofline"]["other_engines"] = alt
-    if not args.no_cpu_baseline and world == 1:
-        cb, spec = cpu_baseline_leg(args.cpu_sample_utts, 10.04)
+    if world == 1 and not args.no_cpu_baseline:
+        tmp = tempfile.mkdtemp()
+        sample_models = [0] + list(range(1, 12))           # the UBM + 11 speakers: bounded CPU work
+        files = []
+        for i in sample_models:
+            p = os.path.join(tmp, "m%d.model" % i)
+            models[i].dump(p)
+            files.append(p)
+        spec = dict(fs=FS, mfcc_kw=MFCC_KW, nd=ND, n_utt=args.cpu_sample_utts, seconds=10.04, seed=AUDIO_SEED,
+                    n_speakers=CFG2_SPEAKERS, model_files=files, single_core_models=2)
+        cb, err = cpu_baseline_leg(spec)
         if cb is None:
-            result["cpu_baseline"] = {"error": spec}
+            result["cpu_baseline"] = {"error": err}
         else:
-            # parity of the device path on exactly the CPU sample
-            from speaker_recognition_amd import synth
-            sample = [synth.synth_speech(u % N_MODELS, 10.04, FS, seed=spec["seed"] + u) for u in range(spec["n_utt"])]
-            dsums, darg = ex.predict_batch(ms, Batch.from_pcm(sample), nd=ND)
+            sample = [synth.synth_speech(u % CFG2_SPEAKERS, 10.04, FS, seed=AUDIO_SEED + u) for u in range(spec["n_utt"])]
+            sub = ModelSet([GMM.load(f) for f in files])
+            dsums, darg = ex.predict_batch(sub, Batch.from_pcm(sample), nd=ND)
             csums = np.array(cb["sums"])
+            scale = S / float(len(files))                  # the CPU leg scored len(files) of the S models
+            t_total = (cb["t_mfcc_pool_s"] or cb["t_mfcc_s"]) + cb["t_gmm_s"] * scale
             result["cpu_baseline"] = {
-                "value": cb["frames_per_s"], "unit": "frames/s", "cores": cb["cores"], "kind": cb["kind"],
-                "sample": "%d utterances x 10.04 s (%d frames) of the same workload, all %d speaker models; GMM "
-                          "scoring by the reference's compiled C++ score_batch (concurrency=cores), MFCC by the "
-                          "float64 numpy restatement of MFCC.py (1 core)" % (spec["n_utt"], cb["n_frames"], N_MODELS),
-                "mfcc_frames_per_s": cb["mfcc_frames_per_s"], "gmm_frames_per_s": cb["gmm_frames_per_s"],
+                "value": cb["n_frames"] / t_total, "unit": "frames/s", "cores": cb["cores"], "kind": cb["kind"],
+                "sample": "%d utterances x 10.04 s (%d frames) of the same workload; GMM: the reference's compiled C++ score_batch "
+                          "(concurrency = cores) on %d of the %d models, scaled linearly to all of them; MFCC: float64 numpy "
+                          "restatement of MFCC.py through multiprocessing.Pool(%d)" % (spec["n_utt"], cb["n_frames"], len(files), S, cb["pool_procs"]),
+                "gmm_frames_per_s_all_models": cb["gmm_frames_per_s"] / scale,
+                "gmm_frames_per_s_all_models_concurrency_1": (cb["gmm_frames_per_s_1core"] / scale) if cb["gmm_frames_per_s_1core"] else None,
+                "mfcc_frames_per_s_pool": cb["mfcc_frames_per_s_pool"], "mfcc_frames_per_s_1proc": cb["mfcc_frames_per_s_1proc"],
             }
-            result["parity"] = {
-                "argmax_mismatches": int(np.sum(darg != np.array(cb["argmax"]))),
-                "max_rel_sum_diff": float(np.max(np.abs(dsums - csums) / np.maximum(1.0, np.abs(csums)))),
-                "utterances": spec["n_utt"],
-            }
+            result["parity"].update({
+                "cpu_sample_argmax_mismatches": int(np.sum(darg != np.array(cb["argmax"]))),
+                "cpu_sample_max_rel_sum_diff": float(np.max(np.abs(dsums - csums) / np.maximum(1.0, np.abs(csums)))),
+                "cpu_sample": "%d utterances x %d models vs the reference's C++ scorer on the float64 numpy MFCC" % (spec["n_utt"], len(files))})
+    if world == 1 and not args.no_config_blocks:
+        blocks, preq = {}, {}
+        for name, fn in (("configs[1]", lambda: block_cfg1(_lib, ex, base, hbm, preq)),
+                         ("configs[3]_rank_shard_subsample", lambda: block_cfg3(_lib, hbm, preq)),
+                         ("configs[4]_streaming", lambda: block_stream(_lib)),
+                         ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
+                         ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
+            try:
+                blocks[name] = fn()
+            except Exception as e:                          # a secondary block must not take the headline down
+                blocks[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the parity samples of the blocks, checked by the oracle in its own process (checker only)
+        try:
+            import pickle
+            path = os.path.join(tempfile.mkdtemp(), "parity.pkl")
+            pickle.dump(preq, open(path, "wb"))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "parity_check.py"), path],
+                                 capture_output=True, text=True, timeout=900)
+            par = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+            for name, v in par.items():
+                if isinstance(blocks.get(name), dict):
+                    blocks[name]["parity"] = dict(blocks[name].get("parity") or {}, **v)
+        except Exception as e:
+            blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
+        result["configs"] = blocks
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

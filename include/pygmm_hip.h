@@ -19,6 +19,7 @@
 #ifndef PYGMM_HIP_H
 #define PYGMM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -68,9 +69,16 @@ int get_nr_mixtures(GMM *gmm);
 const char *sr_last_error(void);
 
 /* Device plumbing. The HIP runtime is initialised lazily on first use (fork-safe for the
- * multiprocessing callers of src/test/test-nperson.py:135-139). */
+ * multiprocessing callers of src/test/test-nperson.py:135-139).  One process may drive several GPUs:
+ * every host thread has a current device; stream, workspaces, timers and the entry-point lock exist
+ * once per device, so threads on different devices run in parallel and threads sharing a device are
+ * serialised.  Handles that own device memory (SRBatch, SRModelSet, SRStream) belong to the device
+ * they were created on and refuse calls from a thread that is on another one.
+ * sr_set_device: the process default (what threads that never chose get) and the calling thread's;
+ * sr_set_thread_device: the calling thread's only. */
 int sr_device_count(void);
 int sr_set_device(int device);
+int sr_set_thread_device(int device);
 int sr_get_device(void);
 int sr_device_synchronize(void);
 int sr_device_name(char *buf, int buflen);
@@ -84,9 +92,15 @@ int sr_gmm_dumps(GMM *gmm, char *buf, long buflen, long *needed);     /* text fo
 GMM *sr_gmm_loads(const char *text);
 
 /* Contiguous fp32 scoring of ONE model (frames row-major [n][dim], host memory).
- * flags: SR_CLAMP_COMPAT reproduces the reference's underflow behaviour
- * (LL < -708.396 -> ln(1e-15), gmm.cc:34-38 + fastexp.cc:105). */
+ * flags: SR_CLAMP_COMPAT reproduces the reference's underflow behaviour: its mixture sum runs in
+ * the linear domain under FTZ arithmetic, so a term w_k p_k(x) below DBL_MIN = exp(-708.396) counts
+ * as 0 and an all-zero sum returns ln(1e-15) (gmm.cc:34-38, :237-244; pinned by reference-DSO
+ * vectors, tests/golden/make_clamp_golden.py).  Not reproduced: the reference's flush of partial
+ * products in dimension order and its per-dimension exponent floor (fastexp.cc:104-131), which only
+ * differ for frames ~37 sigma away from every mixture.
+ * SR_SCORE_PRECISE keeps to the fp32-grade engines (the split-fp16 ones carry 22 significand bits). */
 #define SR_CLAMP_COMPAT 1
+#define SR_SCORE_PRECISE 0x200
 int sr_score_frames_f32(GMM *gmm, const float *X, long n, int dim, float *ll_out, double *sum_out,
                         int flags);
 
@@ -96,6 +110,12 @@ typedef struct SRModelSet SRModelSet;
 SRModelSet *sr_modelset_create(GMM *const *models, int n_models);
 void sr_modelset_free(SRModelSet *set);
 int sr_modelset_size(SRModelSet *set);
+/* Conditioning of the packed set as the engine dispatcher sees it: out8[0] = amp = max_k sum_d
+ * ((mu_kd - centre_d) / sigma_kd)^2 (the cancellation the expanded quadratic form has to survive in
+ * fp32), [1] = dead fraction of the 32-mixture tiles, [2] = largest per-dimension sigma ratio,
+ * [3] = largest scaled coefficient of the fp16 layouts, [4] = 1 if sigma and weights are shared,
+ * [5] = models, [6] = device. */
+int sr_modelset_info(SRModelSet *set, double *out8);
 int sr_modelset_dim(SRModelSet *set);
 
 /* Utterance batch resident in HBM: either PCM (int16, concatenated, sample_offsets[U+1]) or
@@ -145,6 +165,30 @@ SRBatch *sr_mfcc_extract_batch(SRMfcc *m, SRBatch *pcm, int nd, int cmvn);
 int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out,
                          int *argmax_out, int flags);
 
+/* Every GPU of the node from ONE host process (no torch, no MPI, no collective): utterances are dealt
+ * to n_slots slots by length, slot i lives on device i % sr_device_count() with its own replica of
+ * the models and extractor tables, one host thread per slot runs upload -> MFCC -> CMVN/deltas -> all
+ * models -> sums + argmax, and the per-utterance rows are gathered on the host (the reference:
+ * Threadpool inside the call, gmm.cc:533-560, and multiprocessing.Pool over utterances,
+ * test-gmm.py:128-133).  n_slots = 0 means one slot per visible device; more slots than devices is
+ * legal (the surplus share a device, serialised by its lock).  slot_seconds_out (optional,
+ * [n_slots]) receives each slot's wall time for the pass. */
+typedef struct SRMulti SRMulti;
+SRMulti *sr_multi_create(GMM *const *models, int n_models, double fs, double win_length_ms,
+                         double win_shift_ms, int fft_size, int n_filters, int n_ceps,
+                         double pre_emphasis, int n_slots);
+void sr_multi_free(SRMulti *m);
+int sr_multi_slots(SRMulti *m);
+int sr_multi_slot_device(SRMulti *m, int slot);
+int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_offsets, int n_utt,
+                         int nd, double *sums_out /*[U][S]*/, int *argmax_out /*[U]*/,
+                         double *slot_seconds_out, int flags);
+
+/* Measured device-to-device copy rate (bytes read + written per second, GB/s) of a `bytes`-sized
+ * buffer over `iters` copies on the library's stream: the HBM ceiling bench.py quotes beside the
+ * nominal 8 TB/s. */
+int sr_hbm_copy_gbps(size_t bytes, int iters, double *gbps_out);
+
 /* Fixed-shape serving session: n_windows windows of window_samples int16 samples per tick.  Two
  * slots of pinned + device buffers and a second HIP stream: the H2D copy of tick i+1 overlaps the
  * kernels of tick i.  submit() returns after queueing (at most two ticks in flight); collect()
@@ -188,7 +232,11 @@ int sr_profile_reset(void);
 int sr_profile_get(int kind, double *total_ms, long *launches);
 
 /* Tunables (kernel variant selection for A/B runs); value 0 = automatic:
+ *   "score_engine" 1 vector ALU | 2 fp32 matrix cores | 3 split-bf16 | 4 split-bf16 shared-sigma |
+ *                  5 split-fp16 | 6 split-fp16 shared-sigma,
  *   "score_frames_per_lane" 1|2|4, "score_model_groups" n, "score_packed" -1 (scalar FMA) | 1 (packed),
+ *   "score_mfma_ft" column tiles per wave, "score_h2s_force_exc" 1 (testing: everything through the
+ *   exception pass of engine 6), "mfcc_waves_per_block" 4|12,
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel). */
 int sr_set_option(const char *key, long value);
 /* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */

@@ -19,19 +19,22 @@ LIB_PATH = os.environ.get("SR_PYGMM_LIB") or os.path.join(_HERE, "lib", "pygmm.s
 LEGACY_SYMBOLS = ["new_gmm", "load", "dump", "train_model", "train_model_from_ubm", "score_all",
                   "score_batch", "score_instance", "get_dim", "get_nr_mixtures"]
 EXT_SYMBOLS = [
-    "sr_last_error", "sr_device_count", "sr_set_device", "sr_get_device", "sr_device_synchronize",
+    "sr_last_error", "sr_device_count", "sr_set_device", "sr_set_thread_device", "sr_get_device", "sr_device_synchronize",
     "sr_device_name", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
     "sr_gmm_loads", "sr_score_frames_f32", "sr_modelset_create", "sr_modelset_free",
-    "sr_modelset_size", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
+    "sr_modelset_size", "sr_modelset_info", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
     "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_reset_pcm", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
     "sr_batch_dim", "sr_batch_offsets", "sr_batch_download", "sr_score_batch_set",
     "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
     "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
+    "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
+    "sr_hbm_copy_gbps",
 ]
 
 SR_CLAMP_COMPAT = 1
+SR_SCORE_PRECISE = 0x200
 SR_STREAM_GRAPH = 0x100
 T_SCORE, T_MFCC, T_CMVN, T_FINALIZE, T_ESTEP, T_SCORE_REF = 0, 1, 2, 3, 4, 5
 
@@ -78,6 +81,7 @@ def lib():
         "sr_last_error": (C.c_char_p, []),
         "sr_device_count": (i32, []),
         "sr_set_device": (i32, [i32]),
+        "sr_set_thread_device": (i32, [i32]),
         "sr_get_device": (i32, []),
         "sr_device_synchronize": (i32, []),
         "sr_device_name": (i32, [C.c_char_p, i32]),
@@ -90,6 +94,7 @@ def lib():
         "sr_modelset_create": (vp, [C.POINTER(vp), i32]),
         "sr_modelset_free": (None, [vp]),
         "sr_modelset_size": (i32, [vp]),
+        "sr_modelset_info": (i32, [vp, dp]),
         "sr_modelset_dim": (i32, [vp]),
         "sr_batch_from_pcm": (vp, [C.POINTER(C.c_int16), C.POINTER(i64), i32]),
         "sr_batch_from_pcm_f32": (vp, [fp, C.POINTER(i64), i32]),
@@ -125,6 +130,12 @@ def lib():
         "sr_stream_submit": (i32, [vp, C.POINTER(C.c_int16)]),
         "sr_stream_collect": (i32, [vp, dp, C.POINTER(i32), dp]),
         "sr_stream_free": (None, [vp]),
+        "sr_multi_create": (vp, [C.POINTER(vp), i32, dbl, dbl, dbl, i32, i32, i32, dbl, i32]),
+        "sr_multi_free": (None, [vp]),
+        "sr_multi_slots": (i32, [vp]),
+        "sr_multi_slot_device": (i32, [vp, i32]),
+        "sr_multi_predict_pcm": (i32, [vp, C.POINTER(C.c_int16), C.POINTER(i64), i32, i32, dp, C.POINTER(i32), dp, i32]),
+        "sr_hbm_copy_gbps": (i32, [C.c_size_t, i32, dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -172,6 +183,18 @@ def as_i32p(a: np.ndarray):
 
 def set_device(device: int) -> None:
     check(lib().sr_set_device(int(device)), "sr_set_device")
+
+
+def set_thread_device(device: int) -> None:
+    """The calling host thread's current device (handles belong to the device they were created on)."""
+    check(lib().sr_set_thread_device(int(device)), "sr_set_thread_device")
+
+
+def hbm_copy_gbps(nbytes: int = 1 << 30, iters: int = 10) -> float:
+    """Measured device-to-device copy rate (read + written bytes per second, GB/s)."""
+    g = C.c_double(0)
+    check(lib().sr_hbm_copy_gbps(int(nbytes), int(iters), C.byref(g)), "sr_hbm_copy_gbps")
+    return g.value
 
 
 def device_count() -> int:

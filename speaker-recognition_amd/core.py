@@ -125,6 +125,13 @@ class ModelSet:
     def dim(self) -> int:
         return lib().sr_modelset_dim(self._h)
 
+    def info(self) -> dict:
+        """Conditioning of the packed set as the engine dispatcher sees it (sr_modelset_info)."""
+        out = np.zeros(8)
+        check(lib().sr_modelset_info(self._h, _lib.as_dp(out)), "sr_modelset_info")
+        return {"amp": out[0], "pad_waste": out[1], "sigma_ratio": out[2], "coef_max": out[3],
+                "shared_sigma": bool(out[4]), "models": int(out[5]), "device": int(out[6])}
+
     def score(self, feats: Batch, frame_ll: bool = False, clamp_compat: bool = True):
         """-> (sums[U, S] float64, argmax[U] int32[, frame_ll[S, n] float32])."""
         U, S = feats.n_utt, len(self)
@@ -243,6 +250,59 @@ class ServingStream:
         try:
             if self._h:
                 lib().sr_stream_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class MultiPredictor:
+    """Every GPU of the node from one process: utterances are dealt to ``n_slots`` slots by length
+    (slot i on device i % device_count), each slot has its own replica of the models and a host thread
+    that runs MFCC -> CMVN/deltas -> all models -> sums + argmax on its GPU; rows are gathered on the
+    host (``sr_multi_*``; the reference: Threadpool in gmm.cc:533-560, Pool in test-gmm.py:128-133)."""
+
+    def __init__(self, gmms, fs, n_slots=0, win_length_ms=32, win_shift_ms=16, FFT_SIZE=2048, n_filters=50,
+                 n_ceps=13, pre_emphasis_coef=0.95):
+        self._keep = list(gmms)
+        arr = (C.c_void_p * len(self._keep))(*[g.gmm for g in self._keep])
+        h = lib().sr_multi_create(arr, len(self._keep), float(fs), float(win_length_ms), float(win_shift_ms),
+                                  int(FFT_SIZE), int(n_filters), int(n_ceps), float(pre_emphasis_coef), int(n_slots))
+        if not h:
+            raise SRError("sr_multi_create failed: %s" % _lib.last_error())
+        self._h = C.c_void_p(h)
+        self.n_models = len(self._keep)
+        self.slot_seconds = None
+
+    @property
+    def n_slots(self) -> int:
+        return lib().sr_multi_slots(self._h)
+
+    def slot_devices(self):
+        return [lib().sr_multi_slot_device(self._h, i) for i in range(self.n_slots)]
+
+    def predict(self, signals, nd=0, clamp_compat=True):
+        """``signals``: list of int16 arrays.  -> (sums[U, S], argmax[U])."""
+        sigs = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]
+        offsets = np.zeros(len(sigs) + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum([len(s) for s in sigs])
+        cat = np.ascontiguousarray(np.concatenate(sigs)) if sigs else np.zeros(0, np.int16)
+        return self.predict_concat(cat, offsets, nd, clamp_compat)
+
+    def predict_concat(self, cat, offsets, nd=0, clamp_compat=True):
+        U = len(offsets) - 1
+        sums = np.zeros((U, self.n_models), dtype=np.float64)
+        arg = np.full(U, -1, dtype=np.int32)
+        secs = np.zeros(self.n_slots, dtype=np.float64)
+        check(lib().sr_multi_predict_pcm(self._h, cat.ctypes.data_as(C.POINTER(C.c_int16)), _lib.as_i64p(offsets), U,
+                                         int(nd), _lib.as_dp(sums), _lib.as_i32p(arg), _lib.as_dp(secs),
+                                         _lib.SR_CLAMP_COMPAT if clamp_compat else 0), "sr_multi_predict_pcm")
+        self.slot_seconds = secs
+        return sums, arg
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().sr_multi_free(self._h)
                 self._h = None
         except Exception:
             pass

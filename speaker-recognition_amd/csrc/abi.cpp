@@ -64,6 +64,7 @@ static std::unique_ptr<SRBatch> feature_batch(const float *X, int64_t n, int dim
     ensure_device();
     if (n < 0 || dim <= 0 || n_utt < 0) fail("bad batch shape");
     auto b = std::make_unique<SRBatch>();
+    b->bind_device();
     b->kind = SRBatch::FEATURES;
     b->n_utt = n_utt;
     b->dim = dim;
@@ -193,25 +194,30 @@ int get_nr_mixtures(GMM *gmm) { return gmm ? gmm->nr_mixtures : 0; }
 
 const char *sr_last_error(void) { return last_error().c_str(); }
 
-int sr_device_count(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    return n;
-}
+int sr_device_count(void) { return visible_devices(); }
 
+// No api lock here: these only move the calling thread between devices.
 int sr_set_device(int device) {
-    SR_TRY
-    if (ctx().stream) {
-        if (device != ctx().device) fail("device already initialised as %d; set it before first use", ctx().device);
+    try {
+        set_default_device(device);
         return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
     }
-    if (device < 0) fail("negative device index");
-    ctx().device = device;
-    return 0;
-    SR_CATCH(-1)
 }
 
-int sr_get_device(void) { return ctx().device; }
+int sr_set_thread_device(int device) {
+    try {
+        set_thread_device(device);
+        return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+
+int sr_get_device(void) { return current_device(); }
 
 int sr_device_synchronize(void) {
     SR_TRY
@@ -303,6 +309,33 @@ SRModelSet *sr_modelset_create(GMM *const *models, int n_models) {
 }
 
 void sr_modelset_free(SRModelSet *set) { delete set; }
+
+// Conditioning of a packed set, as the engine dispatcher sees it (score.hpp): out[0] = amp (max_k
+// sum_d (mu'_kd / sigma_kd)^2 of the expanded form), out[1] = padding waste of the 32-mixture tiles,
+// out[2] = largest per-dimension sigma ratio, out[3] = largest scaled coefficient (fp16 schemes),
+// out[4] = 1 when the set shares sigma and weights, out[5] = models, out[6] = device.
+int sr_modelset_info(SRModelSet *set, double *out8) {
+    SR_TRY
+    if (!set || !out8) fail("null argument");
+    for (int i = 0; i < 8; i++) out8[i] = 0.0;
+    const bool shared = !set->h2s.params.empty() || !set->shared.params.empty();
+    if (!set->h2s.params.empty()) {
+        out8[0] = set->h2s.amp; out8[1] = set->h2s.pad_waste; out8[2] = set->h2s.sigma_ratio; out8[3] = set->h2s.coef_max;
+    } else if (!set->h2.params.empty()) {
+        out8[0] = set->h2.amp; out8[1] = set->h2.pad_waste; out8[2] = set->h2.sigma_ratio; out8[3] = set->h2.coef_max;
+    } else if (!set->shared.params.empty()) {
+        out8[0] = set->shared.amp; out8[1] = set->shared.pad_waste;
+    } else if (!set->bx3.params.empty()) {
+        out8[0] = set->bx3.amp; out8[1] = set->bx3.pad_waste; out8[2] = set->bx3.sigma_ratio;
+    } else if (!set->mfma.params.empty()) {
+        out8[0] = set->mfma.amp; out8[1] = set->mfma.pad_waste;
+    }
+    out8[4] = shared ? 1.0 : 0.0;
+    out8[5] = set->host.n_models;
+    out8[6] = set->device;
+    return 0;
+    SR_CATCH(-1)
+}
 int sr_modelset_size(SRModelSet *set) { return set ? set->host.n_models : 0; }
 int sr_modelset_dim(SRModelSet *set) { return set ? set->host.dim : 0; }
 
@@ -310,6 +343,7 @@ static SRBatch *pcm_batch(const void *pcm, bool is_f32, const int64_t *sample_of
     ensure_device();
     if (n_utt < 0 || !sample_offsets) fail("bad PCM batch arguments");
     auto b = std::make_unique<SRBatch>();
+    b->bind_device();
     b->kind = is_f32 ? SRBatch::PCMF32 : SRBatch::PCM16;
     b->n_utt = n_utt;
     b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
@@ -353,6 +387,7 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     if (!b || !pcm) fail("null argument");
     if (b->kind != SRBatch::PCM16) fail("sr_batch_update_pcm needs an int16 PCM batch");
     if (n_samples != b->n_rows) fail("sample count %lld does not match the batch (%lld)", (long long)n_samples, (long long)b->n_rows);
+    b->bind_device();
     b->pcm16.upload(pcm, (size_t)n_samples);
     sync_stream();
     return 0;
@@ -368,6 +403,7 @@ int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_off
         if (sample_offsets[u + 1] < sample_offsets[u]) fail("sample_offsets must be non-decreasing");
     const int64_t n = sample_offsets[n_utt];
     if (n > 0 && !pcm) fail("null PCM pointer");
+    b->bind_device();
     b->n_utt = n_utt;
     b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
     b->n_rows = n;
@@ -396,6 +432,7 @@ int sr_batch_download(SRBatch *b, float *out) {
     SR_TRY
     if (!b || !out) fail("null argument");
     if (b->kind != SRBatch::FEATURES) fail("only feature batches can be downloaded");
+    b->bind_device();
     b->data.download(out, (size_t)b->n_rows * b->dim);
     sync_stream();
     return 0;
@@ -457,7 +494,7 @@ int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, doubl
                          int *argmax_out, int flags) {
     SR_TRY
     if (!m || !set || !pcm) fail("null argument");
-    static SRBatch *feat_ws = new SRBatch();   // reused across steps: the serving loop allocates nothing
+    SRBatch *feat_ws = &per_device<SRBatch>();   // reused across steps: the serving loop allocates nothing
     mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
     const ScoreResult r = score_device(*set, *feat_ws, false, flags);
     if (!fetch_results(r, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
@@ -476,6 +513,30 @@ int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
     SR_TRY
     if (!gmm || !X || !param) fail("null argument to sr_train_f32");
     return train_em(*gmm, ubm_or_null, X, n, dim, *param, seed);
+    SR_CATCH(-1)
+}
+
+int sr_hbm_copy_gbps(size_t bytes, int iters, double *gbps_out) {
+    SR_TRY
+    if (!gbps_out || bytes == 0 || iters <= 0) fail("bad arguments to sr_hbm_copy_gbps");
+    ensure_device();
+    DevBuf<char> a(bytes), b(bytes);
+    SR_HIP(hipMemsetAsync(a.p, 1, bytes, ctx().stream));
+    hipEvent_t e0, e1;
+    SR_HIP(hipEventCreate(&e0));
+    SR_HIP(hipEventCreate(&e1));
+    SR_HIP(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, ctx().stream));   // warm
+    SR_HIP(hipEventRecord(e0, ctx().stream));
+    for (int i = 0; i < iters; i++)
+        SR_HIP(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    SR_HIP(hipEventRecord(e1, ctx().stream));
+    SR_HIP(hipStreamSynchronize(ctx().stream));
+    float ms = 0.f;
+    SR_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *gbps_out = 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+    return 0;
     SR_CATCH(-1)
 }
 

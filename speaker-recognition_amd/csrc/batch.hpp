@@ -29,6 +29,7 @@ struct TileTable {
 struct SRBatch {
     enum Kind { PCM16 = 0, PCMF32 = 1, FEATURES = 2 };
     int kind = FEATURES;
+    int device = -1;                // the GPU its buffers live on (set when they are first filled)
     int n_utt = 0;
     int dim = 0;                    // features only
     int64_t n_rows = 0;             // samples or frames
@@ -39,4 +40,10 @@ struct SRBatch {
     std::vector<std::unique_ptr<sr::TileTable>> tile_tables;
 
     sr::TileTable &tiles_for(int frames_per_tile);
+    // binds an empty batch to the calling thread's device / refuses one that lives elsewhere
+    void bind_device() {
+        if (device < 0) device = sr::current_device();
+        if (device != sr::current_device())
+            sr::fail("batch lives on device %d, the calling thread is on device %d", device, sr::current_device());
+    }
 };

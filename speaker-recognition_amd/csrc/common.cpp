@@ -30,32 +30,72 @@ void fail(const char *fmt, ...) {
 
 std::atomic<long> g_devbuf_epoch{0};
 
-std::recursive_mutex &api_mutex() {
-    static std::recursive_mutex *m = new std::recursive_mutex();   // leaked: usable during exit
-    return *m;
+static std::atomic<int> g_default_device{0};
+static thread_local int tl_device = -1;
+
+int current_device() { return tl_device >= 0 ? tl_device : g_default_device.load(); }
+
+static void check_device_index(int device) {
+    if (device < 0 || device >= MAX_DEVICES) fail("device index %d out of range (0..%d)", device, MAX_DEVICES - 1);
+}
+void set_thread_device(int device) {
+    check_device_index(device);
+    tl_device = device;
+}
+void set_default_device(int device) {
+    check_device_index(device);
+    g_default_device.store(device);
+    tl_device = device;
 }
 
-static Ctx g_ctx;
-static bool g_ready = false;
+int visible_devices() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex *m = new std::recursive_mutex[MAX_DEVICES];   // leaked: usable during exit
+    return m[current_device()];
+}
+
+static Ctx g_ctx[MAX_DEVICES];
+static bool g_ready[MAX_DEVICES];
 static std::mutex g_mu;
 
-Ctx &ctx() { return g_ctx; }
+Ctx &ctx() { return g_ctx[current_device()]; }
 
 void ensure_device() {
+    const int d = current_device();
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ready) return;
+    if (g_ready[d]) {
+        // the HIP current device is per host thread: set it on every entry (a thread that first
+        // reaches the library after another one initialised the context would otherwise allocate
+        // on device 0 while the stream belongs to device d)
+        SR_HIP(hipSetDevice(d));
+        return;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
         fail("no HIP device available (%s); lib/pygmm.so has no CPU path",
              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    if (g_ctx.device >= n) fail("device %d requested but only %d visible", g_ctx.device, n);
-    SR_HIP(hipSetDevice(g_ctx.device));
+    if (d >= n) fail("device %d requested but only %d visible", d, n);
+    SR_HIP(hipSetDevice(d));
     hipDeviceProp_t prop;
-    SR_HIP(hipGetDeviceProperties(&prop, g_ctx.device));
-    g_ctx.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    SR_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-    g_ready = true;
+    SR_HIP(hipGetDeviceProperties(&prop, d));
+    g_ctx[d].device = d;
+    g_ctx[d].n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].stream, hipStreamNonBlocking));
+    g_ready[d] = true;
+}
+
+void *per_device_slot(void **slots, void *(*make)()) {
+    static std::mutex mu;
+    const int d = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    if (!slots[d]) slots[d] = make();
+    return slots[d];
 }
 
 // ---------------- timers ----------------
@@ -63,15 +103,20 @@ struct Pending {
     TimerKind kind;
     hipEvent_t e0, e1;
 };
-static std::vector<Pending> g_pending;
-static std::vector<hipEvent_t> g_pool;
-static double g_ms[T_COUNT];
-static long g_launches[T_COUNT];
+struct TimerState {
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[T_COUNT] = {};
+    long launches[T_COUNT] = {};
+    bool prewarmed = false;
+};
+static TimerState &ts() { return per_device<TimerState>(); }
 
 static hipEvent_t get_event() {
-    if (!g_pool.empty()) {
-        hipEvent_t e = g_pool.back();
-        g_pool.pop_back();
+    auto &t = ts();
+    if (!t.pool.empty()) {
+        hipEvent_t e = t.pool.back();
+        t.pool.pop_back();
         return e;
     }
     hipEvent_t e;
@@ -89,16 +134,16 @@ ScopedKernelTimer::ScopedKernelTimer(TimerKind k) : kind(k) {
 ScopedKernelTimer::~ScopedKernelTimer() {
     if (!e0) return;
     (void)hipEventRecord(e1, ctx().stream);
-    g_pending.push_back({kind, e0, e1});
+    ts().pending.push_back({kind, e0, e1});
 }
 
 // The HIP runtime grows its signal pool the first time more than a handful of events have been
 // recorded (measured: one ~8 ms stall in the second profiled step).  Do that growth here, once, so
 // that timed regions bracketed by events see none of it.
 void profile_prewarm() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+    auto &t = ts();
+    if (t.prewarmed) return;
+    t.prewarmed = true;
     std::vector<hipEvent_t> ev(64);
     for (auto &e : ev) {
         SR_HIP(hipEventCreate(&e));
@@ -107,37 +152,40 @@ void profile_prewarm() {
     SR_HIP(hipStreamSynchronize(ctx().stream));
     float ms = 0.f;
     for (size_t i = 1; i < ev.size(); i++) (void)hipEventElapsedTime(&ms, ev[i - 1], ev[i]);
-    for (auto &e : ev) g_pool.push_back(e);
+    for (auto &e : ev) t.pool.push_back(e);
 }
 
 void profile_collect() {
-    if (g_pending.empty()) return;
+    auto &t = ts();
+    if (t.pending.empty()) return;
     SR_HIP(hipStreamSynchronize(ctx().stream));
-    for (auto &p : g_pending) {
+    for (auto &p : t.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
-            g_ms[p.kind] += ms;
-            g_launches[p.kind] += 1;
+            t.ms[p.kind] += ms;
+            t.launches[p.kind] += 1;
         }
-        g_pool.push_back(p.e0);
-        g_pool.push_back(p.e1);
+        t.pool.push_back(p.e0);
+        t.pool.push_back(p.e1);
     }
-    g_pending.clear();
+    t.pending.clear();
 }
 
 void profile_reset() {
     profile_collect();
+    auto &t = ts();
     for (int i = 0; i < T_COUNT; i++) {
-        g_ms[i] = 0;
-        g_launches[i] = 0;
+        t.ms[i] = 0;
+        t.launches[i] = 0;
     }
 }
 
 void profile_get(int kind, double *ms, long *launches) {
     profile_collect();
     if (kind < 0 || kind >= T_COUNT) fail("bad timer kind %d", kind);
-    if (ms) *ms = g_ms[kind];
-    if (launches) *launches = g_launches[kind];
+    auto &t = ts();
+    if (ms) *ms = t.ms[kind];
+    if (launches) *launches = t.launches[kind];
 }
 
 }  // namespace sr

@@ -33,21 +33,41 @@ struct Error : std::runtime_error {
                        __LINE__);                                                      \
     } while (0)
 
-// One lock around every compute entry point of the C ABI: the library keeps one stream and cached
-// workspaces per process, so concurrent callers (ctypes drops the GIL) are serialised rather than
-// left to race.  The reference's callers parallelise with processes (test-nperson.py:135-139).
-std::recursive_mutex &api_mutex();
+// ---- devices.  One process may drive several GPUs: every host thread has a CURRENT device
+// (thread-local; the process default until sr_set_device / set_thread_device changes it), and
+// everything the library caches -- stream, workspaces, timers, lock -- exists once per device.
+// The reference parallelises scoring with a thread pool inside the call (gmm.cc:533-560) and
+// utterances with processes (test-gmm.py:128-133); here a host thread per GPU plays both roles
+// (SURVEY.md 8e), and a lock per device serialises the threads that share one.
+constexpr int MAX_DEVICES = 16;
+int current_device();
+void set_thread_device(int device);      // this thread's current device
+void set_default_device(int device);     // what threads that never chose get (and this thread)
+int visible_devices();                   // hipGetDeviceCount, 0 on error
 
-// ---- per-process device context: one stream, lazily created (fork-safe: nothing touches
-// HIP before the first call that needs the device). ----
+// One lock per device around every compute entry point of the C ABI: the library keeps one stream
+// and cached workspaces per device, so concurrent callers on the same device (ctypes drops the
+// GIL) are serialised rather than left to race; callers on different devices run in parallel.
+std::recursive_mutex &api_mutex();       // of the calling thread's current device
+
+// ---- per-device context: one stream, lazily created (fork-safe: nothing touches HIP before the
+// first call that needs the device). ----
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool profiling = false;
     int n_cu = 256;
 };
-Ctx &ctx();
-void ensure_device();   // throws sr::Error when no usable GPU: the product has no CPU path
+Ctx &ctx();             // of the calling thread's current device
+void ensure_device();   // hipSetDevice(current) for THIS thread + lazy stream; throws sr::Error when no usable GPU
+
+// Lazily constructed per-device singleton (workspaces); leaked on purpose: no hipFree at exit.
+void *per_device_slot(void **slots, void *(*make)());
+template <typename T>
+T &per_device() {
+    static void *slots[MAX_DEVICES] = {};
+    return *static_cast<T *>(per_device_slot(slots, []() -> void * { return new T(); }));
+}
 
 // ---- kernel timing with HIP events on OUR stream ----
 enum TimerKind { T_SCORE = 0, T_MFCC = 1, T_CMVN = 2, T_FINALIZE = 3, T_ESTEP = 4, T_SCORE_REF = 5, T_COUNT = 6 };

@@ -213,10 +213,7 @@ struct EmWorkspace {
     DevBuf<float> slabs, mean_f32;
     DevBuf<double> stats;
 };
-static EmWorkspace &ews() {
-    static EmWorkspace *w = new EmWorkspace();
-    return *w;
-}
+static EmWorkspace &ews() { return per_device<EmWorkspace>(); }
 
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed) {

@@ -272,7 +272,10 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
 
 // ---------------- host side ----------------
 
-static char g_last_kernel[192] = "";
+struct LastKernel {
+    char name[256] = "";
+};
+#define g_last_kernel (per_device<LastKernel>().name)      // threads on different devices launch concurrently
 const char *last_score_kernel() { return g_last_kernel; }
 
 ScoreOptions &score_options() {
@@ -292,10 +295,7 @@ struct ScoreWorkspace {
     DevBuf<double> ref_partial;
     DevBuf<int> exc_list, exc_count;     // ... and its (tile, block) exception list
 };
-static ScoreWorkspace &ws() {
-    static ScoreWorkspace *w = new ScoreWorkspace();   // leaked on purpose: no hipFree at exit
-    return *w;
-}
+static ScoreWorkspace &ws() { return per_device<ScoreWorkspace>(); }   // one per device, leaked on purpose
 
 template <int DP, int F, bool PK>
 static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
@@ -444,6 +444,9 @@ static void ensure_bx3_layout(SRModelSet &s) {
 ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags) {
     ensure_device();
     if (feat.kind != SRBatch::FEATURES) fail("scoring needs a feature batch");
+    feat.bind_device();
+    if (set.device != ctx().device)
+        fail("model set lives on device %d, the calling thread is on device %d", set.device, ctx().device);
     if (feat.dim != set.host.dim)
         fail("feature dim %d != model dim %d", feat.dim, set.host.dim);
     const int S = set.host.n_models;
@@ -615,7 +618,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_tiles = tt.n_tiles;
             a.log2_k = (float)std::log2((double)h.n_tiles * MT);
             a.force_exc = opt.h2s_force_exc;
-            snprintf(g_last_kernel, sizeof g_last_kernel,
+            snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_h2s_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
                      "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf, SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
@@ -638,7 +641,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.clamp = (flags & 1) ? 1 : 0;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
-            snprintf(g_last_kernel, sizeof g_last_kernel,
+            snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_bx3_shared_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-bf16 MFMA)",
                      set.shared.kq, set.shared.kl, SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
@@ -671,15 +674,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_tiles = tt.n_tiles;
             ScopedKernelTimer t(T_SCORE);
             if (use_h2) {
-                snprintf(g_last_kernel, sizeof g_last_kernel,
+                snprintf(g_last_kernel, sizeof(LastKernel::name),
                          "gmm_score_split_kernel<f16x2,%d,%d> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)", split.ks, FT);
                 launch_score_split(a, SPLIT_F16X2, split.ks, FT);
             } else if (use_bx3) {
-                snprintf(g_last_kernel, sizeof g_last_kernel,
+                snprintf(g_last_kernel, sizeof(LastKernel::name),
                          "gmm_score_split_kernel<bf16x3,%d,%d> (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)", split.ks, FT);
                 launch_score_split(a, SPLIT_BF16X3, split.ks, FT);
             } else {
-                snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
+                snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
                 launch_score_mfma(a, DP, FT);
             }
         } else {
@@ -695,7 +698,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.dim = feat.dim;
             a.n_models = S;
             a.clamp = (flags & 1) ? 1 : 0;
-            snprintf(g_last_kernel, sizeof g_last_kernel, "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
+            snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
                      (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");
             ScopedKernelTimer t(T_SCORE);
             dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
@@ -723,10 +726,7 @@ struct ResultStaging {
     PinnedBuf<float> frame_ll;
     PinnedBuf<int> oor;
 };
-static ResultStaging &staging() {
-    static ResultStaging *s = new ResultStaging();   // leaked on purpose (no hipHostFree at exit)
-    return *s;
-}
+static ResultStaging &staging() { return per_device<ResultStaging>(); }   // leaked on purpose (no hipHostFree at exit)
 
 // Copies the last scoring call's results to host memory through pinned staging.
 bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,

@@ -152,13 +152,14 @@ static void launch_lpc_order(int order, dim3 grid, size_t lds, const PcmT *pcm, 
 
 // Device window table (float64) of an extractor, created on first use.
 static const double *lpc_window(SRMfcc &m) {
-    if (!m.dev_window_f64) {
+    std::shared_ptr<void> &slot = m.dev_window_f64[current_device()];
+    if (!slot) {
         auto buf = std::make_shared<DevBuf<double>>();
         buf->upload(m.window.data(), m.window.size());
         sync_stream();
-        m.dev_window_f64 = buf;
+        slot = buf;
     }
-    return std::static_pointer_cast<DevBuf<double>>(m.dev_window_f64)->p;
+    return std::static_pointer_cast<DevBuf<double>>(slot)->p;
 }
 
 // LPC coefficients of every frame of `pcm` into columns [col_off, col_off + n_lpc) of `out`.

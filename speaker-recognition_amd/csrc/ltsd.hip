@@ -133,8 +133,8 @@ struct LtsdPlan {
 };
 
 static LtsdPlan &plan_for(int N) {
-    static std::map<std::pair<int, int>, std::unique_ptr<LtsdPlan>> *plans =
-        new std::map<std::pair<int, int>, std::unique_ptr<LtsdPlan>>();   // leaked on purpose
+    typedef std::map<std::pair<int, int>, std::unique_ptr<LtsdPlan>> PlanMap;
+    PlanMap *plans = &per_device<PlanMap>();                               // leaked on purpose
     auto key = std::make_pair(ctx().device, N);
     auto it = plans->find(key);
     if (it != plans->end()) return *it->second;
@@ -167,10 +167,7 @@ struct LtsdWork {
     DevBuf<float> amp, ltsd, inv_noise;
     DevBuf<int64_t> d_win_off;
 };
-static LtsdWork &lwork() {
-    static LtsdWork *w = new LtsdWork();
-    return *w;
-}
+static LtsdWork &lwork() { return per_device<LtsdWork>(); }
 
 // amplitude spectra of every window of every utterance -> device [n_windows][NB]; fills win_off [U+1]
 static int64_t ltsd_amplitudes(SRBatch &pcm, int N, std::vector<int64_t> &win_off) {

@@ -674,7 +674,8 @@ struct MfccDeviceTables {
 };
 
 static MfccDev upload_tables(SRMfcc &m) {
-    if (!m.dev) {
+    std::shared_ptr<void> &slot = m.dev[current_device()];
+    if (!slot) {
         auto t = std::make_shared<MfccDeviceTables>();
         const int L = m.frame_len, NF = m.fft_size, nc = NF / 2, B = m.n_filters, C = m.n_ceps;
         std::vector<float> w(L), dctf((size_t)C * B), val, floor_ln(B);
@@ -754,9 +755,9 @@ static MfccDev upload_tables(SRMfcc &m) {
         t->mel_cnt.upload(cnt.data(), cnt.size());
         t->nnz = (int)col.size();
         sync_stream();
-        m.dev = t;
+        slot = t;
     }
-    auto &t = *std::static_pointer_cast<MfccDeviceTables>(m.dev);
+    auto &t = *std::static_pointer_cast<MfccDeviceTables>(slot);
     MfccDev d;
     d.window = t.window.p;
     d.twiddle = t.twiddle.p;
@@ -797,15 +798,14 @@ struct MfccWorkspace {
     DevBuf<int64_t> raw_off;
     std::vector<int64_t> raw_off_host;   // what raw_off currently holds (skip the upload + sync when unchanged)
 };
-static MfccWorkspace &mws() {
-    static MfccWorkspace *w = new MfccWorkspace();   // leaked on purpose: no hipFree at exit
-    return *w;
-}
+static MfccWorkspace &mws() { return per_device<MfccWorkspace>(); }   // leaked on purpose: no hipFree at exit
 
 // PCM batch -> feature batch.  `out` is reused when it is large enough (serving loop).
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out) {
     ensure_device();
     if (pcm.kind != SRBatch::PCM16 && pcm.kind != SRBatch::PCMF32) fail("MFCC needs a PCM batch");
+    pcm.bind_device();
+    out.bind_device();
     if (nd < 0 || nd > 2) fail("delta order must be 0, 1 or 2");
     if (m.n_lpc > 0 && nd != 0) fail("LPC columns (mix_feature) come without deltas: use nd = 0");
     const MfccDev dev = upload_tables(m);
@@ -841,7 +841,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
     }
 
     if (NF > 0) {
-        auto &tabs = *std::static_pointer_cast<MfccDeviceTables>(m.dev);
+        auto &tabs = *std::static_pointer_cast<MfccDeviceTables>(m.dev[current_device()]);
         const bool fast = m.fft_size == 2048 && tabs.runs_contiguous && m.n_ceps <= 16 && !mfcc_force_generic();
         ScopedKernelTimer t(T_MFCC);
         if (fast) {

@@ -16,8 +16,8 @@ struct SRMfcc {
     std::vector<double> window;    // [frame_len]
     std::vector<double> melbank;   // [n_filters][fft_size/2+1]
     std::vector<double> dct;       // [n_ceps][n_filters]  (DCT-II rows 1..n_ceps)
-    std::shared_ptr<void> dev;     // device tables, created on first use
-    std::shared_ptr<void> dev_window_f64;   // float64 window for the LPC kernel
+    std::shared_ptr<void> dev[sr::MAX_DEVICES];              // device tables, created on first use on each device
+    std::shared_ptr<void> dev_window_f64[sr::MAX_DEVICES];   // float64 window for the LPC kernel
     int n_lpc = 0;                 // > 0: append LPC columns (mix_feature, feature/__init__.py:25-30)
     SRMfcc(double fs, double win_length_ms, double win_shift_ms, int fft_size, int n_filters,
            int n_ceps, double pre_emph);

@@ -28,6 +28,7 @@ struct SRStream {
         int16_t *h_pcm = nullptr;        // pinned
         double *h_sums = nullptr;        // pinned [n_windows][S]
         int *h_argmax = nullptr;         // pinned [n_windows]
+        int *h_oor = nullptr;            // pinned: the fp16 engines' saturation flag of this tick
         SRBatch pcm, feat;
         hipEvent_t h2d_done = nullptr, done = nullptr, t_submit = nullptr;
         hipGraphExec_t exec = nullptr;   // SR_STREAM_GRAPH: the captured tick
@@ -36,6 +37,7 @@ struct SRStream {
     } slot[2];
     std::deque<int> in_flight;           // slot indices, oldest first
     long submitted = 0;
+    int device = 0;                      // the GPU the session lives on
 };
 
 using namespace sr;
@@ -48,6 +50,7 @@ void stream_destroy(SRStream *s) {
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.h_sums) (void)hipHostFree(sl.h_sums);
         if (sl.h_argmax) (void)hipHostFree(sl.h_argmax);
+        if (sl.h_oor) (void)hipHostFree(sl.h_oor);
         if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
         if (sl.done) (void)hipEventDestroy(sl.done);
         if (sl.t_submit) (void)hipEventDestroy(sl.t_submit);
@@ -61,7 +64,9 @@ void stream_destroy(SRStream *s) {
 // pinned buffers.  Launches only (every table is cached after the first pass over this shape).
 void enqueue_tick(SRStream *s, SRStream::Slot &sl) {
     mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);
-    const ScoreResult r = score_device(*s->set, sl.feat, false, (s->flags & 0xff) | SCORE_PRECISE);
+    const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags & 0xff);
+    sl.h_oor[0] = 0;
+    if (r.d_oor) SR_HIP(hipMemcpyAsync(sl.h_oor, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
     SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
                           hipMemcpyDeviceToHost, ctx().stream));
     SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
@@ -110,7 +115,11 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
         ensure_device();
         if (!m || !set || n_windows <= 0 || window_samples <= 0) fail("bad arguments to sr_stream_create");
         if (mfcc_num_frames(*m, window_samples) - nd <= 0) fail("window of %lld samples yields no frames", (long long)window_samples);
-        auto *s = new SRStream();
+        // owned by a guard until every step below has succeeded (pinned buffers, events and the
+        // copy stream are released by stream_destroy on any failure)
+        std::unique_ptr<SRStream, void (*)(SRStream *)> guard(new SRStream(), stream_destroy);
+        SRStream *s = guard.get();
+        s->device = current_device();
         s->mfcc = m;
         s->set = set;
         s->n_windows = n_windows;
@@ -124,9 +133,12 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_pcm), n_samp * sizeof(int16_t), hipHostMallocDefault));
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_sums), (size_t)n_windows * s->n_models * sizeof(double), hipHostMallocDefault));
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_argmax), (size_t)n_windows * sizeof(int), hipHostMallocDefault));
+            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_oor), sizeof(int), hipHostMallocDefault));
+            sl.h_oor[0] = 0;
             SR_HIP(hipEventCreate(&sl.h2d_done));
             SR_HIP(hipEventCreate(&sl.done));
             SR_HIP(hipEventCreate(&sl.t_submit));
+            sl.pcm.bind_device();
             sl.pcm.kind = SRBatch::PCM16;
             sl.pcm.n_utt = n_windows;
             sl.pcm.n_rows = (int64_t)n_samp;
@@ -139,10 +151,10 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
             // one synchronous pass per slot builds every table / workspace for this shape, so the
             // steady state launches kernels only
             mfcc_extract_batch(*m, sl.pcm, nd, 1, sl.feat);
-            (void)score_device(*set, sl.feat, false, (flags & 0xff) | SCORE_PRECISE);
+            (void)score_device(*set, sl.feat, false, flags & 0xff);
             sync_stream();
         }
-        return s;
+        return guard.release();
     } catch (const std::exception &e) {
         set_error("%s", e.what());
         return nullptr;
@@ -150,14 +162,25 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
 }
 
 void sr_stream_free(SRStream *s) {
-    if (s) (void)hipDeviceSynchronize();
-    stream_destroy(s);
+    if (!s) return;
+    const int prev = current_device();
+    try {
+        set_thread_device(s->device);
+        std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());   // no submit / collect of another thread in between
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+        stream_destroy(s);
+        set_thread_device(prev);
+    } catch (...) {
+    }
 }
 
 int sr_stream_submit(SRStream *s, const int16_t *pcm) {
     try {
         std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         if (!s || !pcm) fail("null argument");
+        if (s->device != current_device()) fail("stream lives on device %d, the calling thread is on device %d", s->device, current_device());
+        ensure_device();
         if (s->in_flight.size() >= 2) fail("two ticks already in flight: collect one first");
         const int k = (int)(s->submitted & 1);
         auto &sl = s->slot[k];
@@ -193,11 +216,20 @@ int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *de
     try {
         std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
         if (!s) fail("null stream");
+        if (s->device != current_device()) fail("stream lives on device %d, the calling thread is on device %d", s->device, current_device());
+        ensure_device();
         if (s->in_flight.empty()) fail("nothing in flight");
         const int k = s->in_flight.front();
         s->in_flight.pop_front();
         auto &sl = s->slot[k];
         SR_HIP(hipEventSynchronize(sl.done));
+        if (sl.h_oor[0] != 0) {
+            // a frame of this tick left the fp16 engine's range: its features are still in the slot --
+            // score them again, synchronously, on the fp32-grade engines
+            const ScoreResult r = score_device(*s->set, sl.feat, false, (s->flags & 0xff) | SCORE_PRECISE);
+            fetch_results(r, (size_t)s->n_windows, (size_t)s->n_models, (size_t)sl.feat.n_rows, sl.h_sums, sl.h_argmax, nullptr);
+            sl.h_oor[0] = 0;
+        }
         if (sums_out) std::memcpy(sums_out, sl.h_sums, (size_t)s->n_windows * s->n_models * sizeof(double));
         if (argmax_out) std::memcpy(argmax_out, sl.h_argmax, (size_t)s->n_windows * sizeof(int));
         if (device_ms) {

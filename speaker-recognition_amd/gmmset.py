@@ -23,7 +23,8 @@ class GMMSet(object):
         # speakers adapted from a UBM inherit its size (gmmset.py:24-27)
         self.gmm_order = gmm_order if ubm is None else ubm.get_nr_mixtures()
         self.gmms, self.y = [], []
-        self._set = None            # packed device copy of self.gmms, rebuilt when the list changes
+        self._set = None
+        self._set_key = None            # packed device copy of self.gmms, rebuilt when the list changes
 
     # ---- enrolment ----
     def _append(self, label, gmm):
@@ -61,8 +62,12 @@ class GMMSet(object):
 
     # ---- scoring ----
     def _model_set(self):
-        if self._set is None or len(self._set) != len(self.gmms):
+        # the packed device copy is valid for exactly these model objects in this state: refitting
+        # a model in place, replacing an element or reloading one must not leave a stale copy
+        key = tuple((id(g), getattr(g, "_version", 0)) for g in self.gmms)
+        if self._set is None or self._set_key != key:
             self._set = ModelSet(self.gmms)
+            self._set_key = key
         return self._set
 
     def gmm_score(self, gmm, x):

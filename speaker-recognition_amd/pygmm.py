@@ -51,7 +51,11 @@ class GMM(object):
         return g
 
     def dump(self, model_file):
-        lib().dump(self.gmm, str(model_file).encode())
+        # through dumps(): the legacy `dump` symbol returns void (pygmm.hh:32), so a failed write
+        # would only reach stderr; here it raises
+        text = self.dumps()
+        with open(str(model_file), "w") as f:
+            f.write(text)
 
     def dumps(self):
         need = C.c_long(0)
@@ -108,6 +112,7 @@ class GMM(object):
                                     X.shape[0], X.shape[1], C.byref(p), int(self.seed))
         check(n_iter, "train")
         self.nr_mixture = lib().get_nr_mixtures(self.gmm)
+        self._version = getattr(self, "_version", 0) + 1      # invalidates packed copies (GMMSet._model_set)
         return n_iter
 
     # ---- scoring (pygmm.py:120-132) ----
@@ -151,6 +156,9 @@ class GMM(object):
         text = st.pop("gmm")
         self.__dict__.update(st)
         if text is None:
-            self.gmm = C.c_void_p(lib().new_gmm(int(self.nr_mixture), int(self.covariance_type)))
+            h = lib().new_gmm(int(self.nr_mixture), int(self.covariance_type))
         else:
-            self.gmm = C.c_void_p(lib().sr_gmm_loads(text.encode()))
+            h = lib().sr_gmm_loads(text.encode())
+        if not h:
+            raise SRError("cannot restore a pickled GMM: %s" % _lib.last_error())
+        self.gmm = C.c_void_p(h)

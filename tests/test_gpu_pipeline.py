@@ -236,3 +236,36 @@ def test_plain_c_host_example(built_lib, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("-> speaker") == 3 and "kernel:" in r.stdout
+
+
+def test_multi_slot_prediction_equals_single_device(built_lib):
+    """One host process, several slots (a host thread + stream per device, models
+    replicated, utterances dealt by length, rows gathered on the host).  On a single-GPU box the
+    surplus slots share device 0 -- the threading, partitioning and gather are the same code -- so
+    1, 2 and 3 slots must all reproduce the single-device fused step bit for bit (an utterance's
+    results do not depend on its batch), whatever the utterance lengths (incl. too-short ones)."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, MultiPredictor
+    from speaker_recognition_amd.pygmm import GMM
+    kw = dict(win_length_ms=25, win_shift_ms=10)
+    models = [GMM.from_arrays(*synth.synth_gmm(64, 39, 7 + s)) for s in range(5)]
+    rng = np.random.default_rng(5)
+    secs = [1.0, 0.4, 2.5, 0.05, 1.7, 0.9, 3.1, 0.6, 1.2]          # 0.05 s: too short for any frame
+    sigs = [synth.synth_speech(int(rng.integers(0, 30)), s, 16000, seed=100 + i) for i, s in enumerate(secs)]
+    ex = MfccExtractor(16000, **kw)
+    want_sums, want_arg = ex.predict_batch(ModelSet(models), Batch.from_pcm(sigs), nd=2)
+    for n_slots in (1, 2, 3):
+        mp = MultiPredictor(models, 16000, n_slots=n_slots, **kw)
+        assert mp.n_slots == n_slots and all(0 <= d < _lib.device_count() for d in mp.slot_devices())
+        sums, arg = mp.predict(sigs, nd=2)
+        assert np.array_equal(arg, want_arg), n_slots
+        assert np.array_equal(sums, want_sums), n_slots
+        assert mp.slot_seconds.shape == (n_slots,) and np.all(mp.slot_seconds > 0)
+    # handles are bound to their device: a thread parked on another device index is refused
+    if _lib.device_count() == 1:
+        _lib.set_thread_device(1)
+        try:
+            with pytest.raises(_lib.SRError):
+                Batch.from_pcm(sigs)                 # device 1 does not exist on this box
+        finally:
+            _lib.set_thread_device(0)
