@@ -90,14 +90,41 @@ static std::vector<float> rows_to_f32(double **X, long n, int dim) {
     return out;
 }
 
+// The legacy ABI scores ONE model per call, and its callers loop over the speakers with the same
+// utterance (gmmset.py:59-64, :95-99: S calls of score_all(x)): re-uploading x S times would make
+// the drop-in path pay S H2D copies and S tile-table builds.  The last uploaded matrix stays on the
+// device, keyed by shape and a 64-bit FNV-1a hash of its fp32 contents (~0.1 ms per MB on the host).
+struct LegacyFeatureCache {
+    uint64_t hash = 0;
+    long n = -1;
+    int dim = -1;
+    std::unique_ptr<SRBatch> batch;
+};
+
+static uint64_t fnv1a(const void *p, size_t bytes) {
+    const uint64_t *w = static_cast<const uint64_t *>(p);
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < bytes / 8; i++) h = (h ^ w[i]) * 1099511628211ull;
+    const unsigned char *c = static_cast<const unsigned char *>(p) + (bytes & ~(size_t)7);
+    for (size_t i = 0; i < (bytes & 7); i++) h = (h ^ c[i]) * 1099511628211ull;
+    return h;
+}
+
 static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out,
                       int flags) {
     SRModelSet &set = single_set(g);
     if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
-    const int64_t off[2] = {0, n};
-    auto b = feature_batch(X, n, dim, off, 1);
+    auto &cache = per_device<LegacyFeatureCache>();
+    const uint64_t h = fnv1a(X, (size_t)n * dim * sizeof(float));
+    if (!cache.batch || cache.n != n || cache.dim != dim || cache.hash != h) {
+        const int64_t off[2] = {0, n};
+        cache.batch = feature_batch(X, n, dim, off, 1);
+        cache.n = n;
+        cache.dim = dim;
+        cache.hash = h;
+    }
     double sum = 0.0;
-    score_batch_set(set, *b, &sum, nullptr, ll_out, flags);
+    score_batch_set(set, *cache.batch, &sum, nullptr, ll_out, flags);
     if (sum_out) *sum_out = sum;
 }
 

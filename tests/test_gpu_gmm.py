@@ -541,3 +541,36 @@ def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):
         s4, a4, f4 = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
         assert np.array_equal(a4, arg)
         assert np.max(np.abs(f4 - fll) / np.maximum(1.0, np.abs(want))) < 1e-5
+
+
+def test_cfg3_shape_k2048_map_speakers_vs_oracle(built_lib, oracle_built):
+    """BASELINE configs[3]'s model shape at a size the oracle can follow: a 2048-mixture UBM + 44 MAP
+    speakers (45 models = three full blocks of the shared-sigma engines), 39-dim, ragged utterances with
+    clamped outliers: per-frame LL of EVERY model against the oracle for the default engine (split-fp16
+    shared-sigma), its exception pass alone, and the split-bf16 shared-sigma engine; sums and argmax too."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    K, D, S = 2048, 39, 44
+    ubm = synth.synth_gmm(K, D, 99)
+    models = [ubm] + [synth.synth_map_speaker(ubm, 500 + s) for s in range(S)]
+    lens = [130, 64, 1, 257]
+    utts = [synth.draw_frames(models[1 + (7 * u) % S], n, 3000 + u, outlier_frac=0.01) for u, n in enumerate(lens)]
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+    off = np.concatenate([[0], np.cumsum(lens)])
+    gm = [GMM.from_arrays(*m) for m in models]
+    ms = ModelSet(gm)
+    _lib.set_option("score_engine", 4)      # sets of more than 65536 mixtures pack only the layout in force at creation
+    ms4 = ModelSet(gm)
+    for eng, force in ((0, 0), (6, 1), (4, 0)):
+        _lib.set_option("score_engine", eng)
+        _lib.set_option("score_h2s_force_exc", force)
+        sums, arg, fll = (ms4 if eng == 4 else ms).score(Batch.from_features(utts), frame_ll=True)
+        assert ("h2s" in _lib.last_score_kernel()) == (eng != 4)
+        assert ll_close(fll, want) < TOL, (eng, force, ll_close(fll, want))
+        for u, n in enumerate(lens):
+            w = want[:, off[u]:off[u + 1]].sum(axis=1)
+            assert np.max(np.abs(sums[u] - w) / np.abs(w)) < 2e-5, (eng, u)
+            assert arg[u] == int(np.argmax(w)), (eng, u)

@@ -269,3 +269,41 @@ def test_multi_slot_prediction_equals_single_device(built_lib):
                 Batch.from_pcm(sigs)                 # device 1 does not exist on this box
         finally:
             _lib.set_thread_device(0)
+
+
+def test_cfg0_at_stated_size_cli_vs_cpu_restatement(built_lib, tmp_path):
+    """BASELINE configs[0] at its stated size: 10 speakers x 30 s of 16 kHz mono WAV to enroll, another
+    10 x 30 s to predict, 25 ms / 10 ms frames (2998 frames per file), 13 MFCC, a 16-mixture diagonal GMM
+    per speaker, through speaker-recognition.py's enroll / predict tasks.  Every clip is recognised, and
+    with the SAME trained models the CPU restatement (float64 MFCC.py port + the C restatement of the
+    reference's scorer) takes every decision the same way with per-utterance scores within 2e-3."""
+    from oracle import gmm_oracle as go, mfcc_oracle as mo
+    from speaker_recognition_amd import cli, synth
+    from speaker_recognition_amd.interface import ModelInterface
+    fs = 16000
+    spk = [3 * i for i in range(10)]
+    for s in spk:
+        d = tmp_path / ("spk%d" % s)
+        d.mkdir()
+        wavfile.write(str(d / "enroll.wav"), fs, synth.synth_speech(s, 30.0, fs, seed=1000 + s))
+        wavfile.write(str(tmp_path / ("test_spk%d.wav" % s)), fs, synth.synth_speech(s, 30.0, fs, seed=2000 + s))
+    model = str(tmp_path / "model.out")
+    cli.main(["-t", "enroll", "-i", str(tmp_path / "spk*"), "-m", model, "--mixtures", "16",
+              "--win-length-ms", "25", "--win-shift-ms", "10", "--seed", "3", "--no-lpc"])
+    args = cli.get_args(["-t", "predict", "-i", str(tmp_path / "test_*.wav"), "-m", model])
+    res = cli.task_predict(args.input, args.model)
+    assert len(res) == 10
+    for f, label in res:
+        assert os.path.basename(f).replace("test_", "").replace(".wav", "") == label
+    m = ModelInterface.load(model)
+    kw = dict(win_length_ms=25, win_shift_ms=10)
+    params = [go.GMMParams(*g.params()) for g in m.gmmset.gmms]
+    assert all(p.K == 16 and p.D == 13 for p in params)
+    for f, label in res:
+        _, sig = wavfile.read(f)
+        feat = mo.extract(fs, sig, **kw)
+        assert feat.shape == (2998, 13)                     # SURVEY.md 8: T = 2998
+        scores = [go.score_all(p, feat) / len(feat) for p in params]
+        assert m.gmmset.y[int(np.argmax(scores))] == label
+        dev = np.array(m.gmmset.predict_one_scores(m._features(fs, sig))) / len(feat)
+        assert np.max(np.abs(dev - np.array(scores)) / np.abs(scores)) < 2e-3
