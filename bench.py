@@ -227,17 +227,24 @@ def block_cfg1(_lib, ex, base, hbm, preq):
     n_frames = CFG1_UTTS * FRAMES_PER_UTT
     step = lambda: ex.predict_batch(ms, pcm, nd=ND)
     step(); step()
-    _lib.profile_reset()
     _lib.synchronize()
+    _lib.profile_reset()
     el, (sums, arg) = timed(step, 0, 10, _lib.synchronize)
     kt = kernel_times(_lib, 10)
+    _lib.set_option("predict_chunks", 4)
+    step()
+    el4, _ = timed(step, 0, 10, _lib.synchronize)                   # the pipelining option, for the record
+    _lib.set_option("predict_chunks", 0)
     kname = _lib.last_score_kernel()
     # parity sample (checked by the oracle subprocess): 2 utterances x 6 models on the device's own features
     fb = ex.extract_batch(Batch.from_pcm([cat[off[u]:off[u + 1]] for u in (0, 1)]), nd=ND)
     preq["configs[1]"] = {"models": raw[:6], "X": fb.download().astype(np.float64), "offsets": fb.offsets(),
                           "device_sums": sums[:2, :6]}
     return {"workload": "BASELINE.json configs[1]: 39-dim MFCC+delta+delta-delta, 100 speaker GMMs x 64 mixtures, %d utterances x %d frames" % (CFG1_UTTS, FRAMES_PER_UTT),
-            "frames_per_s": n_frames * 10 / el, "ms_per_step": 1e3 * el / 10, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
+            "frames_per_s": n_frames * 10 / el, "ms_per_step": 1e3 * el / 10,
+            "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
+            "sum_of_kernels_ms": sum(v["ms_per_step"] for v in kt.values()),
+            "ms_per_step_with_predict_chunks_4": 1e3 * el4 / 10,
             "roofline": score_roofline(kname, n_frames, CFG1_MODELS, CFG1_MIX, DIM, kt["gmm_score"]["ms_per_step"] * 1e-3, hbm),
             "mfcc_roofline": mfcc_roofline(CFG1_UTTS * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
             "parity": None}
@@ -482,7 +489,16 @@ def main():
     kt = kernel_times(_lib, args.steps)
     kname = _lib.last_score_kernel()
     hbm = _lib.hbm_copy_gbps(1 << 30, 10)
-    score_s = (kt["gmm_score"]["ms_per_step"] + kt["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
+    # the same step WITH the feature/scoring pipelining (8 chunks of utterances, feature kernels of chunk i+1.. on a
+    # second stream under the scoring of chunk i): an option, off by default because it measures slower
+    kt1 = kt
+    _lib.set_option("predict_chunks", 8)
+    step()
+    _lib.profile_reset()
+    el8, _ = timed(step, 0, 2, _lib.synchronize)
+    kt8 = kernel_times(_lib, 2)
+    _lib.set_option("predict_chunks", 0)
+    score_s = (kt1["gmm_score"]["ms_per_step"] + kt1["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
     result = {
         "metric": "frames/sec scored (MFCC+GMM)",
         "value": world * n_frames * args.steps / elapsed,
@@ -507,8 +523,14 @@ def main():
         "rank_frames_per_s": rates,
         "scaling_efficiency_vs_rank0_alone": None,
         "roofline": score_roofline(kname, n_frames, S, CFG2_MIX, DIM, score_s, hbm),
-        "mfcc_roofline": mfcc_roofline(args.utts * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
+        "mfcc_roofline": mfcc_roofline(args.utts * (FRAMES_PER_UTT + ND), kt1["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
         "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
+        "kernel_launches_per_step": {k: v["launches"] / max(1, args.steps) for k, v in kt.items()},
+        "sum_of_kernels_ms": sum(v["ms_per_step"] for v in kt.values()),
+        "pipelined_option": {"predict_chunks": 8, "ms_per_step": 1e3 * el8 / 2, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt8.items()},
+                             "note": "feature kernels of chunk i+1.. on a second stream under the scoring of chunk i (sr_set_option "
+                                     "predict_chunks): built for overlap, measures slower than one pass (the feature kernels starve next to "
+                                     "the scoring kernel), so it is off by default"},
         "hbm_copy_ceiling_GBps": hbm,
         "device": _lib.device_name(),
         "model_set": ms.info(),

@@ -86,9 +86,14 @@ void ensure_device() {
     SR_HIP(hipGetDeviceProperties(&prop, d));
     g_ctx[d].device = d;
     g_ctx[d].n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].stream, hipStreamNonBlocking));
+    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].main, hipStreamNonBlocking));
+    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].aux, hipStreamNonBlocking));
+    g_ctx[d].stream = g_ctx[d].main;
     g_ready[d] = true;
 }
+
+StreamScope::StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s; }
+StreamScope::~StreamScope() { ctx().stream = saved; }
 
 void *per_device_slot(void **slots, void *(*make)()) {
     static std::mutex mu;
@@ -158,7 +163,8 @@ void profile_prewarm() {
 void profile_collect() {
     auto &t = ts();
     if (t.pending.empty()) return;
-    SR_HIP(hipStreamSynchronize(ctx().stream));
+    SR_HIP(hipStreamSynchronize(ctx().main));
+    SR_HIP(hipStreamSynchronize(ctx().aux));
     for (auto &p : t.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {

@@ -54,12 +54,21 @@ std::recursive_mutex &api_mutex();       // of the calling thread's current devi
 // first call that needs the device). ----
 struct Ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where launches go (normally `main`; StreamScope redirects)
+    hipStream_t main = nullptr, aux = nullptr;
     bool profiling = false;
     int n_cu = 256;
 };
 Ctx &ctx();             // of the calling thread's current device
 void ensure_device();   // hipSetDevice(current) for THIS thread + lazy stream; throws sr::Error when no usable GPU
+
+// Redirects the calling thread's device launches to another stream of the same device for a scope
+// (the feature stage of the pipelined predict path runs on `aux` under the scoring of `main`).
+struct StreamScope {
+    hipStream_t saved;
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
+};
 
 // Lazily constructed per-device singleton (workspaces); leaked on purpose: no hipFree at exit.
 void *per_device_slot(void **slots, void *(*make)());

@@ -798,26 +798,36 @@ struct MfccWorkspace {
     DevBuf<int64_t> raw_off;
     std::vector<int64_t> raw_off_host;   // what raw_off currently holds (skip the upload + sync when unchanged)
 };
-static MfccWorkspace &mws() { return per_device<MfccWorkspace>(); }   // leaked on purpose: no hipFree at exit
+struct MfccWorkspaces {
+    MfccWorkspace slot[MFCC_SLOTS];
+};
+static MfccWorkspace &mws(int slot) { return per_device<MfccWorkspaces>().slot[slot]; }   // leaked on purpose: no hipFree at exit
 
 // PCM batch -> feature batch.  `out` is reused when it is large enough (serving loop).
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out) {
+    mfcc_extract_range(m, pcm, 0, pcm.n_utt, nd, cmvn, out, 0);
+}
+
+void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmvn, SRBatch &out, int slot) {
     ensure_device();
+    if (u0 < 0 || u1 > pcm.n_utt || u0 > u1 || slot < 0 || slot >= MFCC_SLOTS) fail("bad utterance range");
     if (pcm.kind != SRBatch::PCM16 && pcm.kind != SRBatch::PCMF32) fail("MFCC needs a PCM batch");
     pcm.bind_device();
     out.bind_device();
     if (nd < 0 || nd > 2) fail("delta order must be 0, 1 or 2");
     if (m.n_lpc > 0 && nd != 0) fail("LPC columns (mix_feature) come without deltas: use nd = 0");
     const MfccDev dev = upload_tables(m);
-    const int U = pcm.n_utt;
+    const int U = u1 - u0;
+    if (m.n_lpc > 0 && (u0 != 0 || u1 != pcm.n_utt)) fail("LPC columns need the whole batch");
+    const int64_t *d_pcm_off = pcm.d_offsets.p + u0;      // offsets stay absolute into the PCM buffer
     std::vector<int64_t> raw_off(U + 1, 0), out_off(U + 1, 0);
     for (int u = 0; u < U; u++) {
-        const int64_t T = mfcc_num_frames(m, pcm.offsets[u + 1] - pcm.offsets[u]);
+        const int64_t T = mfcc_num_frames(m, pcm.offsets[u0 + u + 1] - pcm.offsets[u0 + u]);
         raw_off[u + 1] = raw_off[u] + T;
         out_off[u + 1] = out_off[u] + std::max<int64_t>(0, T - nd);
     }
     const int64_t NF = raw_off[U];
-    auto &w = mws();
+    auto &w = mws(slot);
     w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
     bool uploaded = false;
     if (w.raw_off_host != raw_off) {
@@ -888,7 +898,7 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
         auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV, W>;                                      \
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, ctx().stream, PCMPTR, pcm.d_offsets.p, \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, ctx().stream, PCMPTR, d_pcm_off, \
                            w.raw_off.p, U, NF, frames_per_wave, dev, mr, w.raw.p);                   \
     } while (0)
             if (pcm.kind == SRBatch::PCM16) {
@@ -910,13 +920,13 @@ void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out)
                 SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.pcm16.p,
-                                   pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+                                   d_pcm_off, w.raw_off.p, U, NF, dev, w.raw.p);
             } else {
                 auto kern = mfcc_frames_kernel<float>;
                 SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx().stream, pcm.data.p,
-                                   pcm.d_offsets.p, w.raw_off.p, U, NF, dev, w.raw.p);
+                                   d_pcm_off, w.raw_off.p, U, NF, dev, w.raw.p);
             }
         }
         SR_HIP(hipGetLastError());

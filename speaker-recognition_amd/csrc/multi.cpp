@@ -90,14 +90,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         sync_stream();
         s.sums.assign((size_t)U * m->n_models, 0.0);
         s.argmax.assign((size_t)U, -1);
-        if (U > 0) {
-            mfcc_extract_batch(*m->mfcc, b, nd, 1, *s.feat);
-            ScoreResult r = score_device(*s.set, *s.feat, false, flags);
-            if (!fetch_results(r, (size_t)U, (size_t)m->n_models, (size_t)s.feat->n_rows, s.sums.data(), s.argmax.data(), nullptr)) {
-                r = score_device(*s.set, *s.feat, false, flags | SCORE_PRECISE);
-                fetch_results(r, (size_t)U, (size_t)m->n_models, (size_t)s.feat->n_rows, s.sums.data(), s.argmax.data(), nullptr);
-            }
-        }
+        if (U > 0) predict_pcm(m->mfcc.get(), s.set.get(), &b, nd, s.sums.data(), s.argmax.data(), flags);
         s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } catch (const std::exception &e) {
         s.error = e.what();

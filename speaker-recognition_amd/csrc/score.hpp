@@ -108,6 +108,12 @@ void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argm
 // with SCORE_PRECISE).
 bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
                    int *argmax_out, float *frame_ll_out);
+// PCM batch -> MFCC -> CMVN/deltas -> all models -> sums + argmax on the host (abi.cpp; pipelined over
+// chunks of utterances for large batches).
+}  // namespace sr
+struct SRMfcc;
+namespace sr {
+void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out, int *argmax_out, int flags);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);
 // Packs the layouts a set needs (all of them for small sets; for large ones the vector layout plus
