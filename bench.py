@@ -492,12 +492,14 @@ def main():
     # the same step WITH the feature/scoring pipelining (8 chunks of utterances, feature kernels of chunk i+1.. on a
     # second stream under the scoring of chunk i): an option, off by default because it measures slower
     kt1 = kt
-    _lib.set_option("predict_chunks", 8)
-    step()
-    _lib.profile_reset()
-    el8, _ = timed(step, 0, 2, _lib.synchronize)
-    kt8 = kernel_times(_lib, 2)
-    _lib.set_option("predict_chunks", 0)
+    el8, kt8 = None, None
+    if not args.no_config_blocks:
+        _lib.set_option("predict_chunks", 8)
+        step()
+        _lib.profile_reset()
+        el8, _ = timed(step, 0, 2, _lib.synchronize)
+        kt8 = kernel_times(_lib, 2)
+        _lib.set_option("predict_chunks", 0)
     score_s = (kt1["gmm_score"]["ms_per_step"] + kt1["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
     result = {
         "metric": "frames/sec scored (MFCC+GMM)",
@@ -527,7 +529,7 @@ def main():
         "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
         "kernel_launches_per_step": {k: v["launches"] / max(1, args.steps) for k, v in kt.items()},
         "sum_of_kernels_ms": sum(v["ms_per_step"] for v in kt.values()),
-        "pipelined_option": {"predict_chunks": 8, "ms_per_step": 1e3 * el8 / 2, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt8.items()},
+        "pipelined_option": None if kt8 is None else {"predict_chunks": 8, "ms_per_step": 1e3 * el8 / 2, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt8.items()},
                              "note": "feature kernels of chunk i+1.. on a second stream under the scoring of chunk i (sr_set_option "
                                      "predict_chunks): built for overlap, measures slower than one pass (the feature kernels starve next to "
                                      "the scoring kernel), so it is off by default"},

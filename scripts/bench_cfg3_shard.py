@@ -24,6 +24,7 @@ def main():
     D, T = 39, 1000
     _lib.set_option("score_engine", int(os.environ.get("CFG3_ENGINE", 0)))   # before the set is packed
     _lib.set_option("score_h2s_force_exc", int(os.environ.get("CFG3_FORCE_EXC", 0)))
+    _lib.set_option("score_h2s_tiles_per_launch", int(os.environ.get("CFG3_TPL", 0)))
     t0 = time.time()
     ubm = synth.synth_gmm(K, D, 99)
     w, mean, sigma = ubm
@@ -41,7 +42,7 @@ def main():
     t_setup = time.time() - t0
     _lib.profile_enable(True)
     times = []
-    for r in range(2):
+    for r in range(int(os.environ.get("CFG3_ROUNDS", 2))):
         _lib.profile_reset()
         t1 = time.time()
         sums, arg = ms.score(feats)

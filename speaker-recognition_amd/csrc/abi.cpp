@@ -729,6 +729,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "predict_chunks") {
         if (value < 0 || value > PredictPipe::MAX_CHUNKS) fail("predict_chunks must be 0 (automatic) .. %d", PredictPipe::MAX_CHUNKS);
         predict_chunks_option() = (int)value;
+    } else if (k == "score_h2s_tiles_per_launch") {
+        if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
+        score_options().h2s_tiles_per_launch = (int)((value + 7) / 8 * 8);
     } else if (k == "score_h2s_force_exc") {
         score_options().h2s_force_exc = value != 0;
     } else if (k == "score_mfma_ft") {

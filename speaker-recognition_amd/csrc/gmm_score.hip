@@ -618,6 +618,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_tiles = tt.n_tiles;
             a.log2_k = (float)std::log2((double)h.n_tiles * MT);
             a.force_exc = opt.h2s_force_exc;
+            a.tiles_per_launch = opt.h2s_tiles_per_launch;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_h2s_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
                      "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf, SHARED_SB);

@@ -36,6 +36,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int H2S_G = 2;                         // images per LDS stage (one barrier per stage)
+constexpr int H2S_ROUNDS_PER_LAUNCH = 12;
+#ifndef H2S_CHAIN_PRIO
+#define H2S_CHAIN_PRIO 0
+#endif
 constexpr float H2S_SUM_LO = 7.8886090522101181e-31f;    // 2^-100
 constexpr float H2S_SUM_HI = 1.2676506002282294e+30f;    // 2^100
 constexpr float H2S_LOG2E = 1.4426950408889634f;
@@ -110,6 +114,7 @@ struct H2sArgs {
     int exc_cap;
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
+    int tile_base;                // first frame tile of this launch (long grids are cut into several launches)
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
 };
@@ -176,7 +181,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
             const int tile_lo = work & 7;          // XCD-aware order, as gmm_score_kernel
             const int q = work >> 3;
             const int g = q % a.n_groups;
-            tile_id = (q / a.n_groups) * 8 + tile_lo;
+            tile_id = a.tile_base + (q / a.n_groups) * 8 + tile_lo;
             if (tile_id >= a.n_tiles) return;
             blk_begin = a.group_block_begin[g];
             blk_end = a.group_block_begin[g + 1];
@@ -199,6 +204,13 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
 
         const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // Every workgroup streams the same parameter images from L2, and the 4 MiB L2 of an XCD cannot hold
+        // the whole stream: the workgroups of an XCD hit in L2 only while they sweep in phase.  They do for
+        // the first ~30 rounds of a launch (all start at block 0 together: 3 % L2 misses on 3 M frames), then
+        // the start times drift apart (42 % misses = 1.1 TB of fabric reads over 10 M frames).  Steering the
+        // starting block by a shared hint or by the clock made it WORSE (44 % at 3 M frames: a workgroup that
+        // starts mid-sweep is out of phase with everyone who started at 0), so long grids are simply cut into
+        // launches of H2S_ROUNDS_PER_LAUNCH rounds, each of which starts in phase (launch_h2s).
         for (int blk = blk_begin; blk < blk_end; blk++) {
             const SharedBlock sb = a.blocks[blk];
             const uint4 *stream = a.params + sb.offset_u4;
@@ -275,10 +287,14 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                         for (int gi = 0; gi < G; gi++) {
                             const int img = st * G + gi;
                             f32x16 acc;
+                            // the matrix pipe must never wait for an issue slot: a wave in its chain outranks
+                            // the waves in their (vector-ALU) epilogues
+                            __builtin_amdgcn_s_setprio(H2S_CHAIN_PRIO);
                             if (img == 0)
                                 h2s_chain_regs<KQF>(qacc, zero16, fr, bq);
                             else
                                 h2s_chain_regs<KLF>(acc, qacc, fr, bl);
+                            __builtin_amdgcn_s_setprio(0);
                             __builtin_amdgcn_sched_barrier(0);
                             if (gi == G - 1) {
                                 // every wave holds its fragments of this stage: `cur` may be refilled, and
@@ -394,8 +410,17 @@ static void launch_h2s(const H2sLaunch &l) {
     a.n_tiles = l.n_tiles;
     a.log2_k = l.log2_k;
     a.force_exc = l.force_exc;
-    dim3 grid((unsigned)((int64_t)l.n_groups * ((l.n_tiles + 7) / 8) * 8));
-    hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, false>), grid, dim3(256), 0, ctx().stream, a);
+    // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
+    const int resident = ctx().n_cu * h2s_waves_per_eu(KQF, KLF, false);
+    int tiles_per_launch = l.tiles_per_launch > 0 ? l.tiles_per_launch
+                           : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
+    for (int base = 0; base < l.n_tiles; base += tiles_per_launch) {
+        a.tile_base = base;
+        const int n = std::min(tiles_per_launch, l.n_tiles - base);
+        dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
+        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, false>), grid, dim3(256), 0, ctx().stream, a);
+    }
+    a.tile_base = 0;
     // the exception pass: persistent workgroups over the (tile, block) list the main pass left
     const int fix_grid = std::max(1, std::min(l.exc_cap, ctx().n_cu * 2));
     hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, true>), dim3((unsigned)fix_grid), dim3(256), 0, ctx().stream, a);

@@ -16,6 +16,7 @@ struct ScoreOptions {
                                // 5 = split-fp16 (2 parts, 3 products) matrix-core kernel;
                                // 6 = split-fp16, shared-sigma form
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
+    int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
 };
 
@@ -80,6 +81,7 @@ struct H2sLaunch {
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
     float log2_k;
     int force_exc;
+    int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
 };
 void launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
