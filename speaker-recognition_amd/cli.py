@@ -41,6 +41,8 @@ def get_args(argv=None):
     parser.add_argument("--no-lpc", action="store_true", help="MFCC half of mix_feature only (13 dims)")
     parser.add_argument("--seed", type=int, default=-1, help="EM initialisation seed (-1: random)")
     parser.add_argument("--device", type=int, default=0)
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="predict: shard the input files over this many GPUs from one process (0 = all visible)")
     return parser.parse_args(argv)
 
 
@@ -75,10 +77,18 @@ def task_enroll(input_dirs, output_model, args=None):
     m.dump(output_model)
 
 
-def task_predict(input_files, input_model):
+def task_predict(input_files, input_model, gpus=1):
     m = ModelInterface.load(input_model)
     out = []
-    for f in sorted(glob.glob(os.path.expanduser(input_files))):
+    files = sorted(glob.glob(os.path.expanduser(input_files)))
+    if gpus != 1:
+        # every file in one utterance-sharded pass over the node's GPUs (interface.predict_many)
+        labels = m.predict_many([read_wav(f) for f in files], gpus=gpus)
+        for f, label in zip(files, labels):
+            print(f, "->", label)
+            out.append((f, label))
+        return out
+    for f in files:
         fs, signal = read_wav(f)
         label = m.predict(fs, signal)
         print(f, "->", label)
@@ -108,7 +118,7 @@ def main(argv=None):
     if args.task == "enroll":
         task_enroll(args.input, args.model, args)
     elif args.task == "predict":
-        task_predict(args.input, args.model)
+        task_predict(args.input, args.model, args.gpus)
     else:
         print('task must be "enroll" or "predict"')
         sys.exit(2)

@@ -89,8 +89,20 @@ class ModelInterface(object):
             return None
         return self.gmmset.predict_one(feat)
 
-    def predict_many(self, items):
-        """Extension: [(fs, signal), ...] -> labels, every utterance scored in one batch."""
+    def predict_many(self, items, gpus=1):
+        """Extension: [(fs, signal), ...] -> labels, every utterance scored in one batch.  ``gpus`` != 1
+        (0 = every visible GPU) shards the utterances over the GPUs of the node from this one process
+        (core.MultiPredictor: a host thread and a model replica per GPU, no collective) -- for the MFCC-only
+        feature (``lpc=False``) on int16 audio of one sampling rate; anything else takes the one-GPU path."""
+        items = list(items)
+        rates = {fs for fs, _ in items}
+        if gpus != 1 and not self.lpc and len(rates) == 1 and items and \
+                all(np.asarray(sig).dtype == np.int16 and np.asarray(sig).ndim == 1 for _, sig in items):
+            from .core import MultiPredictor
+            kw = dict(self.feature_kwargs)
+            mp = MultiPredictor(self.gmmset.gmms, rates.pop(), n_slots=int(gpus), **kw)
+            _, winners = mp.predict([sig for _, sig in items], nd=self.nd if self.diff else 0)
+            return [None if w < 0 else self.gmmset.y[w] for w in winners]
         feats = [self._features(fs, sig) for fs, sig in items]
         return self.gmmset.predict(feats)
 

@@ -295,6 +295,8 @@ def test_cfg0_at_stated_size_cli_vs_cpu_restatement(built_lib, tmp_path):
     assert len(res) == 10
     for f, label in res:
         assert os.path.basename(f).replace("test_", "").replace(".wav", "") == label
+    # the same through the one-process multi-GPU path (3 slots: on a one-GPU box they share device 0)
+    assert cli.task_predict(args.input, args.model, gpus=3) == res
     m = ModelInterface.load(model)
     kw = dict(win_length_ms=25, win_shift_ms=10)
     params = [go.GMMParams(*g.params()) for g in m.gmmset.gmms]
