@@ -265,9 +265,15 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                 constexpr int KM = KQF > KLF ? KQF : KLF;
                 uint4 fr[KM];
                 auto load_frags = [&](const uint4 *at, int kn) {
+#ifdef H2S_DEBUG_ONE_FRAG         /* energy experiment only: one LDS read per image, wrong results */
+                    fr[0] = at[0];
+#pragma unroll
+                    for (int ks = 1; ks < KM; ks++) fr[ks] = fr[0];
+#else
 #pragma unroll
                     for (int ks = 0; ks < KM; ks++)
                         if (ks < kn) fr[ks] = at[ks * 64];
+#endif
                 };
                 const int n_stage_total = a.n_mix_tiles * N_STAGES;
                 __syncthreads();                      // previous block's readers are done with both buffers
@@ -315,11 +321,15 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                                 for (int r = 0; r < 16; r++) qacc[r] -= off;
                             } else {
                                 float e0 = 0.0f, e1 = 0.0f;
+#ifdef H2S_DEBUG_NO_EPILOGUE      /* energy experiment only: wrong results */
+                                e0 = acc[0]; e1 = acc[15];
+#else
 #pragma unroll
                                 for (int r = 0; r < 16; r += 2) {
                                     e0 += __builtin_amdgcn_exp2f(acc[r]);
                                     e1 += __builtin_amdgcn_exp2f(acc[r + 1]);
                                 }
+#endif
                                 ssum[img - 1] += e0 + e1;
                                 asm volatile("" : "+v"(ssum[img - 1]));
                             }
@@ -343,7 +353,11 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                     // the offset form is only trusted well inside fp32's exponent range and well above
                     // the reference's underflow boundary
                     const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
+#if defined(H2S_DEBUG_NO_EPILOGUE) || defined(H2S_DEBUG_ONE_FRAG)
+                    (void)ok;                                   // energy experiments: results are wrong by construction
+#else
                     bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+#endif
                 }
                 ll_keep[si] = ll;
             }
