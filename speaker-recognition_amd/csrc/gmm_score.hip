@@ -516,7 +516,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (DP > 40 && FT > 3) FT = 3;
     if (use_shared || use_h2s) FT = 1;
     if (use_split) FT = opt.mfma_ft ? std::min(opt.mfma_ft, split_max_ft(split.ks)) : 1;   // one column tile per wave won or tied every sweep
-    TileTable &tt = feat.tiles_for(use_mat ? 128 * FT : 256 * F);
+    int h2s_shape = 0;      // 0: 4-wave workgroups; 1: 12 waves; 2: 8 waves x 2 column tiles (launch_score_h2_shared)
+    if (use_h2s) {
+        // one wide workgroup per CU (one copy of the parameter stream in LDS for all its waves) once the batch
+        // fills the chip a few times over; three 4-wave workgroups per CU below that
+        const int64_t n32 = (feat.n_rows + 31) / 32 + feat.n_utt;     // upper bound of the 32-frame tiles
+        const bool wide = n32 >= (int64_t)4 * ctx().n_cu * h2s_tiles_per_wg(H2S_WIDE_SHAPE);
+        h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_WIDE_SHAPE : 0);
+    }
+    TileTable &tt = feat.tiles_for(use_h2s ? 32 : use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
@@ -530,9 +538,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // enough workgroups for a short tail: >= ~16 rounds of resident ones for the vector and
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
-            const int target = use_h2s ? ctx().n_cu * 3 * 6 : use_shared ? ctx().n_cu * 2 * 6
+            const int target = use_h2s ? ctx().n_cu * h2s_resident_per_cu(set.h2s.kqf, set.h2s.klf, h2s_shape) * 6 : use_shared ? ctx().n_cu * 2 * 6
                                : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
-            G = (target + tt.n_tiles - 1) / tt.n_tiles;
+            // (the split-fp16 shared-sigma engine's workgroups take several 32-frame tiles each)
+            const int n_wg_tiles = use_h2s ? (tt.n_tiles + h2s_tiles_per_wg(h2s_shape) - 1) / h2s_tiles_per_wg(h2s_shape) : tt.n_tiles;
+            G = (target + n_wg_tiles - 1) / n_wg_tiles;
         }
         const int n_units = use_h2s ? (int)set.h2s.blocks.size()
                             : use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of
@@ -554,7 +564,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             w.group_chunk_begin.upload(w.gcb_host.data(), w.gcb_host.size());
             uploaded = true;
         }
-        w.partial.ensure((size_t)tt.n_tiles * S * 4);
+        w.partial.ensure((size_t)tt.n_tiles * S * ((use_split || use_shared || use_h2s) ? 1 : 4));
         if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
 
         if (use_h2s) {
@@ -565,11 +575,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             used_oor = true;
             // pre-pass: the reference model's per-frame LL (natural log, no clamp) = the offset
             w.ref_ll.ensure((size_t)std::max<int64_t>(1, feat.n_rows));
-            w.ref_partial.ensure((size_t)tt.n_tiles);
+            TileTable &tt_ref = feat.tiles_for(128);     // the pre-pass keeps one column tile per wave
+            w.ref_partial.ensure((size_t)tt_ref.n_tiles);
             {
                 MfmaLaunch r;
                 r.X = feat.data.p;
-                r.tiles = tt.d_tiles.p;
+                r.tiles = tt_ref.d_tiles.p;
                 r.params = reinterpret_cast<const float4 *>(set.d_h2s_ref_params.p);
                 r.chunks = set.d_h2s_ref_chunks.p;
                 r.group_chunk_begin = set.d_h2s_ref_gcb.p;
@@ -583,7 +594,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 r.n_models = 1;
                 r.clamp = 0;
                 r.n_groups = 1;
-                r.n_tiles = tt.n_tiles;
+                r.n_tiles = tt_ref.n_tiles;
                 ScopedKernelTimer t(T_SCORE_REF);
                 launch_score_split(r, SPLIT_F16X2, h.ref.ks, 1);
             }
@@ -619,9 +630,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.log2_k = (float)std::log2((double)h.n_tiles * MT);
             a.force_exc = opt.h2s_force_exc;
             a.tiles_per_launch = opt.h2s_tiles_per_launch;
+            a.shape = h2s_shape;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
-                     "gmm_score_h2s_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
-                     "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf, SHARED_SB);
+                     "gmm_score_h2s_kernel<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
+                     "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf,
+                     h2s_shape == 1 ? "waves=12" : h2s_shape == 2 ? "waves=8x2" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
             launch_score_h2_shared(a, h.kqf, h.klf);
         } else if (use_shared) {

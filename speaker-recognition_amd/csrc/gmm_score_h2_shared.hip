@@ -17,10 +17,16 @@
 //     16 x (v_exp_f32 + v_add_f32) -- no maxima, no subtractions, no rescaling, one float of state
 //     per model.  Nothing is assumed: at the close a lane checks that its sum stayed inside
 //     [2^-100, 2^100] and far enough above the reference's underflow boundary (lse.hpp); a
-//     workgroup with a frame that fails the check writes (tile, block) to an exception list
-//     instead of results, and the same kernel in ONLINE form (classic running maximum, lse.hpp
-//     semantics) re-scores exactly those pairs right after the main launch.
-//  3. The stream is staged through LDS two images (16 KiB) per barrier.
+//     wave with a frame that fails the check writes (32-frame tile, block) to an exception list
+//     instead of results, and gmm_score_h2s_online_kernel (classic running maximum, lse.hpp
+//     semantics, one wave per pair, fragments straight from L2) re-scores exactly those pairs right
+//     after the main launch.  The decision is per 32-frame tile of ONE utterance, so an utterance's
+//     results do not depend on the batch around it.
+//  3. The stream is staged through LDS G images per barrier; the unit of work is a 32-frame tile per wave
+//     (tiles never straddle utterances, workgroups may), so a workgroup can be 4 waves (three of them per
+//     CU, each with its own copy of the stream in LDS) or 12 / 8 waves -- ONE per CU, one copy of the
+//     stream for all of them: a third / a quarter of the L2 -> LDS traffic, which is what the 4-wave form
+//     stalls on (profiles/r02_h2s_stalls.txt).
 //
 // Stream order per block of 15 models, per mixture tile: [Q][L_0]...[L_14], 16 images of KF KiB
 // ([ks][lane][8 x fp16]: one ds_read_b128 per lane and MFMA).
@@ -35,7 +41,6 @@ namespace sr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int H2S_G = 2;                         // images per LDS stage (one barrier per stage)
 constexpr int H2S_ROUNDS_PER_LAUNCH = 12;
 #ifndef H2S_CHAIN_PRIO
 #define H2S_CHAIN_PRIO 0
@@ -45,25 +50,20 @@ constexpr float H2S_SUM_HI = 1.2676506002282294e+30f;    // 2^100
 constexpr float H2S_LOG2E = 1.4426950408889634f;
 
 // KN steps of one flat chain on `acc`; `init` is the C operand of the first MFMA
-template <int KN>
-__device__ __forceinline__ void h2s_chain(f32x16 &acc, const f32x16 &init, const uint4 *at, const f16x8 (&b)[KN]) {
-    uint4 nx = at[0];
-#pragma unroll
-    for (int ks = 0; ks < KN; ks++) {
-        const f16x8 a = __builtin_bit_cast(f16x8, nx);
-        if (ks + 1 < KN) nx = at[(ks + 1) * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b[ks], ks == 0 ? init : acc, 0, 0, 0);
-    }
-}
-
 // The chain on A fragments already in registers: KN MFMAs back to back (a dependent chain on one
 // accumulator issues every 32 cycles only when nothing sits between its links: putting the
 // previous image's epilogue into the gaps was measured 30 % SLOWER, profiles/r02_h2s_variants.txt).
-template <int KN, int KM>
-__device__ __forceinline__ void h2s_chain_regs(f32x16 &acc, const f32x16 &init, const uint4 (&fr)[KM], const f16x8 (&b)[KN]) {
+// With COLS = 2 column tiles per wave the two chains share every A fragment and alternate, so a link's
+// predecessor is two issue slots back.
+template <int KN, int KM, int COLS>
+__device__ __forceinline__ void h2s_chain_regs(f32x16 (&acc)[COLS], const f32x16 (&init)[COLS], const uint4 (&fr)[KM],
+                                               const f16x8 (&b)[COLS][KN]) {
 #pragma unroll
     for (int ks = 0; ks < KN; ks++)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[ks]), b[ks], ks == 0 ? init : acc, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < COLS; c++)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[ks]), b[c][ks],
+                                                            ks == 0 ? init[c] : acc[c], 0, 0, 0);
 }
 
 // Resident B fragments of one lane's frame for a flat slot table: desc = d | op << 8, op 0 zero,
@@ -119,15 +119,24 @@ struct H2sArgs {
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
 };
 
-__host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, bool online) {
-    return (online || kqf + klf > 16) ? 2 : 3;
+// Workgroup shapes: waves per workgroup x 32-frame column tiles per wave x images per LDS stage.
+//   <4,1>   three workgroups per CU, each with its own copy of the stream (small batches)
+//   <12,1>  one workgroup per CU, three waves per SIMD sharing one copy
+//   <8,2>   one workgroup per CU, two waves per SIMD, two column tiles each (half the LDS fragment reads)
+__host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, int waves) {
+    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf > 16) ? 2 : 3;
+}
+__host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) {
+    // a wide workgroup has the CU's LDS to itself: two stages of 8 images while they fit in 160 KiB
+    return waves == 4 ? 2 : ((kqf > klf ? kqf : klf) <= 8 ? 8 : 4);
 }
 
-template <int KQF, int KLF, bool ONLINE>
-__global__ __launch_bounds__(256, h2s_waves_per_eu(KQF, KLF, ONLINE))
+template <int KQF, int KLF, int COLS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, h2s_waves_per_eu(KQF, KLF, COLS, WAVES))
 void gmm_score_h2s_kernel(const H2sArgs a) {
     constexpr int SB = SHARED_SB;
-    constexpr int G = H2S_G;
+    constexpr int G = h2s_stage_images(KQF, KLF, WAVES);
+    constexpr int TILES_WG = WAVES * COLS;                     // 32-frame tiles per workgroup
     constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
     constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;          // every image padded to the larger of the two
     constexpr int STRIDE_U4 = (1 + SB) * IMG_U4;               // one mixture tile of one block
@@ -135,8 +144,6 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     static_assert((1 + SB) % G == 0 && (N_STAGES % 2) == 0, "stages must tile the 16 images and alternate buffers");
     __shared__ uint4 lds_a[G * IMG_U4];
     __shared__ uint4 lds_b[G * IMG_U4];
-    __shared__ double close_slot[SB][4];
-    __shared__ int wg_flag;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,12 +151,12 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     const int col = lane & 31;
     const int hh = lane >> 5;
 
-    // a stage is N_PIECES wave-instructions of 1 KiB; wave w issues pieces w, w + 4, ... (a scalar test)
+    // a stage is N_PIECES wave-instructions of 1 KiB; wave w issues pieces w, w + WAVES, ... (a scalar test)
     constexpr int N_PIECES = G * IMG_U4 / 64;
     auto stage_load = [&](uint4 *dst, const uint4 *src) {
 #pragma unroll
-        for (int i = 0; i < (N_PIECES + 3) / 4; i++) {
-            const int piece = i * 4 + wave;
+        for (int i = 0; i < (N_PIECES + WAVES - 1) / WAVES; i++) {
+            const int piece = i * WAVES + wave;
             if (piece < N_PIECES)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
@@ -163,240 +170,275 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     // tile loop altogether (the stage-0 barrier had no wait: stale fragments for the second model of
     // a block whenever the parameters came from HBM rather than L2).  So: explicit.
     auto publish_barrier = [&]() {
+#ifndef H2S_DEBUG_NO_BARRIER      /* stall experiment only: wrong results */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     };
 
-    const int n_work = ONLINE ? *a.exc_count : (int)gridDim.x;
-    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
-        int tile_id, blk_begin, blk_end;
-        if constexpr (ONLINE) {
-            if (work >= a.exc_cap) break;
-            const int2 e = a.exc_list[work];
-            tile_id = e.x;
-            blk_begin = e.y;
-            blk_end = e.y + 1;
-            __syncthreads();                       // the previous pair's LDS readers are done
-        } else {
-            const int tile_lo = work & 7;          // XCD-aware order, as gmm_score_kernel
-            const int q = work >> 3;
-            const int g = q % a.n_groups;
-            tile_id = a.tile_base + (q / a.n_groups) * 8 + tile_lo;
-            if (tile_id >= a.n_tiles) return;
-            blk_begin = a.group_block_begin[g];
-            blk_end = a.group_block_begin[g + 1];
-        }
-        const TileDesc tile = a.tiles[tile_id];
+    const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
+    const int q = blockIdx.x >> 3;
+    const int g = q % a.n_groups;
+    const int tile0 = a.tile_base + ((q / a.n_groups) * 8 + wg_lo) * TILES_WG;     // first 32-frame tile of this workgroup
+    if (tile0 >= a.n_tiles) return;
+    const int blk_begin = a.group_block_begin[g];
+    const int blk_end = a.group_block_begin[g + 1];
 
-        // ---- resident B fragments of this lane's frame ----
-        f16x8 bq[KQF], bl[KLF];
-        const int local = wave * 32 + col;
-        const bool valid = local < tile.count;
-        const int64_t row = tile.start + (valid ? local : 0);
-        float zmax = 0.0f;
-        h2s_build_b<KQF>(bq, a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
-        h2s_build_b<KLF>(bl, a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
-        if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);           // saturated: the host re-scores on the fp32-grade engines
-        float off = 0.0f;                                      // per-frame offset O (log2 units)
-        if constexpr (!ONLINE) off = a.ref_ll[row] * H2S_LOG2E;
-        const float near_thr = lse_near_threshold(a.clamp);
-        // main pass: the largest term is >= LL - log2 K; below this the ONLINE pass decides
-        const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
+    // ---- resident B fragments of this lane's frame(s) ----
+    f16x8 bq[COLS][KQF], bl[COLS][KLF];
+    bool valid[COLS], has[COLS];
+    int tile_id[COLS];
+    int64_t row[COLS];
+    float off[COLS];                                       // per-frame offset O (log2 units)
+    float zmax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < COLS; c++) {
+        tile_id[c] = tile0 + wave * COLS + c;
+        has[c] = tile_id[c] < a.n_tiles;
+        const TileDesc tile = a.tiles[has[c] ? tile_id[c] : a.n_tiles - 1];
+        valid[c] = has[c] && col < tile.count;
+        row[c] = tile.start + (valid[c] ? col : 0);
+        h2s_build_b<KQF>(bq[c], a.X + row[c] * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
+        h2s_build_b<KLF>(bl[c], a.X + row[c] * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
+        off[c] = a.ref_ll[row[c]] * H2S_LOG2E;
+    }
+    if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);           // saturated: the host re-scores on the fp32-grade engines
+    // the largest term is >= LL - log2 K; below this the online pass decides
+    const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
 
-        const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // Every workgroup streams the same parameter images from L2, and the 4 MiB L2 of an XCD cannot hold
-        // the whole stream: the workgroups of an XCD hit in L2 only while they sweep in phase.  They do for
-        // the first ~30 rounds of a launch (all start at block 0 together: 3 % L2 misses on 3 M frames), then
-        // the start times drift apart (42 % misses = 1.1 TB of fabric reads over 10 M frames).  Steering the
-        // starting block by a shared hint or by the clock made it WORSE (44 % at 3 M frames: a workgroup that
-        // starts mid-sweep is out of phase with everyone who started at 0), so long grids are simply cut into
-        // launches of H2S_ROUNDS_PER_LAUNCH rounds, each of which starts in phase (launch_h2s).
-        for (int blk = blk_begin; blk < blk_end; blk++) {
-            const SharedBlock sb = a.blocks[blk];
-            const uint4 *stream = a.params + sb.offset_u4;
-            float m[ONLINE ? SB : 1], ssum[SB];
+    const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 zero16[COLS];
 #pragma unroll
-            for (int si = 0; si < SB; si++) {
-                if constexpr (ONLINE) m[si] = NEG_BIG;
-                ssum[si] = 0.0f;
-            }
-            if constexpr (ONLINE) {
-                __syncthreads();                      // previous block's readers are done with lds_a
-                stage_load(lds_a, stream);
-                publish_barrier();
-                for (int t = 0; t < a.n_mix_tiles; t++) {
-                    const uint4 *tsrc = stream + (size_t)t * STRIDE_U4;
-                    f32x16 qacc;
+    for (int c = 0; c < COLS; c++) zero16[c] = zero1;
+    // Every workgroup streams the same parameter images from L2, and the 4 MiB L2 of an XCD cannot hold
+    // the whole stream: the workgroups of an XCD hit in L2 only while they sweep in phase.  They do for
+    // the first ~30 rounds of a launch (all start at block 0 together: 3 % L2 misses on 3 M frames), then
+    // the start times drift apart (42 % misses = 1.1 TB of fabric reads over 10 M frames).  Steering the
+    // starting block by a shared hint or by the clock made it WORSE (44 % at 3 M frames: a workgroup that
+    // starts mid-sweep is out of phase with everyone who started at 0), so long grids are simply cut into
+    // launches of H2S_ROUNDS_PER_LAUNCH rounds, each of which starts in phase (launch_h2s).
+    for (int blk = blk_begin; blk < blk_end; blk++) {
+        const SharedBlock sb = a.blocks[blk];
+        const uint4 *stream = a.params + sb.offset_u4;
+        float ssum[COLS][SB];
 #pragma unroll
-                    for (int st = 0; st < N_STAGES; st++) {
-                        const uint4 *cur = (st & 1) ? lds_b : lds_a;
-                        uint4 *other = (st & 1) ? lds_a : lds_b;
-                        if (st + 1 < N_STAGES)
-                            stage_load(other, tsrc + (size_t)(st + 1) * G * IMG_U4);
-                        else if (t + 1 < a.n_mix_tiles)
-                            stage_load(other, tsrc + STRIDE_U4);            // next tile's first stage -> lds_a
+        for (int c = 0; c < COLS; c++)
 #pragma unroll
-                        for (int gi = 0; gi < G; gi++) {
-                            const int img = st * G + gi;
-                            const uint4 *at = cur + gi * IMG_U4 + lane;
-                            if (img == 0) {
-                                h2s_chain<KQF>(qacc, zero16, at, bq);
-                            } else {
-                                const int si = img - 1;
-                                f32x16 acc;
-                                h2s_chain<KLF>(acc, qacc, at, bl);
-                                lse_update16(acc, m[si], ssum[si], near_thr);
-                                // the model loop is unrolled and s_barrier orders memory, not ALU work:
-                                // pin each epilogue where it is written (see gmm_score_bx3_shared.hip)
-                                asm volatile("" : "+v"(m[si]), "+v"(ssum[si]));
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        publish_barrier();
-                    }
-                }
-            } else {
-                // Main pass.  Per image: (1) the chain -- its KN A fragments already sit in registers,
-                // so the MFMAs issue back to back; (2) the NEXT image's fragments are requested from
-                // LDS; (3) this image's epilogue runs while they arrive.  A stage's LDS buffer is free
-                // as soon as the fragments of its last image are in registers, so the barrier (and
-                // the LDS-DMA of the stage after next into the freed buffer) comes before that image's
-                // epilogue, not after it.
-                constexpr int KM = KQF > KLF ? KQF : KLF;
-                uint4 fr[KM];
-                auto load_frags = [&](const uint4 *at, int kn) {
+            for (int si = 0; si < SB; si++) ssum[c][si] = 0.0f;
+        // Per image: (1) the chain(s) -- the KN A fragments already sit in registers, so the MFMAs
+        // issue back to back; (2) the NEXT image's fragments are requested from LDS; (3) this image's
+        // epilogue runs while they arrive.  A stage's LDS buffer is free as soon as the fragments of
+        // its last image are in registers, so the barrier (and the LDS-DMA of the stage after next
+        // into the freed buffer) comes before that image's epilogue, not after it.
+        constexpr int KM = KQF > KLF ? KQF : KLF;
+        uint4 fr[KM];
+        auto load_frags = [&](const uint4 *at, int kn) {
 #ifdef H2S_DEBUG_ONE_FRAG         /* energy experiment only: one LDS read per image, wrong results */
-                    fr[0] = at[0];
+            fr[0] = at[0];
 #pragma unroll
-                    for (int ks = 1; ks < KM; ks++) fr[ks] = fr[0];
+            for (int ks = 1; ks < KM; ks++) fr[ks] = fr[0];
 #else
 #pragma unroll
-                    for (int ks = 0; ks < KM; ks++)
-                        if (ks < kn) fr[ks] = at[ks * 64];
+            for (int ks = 0; ks < KM; ks++)
+                if (ks < kn) fr[ks] = at[ks * 64];
 #endif
-                };
-                const int n_stage_total = a.n_mix_tiles * N_STAGES;
-                __syncthreads();                      // previous block's readers are done with both buffers
-                stage_load(lds_a, stream);
-                if (n_stage_total > 1) stage_load(lds_b, stream + (size_t)G * IMG_U4);
-                publish_barrier();                    // (drains both; the second is not needed yet, once per block)
-                load_frags(lds_a + lane, KQF);
-                for (int t = 0; t < a.n_mix_tiles; t++) {
-                    const uint4 *tsrc = stream + (size_t)t * STRIDE_U4;
-                    const bool more_tiles = t + 1 < a.n_mix_tiles;
-                    f32x16 qacc;
+        };
+        const int n_stage_total = a.n_mix_tiles * N_STAGES;
+        __syncthreads();                      // previous block's readers are done with both buffers
+        stage_load(lds_a, stream);
+        if (n_stage_total > 1) stage_load(lds_b, stream + (size_t)G * IMG_U4);
+        publish_barrier();                    // (drains both; the second is not needed yet, once per block)
+        load_frags(lds_a + lane, KQF);
+        for (int t = 0; t < a.n_mix_tiles; t++) {
+            const uint4 *tsrc = stream + (size_t)t * STRIDE_U4;
+            const bool more_tiles = t + 1 < a.n_mix_tiles;
+            f32x16 qacc[COLS];
 #pragma unroll
-                    for (int st = 0; st < N_STAGES; st++) {
-                        uint4 *cur = (st & 1) ? lds_b : lds_a;
-                        const uint4 *nxt = (st & 1) ? lds_a : lds_b;
+            for (int st = 0; st < N_STAGES; st++) {
+                uint4 *cur = (st & 1) ? lds_b : lds_a;
+                const uint4 *nxt = (st & 1) ? lds_a : lds_b;
 #pragma unroll
-                        for (int gi = 0; gi < G; gi++) {
-                            const int img = st * G + gi;
-                            f32x16 acc;
-                            // the matrix pipe must never wait for an issue slot: a wave in its chain outranks
-                            // the waves in their (vector-ALU) epilogues
-                            __builtin_amdgcn_s_setprio(H2S_CHAIN_PRIO);
-                            if (img == 0)
-                                h2s_chain_regs<KQF>(qacc, zero16, fr, bq);
-                            else
-                                h2s_chain_regs<KLF>(acc, qacc, fr, bl);
-                            __builtin_amdgcn_s_setprio(0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (gi == G - 1) {
-                                // every wave holds its fragments of this stage: `cur` may be refilled, and
-                                // the stage after this one has landed (its DMA was issued a stage ago)
-                                publish_barrier();
-                                if (st + 2 < N_STAGES)
-                                    stage_load(cur, tsrc + (size_t)(st + 2) * G * IMG_U4);
-                                else if (more_tiles)
-                                    stage_load(cur, tsrc + STRIDE_U4 + (size_t)(st + 2 - N_STAGES) * G * IMG_U4);
-                                if (st + 1 < N_STAGES || more_tiles)
-                                    load_frags(nxt + lane, (st + 1 < N_STAGES) ? KLF : KQF);
-                            } else {
-                                load_frags(cur + (gi + 1) * IMG_U4 + lane, KLF);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (img == 0) {
+                for (int gi = 0; gi < G; gi++) {
+                    const int img = st * G + gi;
+                    f32x16 acc[COLS];
+                    __builtin_amdgcn_s_setprio(H2S_CHAIN_PRIO);
+                    if (img == 0)
+                        h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bq);
+                    else
+                        h2s_chain_regs<KLF, KM, COLS>(acc, qacc, fr, bl);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gi == G - 1) {
+                        // every wave holds its fragments of this stage: `cur` may be refilled, and
+                        // the stage after this one has landed (its DMA was issued a stage ago)
+                        publish_barrier();
+#ifdef H2S_DEBUG_DMA_THIRD       /* stall experiment only: a third of the stream (wrong results) */
+                        if (st % 3 == 0)
+#endif
+#ifndef H2S_DEBUG_NO_DMA          /* stall experiment only: wrong results */
+                        if (st + 2 < N_STAGES)
+                            stage_load(cur, tsrc + (size_t)(st + 2) * G * IMG_U4);
+                        else if (more_tiles)
+                            stage_load(cur, tsrc + STRIDE_U4 + (size_t)(st + 2 - N_STAGES) * G * IMG_U4);
+#endif
+                        if (st + 1 < N_STAGES || more_tiles)
+                            load_frags(nxt + lane, (st + 1 < N_STAGES) ? KLF : KQF);
+                    } else {
+                        load_frags(cur + (gi + 1) * IMG_U4 + lane, KLF);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (img == 0) {
 #pragma unroll
-                                for (int r = 0; r < 16; r++) qacc[r] -= off;
-                            } else {
-                                float e0 = 0.0f, e1 = 0.0f;
+                        for (int c = 0; c < COLS; c++)
+#pragma unroll
+                            for (int r = 0; r < 16; r++) qacc[c][r] -= off[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < COLS; c++) {
+                            float e0 = 0.0f, e1 = 0.0f;
 #ifdef H2S_DEBUG_NO_EPILOGUE      /* energy experiment only: wrong results */
-                                e0 = acc[0]; e1 = acc[15];
+                            e0 = acc[c][0]; e1 = acc[c][15];
 #else
 #pragma unroll
-                                for (int r = 0; r < 16; r += 2) {
-                                    e0 += __builtin_amdgcn_exp2f(acc[r]);
-                                    e1 += __builtin_amdgcn_exp2f(acc[r + 1]);
-                                }
-#endif
-                                ssum[img - 1] += e0 + e1;
-                                asm volatile("" : "+v"(ssum[img - 1]));
+                            for (int r = 0; r < 16; r += 2) {
+                                e0 += __builtin_amdgcn_exp2f(acc[c][r]);
+                                e1 += __builtin_amdgcn_exp2f(acc[c][r + 1]);
                             }
-                            __builtin_amdgcn_sched_barrier(0);
+#endif
+                            ssum[c][img - 1] += e0 + e1;
+                            asm volatile("" : "+v"(ssum[c][img - 1]));
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // ---- close the block's models ----
+        }
+        // ---- close the block's models: per 32-frame tile, so an utterance's fate does not depend on its neighbours ----
+#pragma unroll
+        for (int c = 0; c < COLS; c++) {
             bool bad = false;
             float ll_keep[SB];
 #pragma unroll
             for (int si = 0; si < SB; si++) {
-                float ll;
-                if constexpr (ONLINE) {
-                    ll = lse_close2(m[si], ssum[si], other_half(m[si]), other_half(ssum[si]), a.clamp);
-                } else {
-                    const float tot = ssum[si] + other_half(ssum[si]);
-                    const float ll2 = off + log2f(tot);
-                    ll = LSE_LN2 * ll2;
-                    // the offset form is only trusted well inside fp32's exponent range and well above
-                    // the reference's underflow boundary
-                    const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
-#if defined(H2S_DEBUG_NO_EPILOGUE) || defined(H2S_DEBUG_ONE_FRAG)
-                    (void)ok;                                   // energy experiments: results are wrong by construction
+                const float tot = ssum[c][si] + other_half(ssum[c][si]);
+                const float ll2 = off[c] + log2f(tot);
+                ll_keep[si] = LSE_LN2 * ll2;
+                // the offset form is only trusted well inside fp32's exponent range and well above
+                // the reference's underflow boundary
+                const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
+#if defined(H2S_DEBUG_NO_EPILOGUE) || defined(H2S_DEBUG_ONE_FRAG) || defined(H2S_DEBUG_NO_DMA) || defined(H2S_DEBUG_NO_BARRIER) || defined(H2S_DEBUG_DMA_THIRD)
+                (void)ok;                                   // energy experiments: results are wrong by construction
 #else
-                    bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+                bad |= (valid[c] && si < sb.n_models && !ok) || a.force_exc;
 #endif
-                }
-                ll_keep[si] = ll;
             }
-            bool redo = false;
-            if constexpr (!ONLINE) {
-                if (tid == 0) wg_flag = 0;
-                __syncthreads();
-                if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) wg_flag = 1;
-                __syncthreads();
-                redo = wg_flag != 0;
-                if (redo && tid == 0) {
+            if (__builtin_amdgcn_ballot_w64(bad) != 0) {      // wave-uniform
+                if (lane == 0 && has[c]) {
                     const int idx = atomicAdd(a.exc_count, 1);
-                    if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id, blk);
+                    if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id[c], blk);
                 }
+                continue;
             }
-            if (!redo) {
+            // one partial per 32-frame tile and model: a fixed-order float64 sum over the wave's lanes
 #pragma unroll
-                for (int si = 0; si < SB; si++) {
-                    double mine = 0.0;
-                    if (valid && hh == 0 && si < sb.n_models) {
-                        mine = (double)ll_keep[si];
-                        if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll_keep[si];
-                    }
-                    mine = wave_sum_f64(mine);
-                    if (lane == 0) close_slot[si][wave] = mine;
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int si = 0; si < SB; si++) {
+                double mine = 0.0;
+                if (valid[c] && hh == 0 && si < sb.n_models) {
+                    mine = (double)ll_keep[si];
+                    if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row[c]] = ll_keep[si];
                 }
-                __syncthreads();
-                if (tid < sb.n_models) {
-                    const double *p = close_slot[tid];
-                    a.partial[(int64_t)tile_id * a.n_models + sb.first_model + tid] = ((p[0] + p[1]) + p[2]) + p[3];
-                }
+                mine = wave_sum_f64(mine);
+                if (lane == 0 && has[c] && si < sb.n_models)
+                    a.partial[(int64_t)tile_id[c] * a.n_models + sb.first_model + si] = mine;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (!ONLINE) break;             // the main pass maps one workgroup to one (tile, group)
     }
 }
 
+// The exception pass: one wave per (32-frame tile, block) pair of the list, classic online log-sum-exp with the
+// reference's underflow semantics (lse.hpp).  A lone wave has nobody to share LDS with: its A fragments come
+// straight from L2 into registers, the next image's while this one's chain and epilogue run.
 template <int KQF, int KLF>
+__global__ __launch_bounds__(64, 2)
+void gmm_score_h2s_online_kernel(const H2sArgs a) {
+    constexpr int SB = SHARED_SB;
+    constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
+    constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;
+    constexpr int N_IMG = 1 + SB;
+    constexpr int KM = KQF > KLF ? KQF : KLF;
+    static_assert(N_IMG % 2 == 0, "the two fragment sets alternate by image parity");
+    const int lane = threadIdx.x;
+    const int col = lane & 31;
+    const int hh = lane >> 5;
+    const int n_work = min(*a.exc_count, a.exc_cap);
+    const float near_thr = lse_near_threshold(a.clamp);
+    const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const int2 e = a.exc_list[work];
+        const TileDesc tile = a.tiles[e.x];
+        const bool valid = col < tile.count;
+        const int64_t row = tile.start + (valid ? col : 0);
+        f16x8 bq[1][KQF], bl[1][KLF];
+        float zmax = 0.0f;
+        h2s_build_b<KQF>(bq[0], a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
+        h2s_build_b<KLF>(bl[0], a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
+        if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
+        const SharedBlock sb = a.blocks[e.y];
+        const uint4 *stream = a.params + sb.offset_u4 + lane;
+        float m[SB], ssum[SB];
+#pragma unroll
+        for (int si = 0; si < SB; si++) {
+            m[si] = NEG_BIG;
+            ssum[si] = 0.0f;
+        }
+        uint4 fa[KM], fb[KM];
+        auto fetch = [&](uint4 (&fr)[KM], const uint4 *at, int kn) {
+#pragma unroll
+            for (int ks = 0; ks < KM; ks++)
+                if (ks < kn) fr[ks] = at[ks * 64];
+        };
+        fetch(fa, stream, KQF);
+        const int n_img_total = a.n_mix_tiles * N_IMG;
+        for (int t = 0; t < a.n_mix_tiles; t++) {
+            f32x16 qacc[1];
+#pragma unroll
+            for (int img = 0; img < N_IMG; img++) {
+                const int flat = t * N_IMG + img;
+                const uint4 *next = stream + (size_t)(flat + 1) * IMG_U4;
+                const int next_kn = (img + 1 == N_IMG) ? KQF : KLF;
+                f32x16 acc[1];
+                if ((img & 1) == 0) {
+                    if (flat + 1 < n_img_total) fetch(fb, next, next_kn);
+                    if (img == 0) h2s_chain_regs<KQF, KM, 1>(qacc, {zero1}, fa, bq);
+                    else h2s_chain_regs<KLF, KM, 1>(acc, qacc, fa, bl);
+                } else {
+                    if (flat + 1 < n_img_total) fetch(fa, next, next_kn);
+                    h2s_chain_regs<KLF, KM, 1>(acc, qacc, fb, bl);
+                }
+                if (img > 0) {
+                    lse_update16(acc[0], m[img - 1], ssum[img - 1], near_thr);
+                    asm volatile("" : "+v"(m[img - 1]), "+v"(ssum[img - 1]));
+                }
+            }
+        }
+#pragma unroll
+        for (int si = 0; si < SB; si++) {
+            const float ll = lse_close2(m[si], ssum[si], other_half(m[si]), other_half(ssum[si]), a.clamp);
+            double mine = 0.0;
+            if (valid && hh == 0 && si < sb.n_models) {
+                mine = (double)ll;
+                if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll;
+            }
+            mine = wave_sum_f64(mine);
+            if (lane == 0 && si < sb.n_models)
+                a.partial[(int64_t)e.x * a.n_models + sb.first_model + si] = mine;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int KQF, int KLF, int COLS, int WAVES>
 static void launch_h2s(const H2sLaunch &l) {
     H2sArgs a;
     a.X = l.X;
@@ -425,23 +467,34 @@ static void launch_h2s(const H2sLaunch &l) {
     a.log2_k = l.log2_k;
     a.force_exc = l.force_exc;
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
-    const int resident = ctx().n_cu * h2s_waves_per_eu(KQF, KLF, false);
-    int tiles_per_launch = l.tiles_per_launch > 0 ? l.tiles_per_launch
-                           : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
-    for (int base = 0; base < l.n_tiles; base += tiles_per_launch) {
-        a.tile_base = base;
-        const int n = std::min(tiles_per_launch, l.n_tiles - base);
+    constexpr int TILES_WG = WAVES * COLS;
+    const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES));
+    const int n_wg = (l.n_tiles + TILES_WG - 1) / TILES_WG;
+    int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)
+                        : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
+    for (int base = 0; base < n_wg; base += wg_per_launch) {
+        a.tile_base = base * TILES_WG;
+        const int n = std::min(wg_per_launch, n_wg - base);
         dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
-        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, false>), grid, dim3(256), 0, ctx().stream, a);
+        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
     }
     a.tile_base = 0;
-    // the exception pass: persistent workgroups over the (tile, block) list the main pass left
-    const int fix_grid = std::max(1, std::min(l.exc_cap, ctx().n_cu * 2));
-    hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, true>), dim3((unsigned)fix_grid), dim3(256), 0, ctx().stream, a);
+    // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
+    const int fix_grid = std::max(1, std::min(l.exc_cap, ctx().n_cu * 8));
+    hipLaunchKernelGGL((gmm_score_h2s_online_kernel<KQF, KLF>), dim3((unsigned)fix_grid), dim3(64), 0, ctx().stream, a);
 }
 
+// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves; 2: 8 waves x 2)
+int h2s_resident_per_cu(int kqf, int klf, int shape) { return shape == 0 ? h2s_waves_per_eu(kqf, klf, 1, 4) : 1; }
+int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : shape == 1 ? 12 : 16; }
+
 void launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
-#define SR_H2S_CASE(Q, L) if (KQF == Q && KLF == L) return launch_h2s<Q, L>(l);
+#define SR_H2S_CASE(Q, L)                                       \
+    if (KQF == Q && KLF == L) {                                 \
+        if (l.shape == 1) return launch_h2s<Q, L, 1, 12>(l);    \
+        if (l.shape == 2) return launch_h2s<Q, L, 2, 8>(l);     \
+        return launch_h2s<Q, L, 1, 4>(l);                       \
+    }
     // KQF = ceil(3D/16), KLF = ceil((3D+2)/16): equal, or one apart at D = 5, 16, 21, 32, 37, 48
     SR_H2S_CASE(1, 1) SR_H2S_CASE(1, 2) SR_H2S_CASE(2, 2) SR_H2S_CASE(3, 3) SR_H2S_CASE(3, 4) SR_H2S_CASE(4, 4)
     SR_H2S_CASE(4, 5) SR_H2S_CASE(5, 5) SR_H2S_CASE(6, 6) SR_H2S_CASE(6, 7) SR_H2S_CASE(7, 7)

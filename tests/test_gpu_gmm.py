@@ -17,12 +17,15 @@ def _gmm(g, c):
     return GMM.from_arrays(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"])
 
 
+SHAPE_NAME = {1: "waves=4>", 2: "waves=12>", 3: "waves=8x2>"}     # score_h2s_shape -> last_score_kernel()
+
+
 @pytest.fixture(autouse=True)
 def _reset_options(built_lib):
     from speaker_recognition_amd import _lib
     yield
     for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic",
-              "score_h2s_force_exc"):
+              "score_h2s_force_exc", "score_h2s_shape"):
         _lib.set_option(k, 0)
 
 
@@ -425,12 +428,17 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
         ms = ModelSet([GMM.from_arrays(*m) for m in models])
         # engine 6 = the split-fp16 shared-sigma kernel (reference-offset log-sum-exp); its third
         # entry forces every workgroup through the exception (online) pass
-        for eng, G, force in ((0, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (6, 1, 0), (6, 2, 0), (6, 3, 0), (6, 0, 1),
-                              (3, 0, 0), (1, 0, 0)):
+        # a fourth entry = workgroup shape of engine 6 (1: 4 waves, 2: 12 waves, 3: 8 waves x 2 column tiles)
+        for eng, G, force, cols in ((0, 0, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 3, 0, 0), (6, 1, 0, 1), (6, 2, 0, 1),
+                                    (6, 3, 0, 1), (6, 0, 1, 1), (6, 1, 0, 2), (6, 2, 0, 2), (6, 3, 0, 2), (6, 0, 1, 2),
+                                    (6, 1, 0, 3), (6, 2, 0, 3), (6, 0, 1, 3), (3, 0, 0, 0), (1, 0, 0, 0)):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_model_groups", G)
             _lib.set_option("score_h2s_force_exc", force)
+            _lib.set_option("score_h2s_shape", cols)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            if cols:
+                assert SHAPE_NAME[cols] in _lib.last_score_kernel()
             if eng in (4, 6) or (eng == 0 and (K, S) == (64, 14)):      # auto also weighs the padding (phantom models, K % 32)
                 assert "shared" in _lib.last_score_kernel(), (K, D, S, eng)
             if eng == 6 or (eng == 0 and (K, S) == (64, 14)):
@@ -444,6 +452,7 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
                 assert np.max(np.abs(sums[u] - w)) < 2e-5 * n * 60 + 1e-3, (K, D, S, eng, u)
     _lib.set_option("score_model_groups", 0)
     _lib.set_option("score_h2s_force_exc", 0)
+    _lib.set_option("score_h2s_shape", 0)
     # different sigmas -> not eligible
     other = [synth.synth_gmm(64, 39, 900 + s) for s in range(14)]
     ms = ModelSet([GMM.from_arrays(*m) for m in other])
@@ -526,11 +535,12 @@ def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):
     utts = [synth.draw_frames(spk[u % S], 260 + 11 * u, 31 + u, outlier_frac=0.01 if u % 2 else 0.0) for u in range(6)]
     X = np.concatenate(utts).astype(np.float64)
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
-    for compat in (True, False):
+    for compat, cols in ((True, 1), (False, 1), (True, 2), (False, 2), (True, 3), (False, 3)):
         want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
         _lib.set_option("score_engine", 0)
+        _lib.set_option("score_h2s_shape", cols)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
-        assert "h2s" in _lib.last_score_kernel()
+        assert "h2s" in _lib.last_score_kernel() and SHAPE_NAME[cols] in _lib.last_score_kernel()
         rel = np.abs(fll - want) / np.maximum(1.0, np.abs(want))
         assert rel.max() < 1e-5, (compat, rel.max())
         again = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
@@ -564,9 +574,10 @@ def test_cfg3_shape_k2048_map_speakers_vs_oracle(built_lib, oracle_built):
     ms = ModelSet(gm)
     _lib.set_option("score_engine", 4)      # sets of more than 65536 mixtures pack only the layout in force at creation
     ms4 = ModelSet(gm)
-    for eng, force in ((0, 0), (6, 1), (4, 0)):
+    for eng, force, cols in ((0, 0, 1), (6, 1, 1), (0, 0, 2), (6, 1, 2), (0, 0, 3), (6, 1, 3), (4, 0, 0)):
         _lib.set_option("score_engine", eng)
         _lib.set_option("score_h2s_force_exc", force)
+        _lib.set_option("score_h2s_shape", cols)
         sums, arg, fll = (ms4 if eng == 4 else ms).score(Batch.from_features(utts), frame_ll=True)
         assert ("h2s" in _lib.last_score_kernel()) == (eng != 4)
         assert ll_close(fll, want) < TOL, (eng, force, ll_close(fll, want))
