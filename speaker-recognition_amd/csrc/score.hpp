@@ -18,7 +18,7 @@ struct ScoreOptions {
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
     int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
-                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream); 3 = 8 waves x 2 column tiles
+                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream); 3 = 8 waves, ping-pong
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
 };
 
@@ -84,7 +84,7 @@ struct H2sLaunch {
     float log2_k;
     int force_exc;
     int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
-    int shape = 0;          // 0: 4-wave workgroups; 1: 12 waves; 2: 8 waves x 2 column tiles (`tiles` = 32-frame tiles)
+    int shape = 0;          // 0: 4-wave workgroups; 1: 12 waves; 2: 8 waves in ping-pong (`tiles` = 32-frame tiles)
 };
 void launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU

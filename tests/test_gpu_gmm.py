@@ -17,7 +17,7 @@ def _gmm(g, c):
     return GMM.from_arrays(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"])
 
 
-SHAPE_NAME = {1: "waves=4>", 2: "waves=12>", 3: "waves=8x2>"}     # score_h2s_shape -> last_score_kernel()
+SHAPE_NAME = {1: "waves=4>", 2: "waves=12>", 3: "waves=8pp>"}     # score_h2s_shape -> last_score_kernel()
 
 
 @pytest.fixture(autouse=True)
