@@ -733,7 +733,7 @@ int sr_set_option(const char *key, long value) {
         if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
         score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
     } else if (k == "score_h2s_shape") {
-        if (value < 0 || value > 3) fail("score_h2s_shape must be 0 (automatic), 1 (4 waves), 2 (12 waves) or 3 (8 waves, ping-pong)");
+        if (value < 0 || value > 2) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups) or 2 (12-wave workgroups)");
         score_options().h2s_shape = (int)value;
     } else if (k == "score_h2s_force_exc") {
         score_options().h2s_force_exc = value != 0;

@@ -516,7 +516,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (DP > 40 && FT > 3) FT = 3;
     if (use_shared || use_h2s) FT = 1;
     if (use_split) FT = opt.mfma_ft ? std::min(opt.mfma_ft, split_max_ft(split.ks)) : 1;   // one column tile per wave won or tied every sweep
-    int h2s_shape = 0;      // 0: 4-wave workgroups; 1: 12 waves; 2: 8 waves in ping-pong (launch_score_h2_shared)
+    int h2s_shape = 0;      // 0: 4-wave workgroups; 1: 12-wave workgroups (launch_score_h2_shared)
     if (use_h2s) {
         // one wide workgroup per CU (one copy of the parameter stream in LDS for all its waves) once the batch
         // fills the chip a few times over; three 4-wave workgroups per CU below that
@@ -634,7 +634,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_h2s_kernel<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
                      "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf,
-                     h2s_shape == 1 ? "waves=12" : h2s_shape == 2 ? "waves=8pp" : "waves=4", SHARED_SB);
+                     h2s_shape == 1 ? "waves=12" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
             launch_score_h2_shared(a, h.kqf, h.klf);
         } else if (use_shared) {

@@ -42,9 +42,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int H2S_ROUNDS_PER_LAUNCH = 12;
-#ifndef H2S_CHAIN_PRIO
-#define H2S_CHAIN_PRIO 0
-#endif
 constexpr float H2S_SUM_LO = 7.8886090522101181e-31f;    // 2^-100
 constexpr float H2S_SUM_HI = 1.2676506002282294e+30f;    // 2^100
 constexpr float H2S_LOG2E = 1.4426950408889634f;
@@ -122,8 +119,10 @@ struct H2sArgs {
 // Workgroup shapes: waves per workgroup x 32-frame column tiles per wave x images per LDS stage.
 //   <4,1>   three workgroups per CU, each with its own copy of the stream (small batches)
 //   <12,1>  one workgroup per CU, three waves per SIMD sharing one copy
-//   pp      one workgroup of 8 waves per CU, two per SIMD in enforced anti-phase (gmm_score_h2s_pp_kernel)
-//   (two column tiles per wave -- half the LDS fragment reads, 2 waves per SIMD -- measured 4 % slower than <4,1>)
+// Tried and measured slower than <4,1> (profiles/r02_h2s_stalls.txt; the code is in commits 401bc2d and f5a34fe):
+// two column tiles per wave (COLS = 2: half the LDS fragment reads, 2 waves per SIMD) -4 %; 8 waves x 2 column
+// tiles -5 %; 8 waves with the two waves of a SIMD held in anti-phase by a workgroup barrier per phase (one
+// chains while the other runs its epilogue) -3 % with one image per phase, -5 % with two.
 __host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, int waves) {
     return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf > 16) ? 2 : 3;
 }
@@ -154,6 +153,9 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 
     // a stage is N_PIECES wave-instructions of 1 KiB; wave w issues pieces w, w + WAVES, ... (a scalar test)
     constexpr int N_PIECES = G * IMG_U4 / 64;
+    // every wave issues its share of a stage (in a 12-wave workgroup: all twelve 0.136 s on the configs[2]-shaped
+    // 5 M-frame pass, only the first four 0.140 s, only the last four 0.152 s -- a piece costs its issuing wave
+    // ~110 cycles, and the waves of a SIMD reach a stage barrier far apart; profiles/r02_h2s_stalls.txt)
     auto stage_load = [&](uint4 *dst, const uint4 *src) {
 #pragma unroll
         for (int i = 0; i < (N_PIECES + WAVES - 1) / WAVES; i++) {
@@ -262,12 +264,10 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                 for (int gi = 0; gi < G; gi++) {
                     const int img = st * G + gi;
                     f32x16 acc[COLS];
-                    __builtin_amdgcn_s_setprio(H2S_CHAIN_PRIO);
                     if (img == 0)
                         h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bq);
                     else
                         h2s_chain_regs<KLF, KM, COLS>(acc, qacc, fr, bl);
-                    __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (gi == G - 1) {
                         // every wave holds its fragments of this stage: `cur` may be refilled, and
@@ -353,218 +353,6 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                     a.partial[(int64_t)tile_id[c] * a.n_models + sb.first_model + si] = mine;
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-    }
-}
-
-// Ping-pong form: ONE workgroup of 8 waves per CU; the two waves of a SIMD alternate roles every phase --
-// one runs the chains of TWO images (matrix pipe) while the other loads its next two fragment sets and runs its
-// two epilogues (LDS + vector ALU) -- with a workgroup barrier at every phase boundary, so the complementary
-// pairing is enforced instead of left to the arbiter.  (Left alone the arbiter is strictly oldest-first on both
-// the matrix pipe and the vector ALU, and older waves' vector work starves a younger wave's MFMA issue:
-// scripts/ubench/mfma_valu_block.hip.)  A phase boundary costs ~230 cycles whatever the phase holds (barrier
-// latency ~85, post-release issue penalty, skew: profiles/r02_h2s_phases.txt), hence two images per phase.
-// Group B (waves 4-7) runs one phase behind group A by taking one extra barrier at the start; group A takes
-// it at the end.
-template <int KQF, int KLF>
-__global__ __launch_bounds__(512, 2)
-void gmm_score_h2s_pp_kernel(const H2sArgs a) {
-    constexpr int SB = SHARED_SB;
-    constexpr int WAVES = 8;
-    constexpr int G = h2s_stage_images(KQF, KLF, WAVES);
-    constexpr int TILES_WG = WAVES;
-    constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
-    constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;
-    constexpr int STRIDE_U4 = (1 + SB) * IMG_U4;
-    constexpr int N_STAGES = (1 + SB) / G;
-    constexpr int KM = KQF > KLF ? KQF : KLF;
-    static_assert((1 + SB) % G == 0 && (N_STAGES % 2) == 0 && G >= 4 && G % 2 == 0, "stages must tile the 16 images in pairs and alternate buffers");
-    __shared__ uint4 lds_a[G * IMG_U4];
-    __shared__ uint4 lds_b[G * IMG_U4];
-#ifdef H2S_DEBUG_STAMPS           /* timing experiment: shader-clock stamps of one workgroup's phases, printed */
-    __shared__ unsigned stamp[2][5][16];
-#define H2S_STAMP(K) if (blockIdx.x == 0 && blk == blk_begin && t == 2 && (wave & 3) == 0 && lane == 0) stamp[grp][K][img] = (unsigned)__builtin_amdgcn_s_memtime();
-#else
-#define H2S_STAMP(K)
-#endif
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;                     // waves w and w + 4 share a SIMD
-    const int col = lane & 31;
-    const int hh = lane >> 5;
-
-    constexpr int N_PIECES = G * IMG_U4 / 64;
-    auto stage_load = [&](uint4 *dst, const uint4 *src) {
-#pragma unroll
-        for (int i = 0; i < (N_PIECES + WAVES - 1) / WAVES; i++) {
-            const int piece = i * WAVES + wave;
-            if (piece < N_PIECES)
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
-                    (__attribute__((address_space(3))) void *)(dst + piece * 64), 16, 0, 0);
-        }
-    };
-    // phase boundary: a bare s_barrier.  __syncthreads() would add s_waitcnt vmcnt(0), i.e. wait for the LDS-DMA
-    // refill issued in the phase that just ended (~1.5 us, once per stage); LDS is only ever written by DMA here, and
-    // each wave's pieces are waited for explicitly one pair before they are needed.
-    auto phase_barrier = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    const int wg_lo = blockIdx.x & 7;
-    const int q = blockIdx.x >> 3;
-    const int g = q % a.n_groups;
-    const int tile0 = a.tile_base + ((q / a.n_groups) * 8 + wg_lo) * TILES_WG;
-    if (tile0 >= a.n_tiles) return;
-    const int blk_begin = a.group_block_begin[g];
-    const int blk_end = a.group_block_begin[g + 1];
-
-    f16x8 bq[1][KQF], bl[1][KLF];
-    const int tile_id = tile0 + wave;
-    const bool has = tile_id < a.n_tiles;
-    const TileDesc tile = a.tiles[has ? tile_id : a.n_tiles - 1];
-    const bool valid = has && col < tile.count;
-    const int64_t row = tile.start + (valid ? col : 0);
-    float zmax = 0.0f;
-    h2s_build_b<KQF>(bq[0], a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
-    h2s_build_b<KLF>(bl[0], a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
-    const float off = a.ref_ll[row] * H2S_LOG2E;
-    if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
-    const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
-    const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-    for (int blk = blk_begin; blk < blk_end; blk++) {
-        const SharedBlock sb = a.blocks[blk];
-        const uint4 *stream = a.params + sb.offset_u4;
-        float ssum[SB];
-#pragma unroll
-        for (int si = 0; si < SB; si++) ssum[si] = 0.0f;
-        uint4 fr0[KM], fr1[KM];                // fragments of the even / odd image of the current pair
-        auto load_frags = [&](uint4 (&fr)[KM], const uint4 *at, int kn) {
-#pragma unroll
-            for (int ks = 0; ks < KM; ks++)
-                if (ks < kn) fr[ks] = at[ks * 64];
-        };
-        auto epilogue = [&](const f32x16 &acc, float &sum) {
-            float e0 = 0.0f, e1 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                e0 += __builtin_amdgcn_exp2f(acc[r]);
-                e1 += __builtin_amdgcn_exp2f(acc[r + 1]);
-            }
-            sum += e0 + e1;
-            asm volatile("" : "+v"(sum));
-        };
-        const int n_stage_total = a.n_mix_tiles * N_STAGES;
-        __syncthreads();                      // previous block's readers are done with both buffers
-        stage_load(lds_a, stream);
-        if (n_stage_total > 1) stage_load(lds_b, stream + (size_t)G * IMG_U4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        load_frags(fr0, lds_a + lane, KQF);
-        load_frags(fr1, lds_a + IMG_U4 + lane, KLF);
-        if (grp == 1) phase_barrier();        // group B: one phase behind
-        for (int t = 0; t < a.n_mix_tiles; t++) {
-            const uint4 *tsrc = stream + (size_t)t * STRIDE_U4;
-            const bool more_tiles = t + 1 < a.n_mix_tiles;
-            f32x16 qacc[1];
-#pragma unroll
-            for (int st = 0; st < N_STAGES; st++) {
-                uint4 *cur = (st & 1) ? lds_b : lds_a;
-                const uint4 *nxt = (st & 1) ? lds_a : lds_b;
-#pragma unroll
-                for (int gi = 0; gi < G; gi += 2) {
-                    const int img = st * G + gi;              // even image of the pair
-                    f32x16 acc0[1], acc1[1];
-                    // ---- phase 1: the two chains ----
-                    H2S_STAMP(0)
-                    if (img == 0) {
-                        h2s_chain_regs<KQF, KM, 1>(qacc, {zero1}, fr0, bq);
-#pragma unroll
-                        for (int r = 0; r < 16; r++) qacc[0][r] -= off;
-                    } else {
-                        h2s_chain_regs<KLF, KM, 1>(acc0, qacc, fr0, bl);
-                    }
-                    h2s_chain_regs<KLF, KM, 1>(acc1, qacc, fr1, bl);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // the refill of `nxt` (issued a stage ago by every wave, this one included) must have landed two
-                    // phases before the first wave reads it: wait for this wave's pieces one pair early
-                    if (gi == G - 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    H2S_STAMP(1)
-                    phase_barrier();
-                    H2S_STAMP(2)
-                    // ---- phase 2: the next pair's fragments, then this pair's epilogues ----
-                    if (gi == G - 2) {
-                        // both groups hold their fragments of this stage's last pair (group B loaded them a
-                        // phase ago): `cur` may be refilled
-                        if (st + 2 < N_STAGES)
-                            stage_load(cur, tsrc + (size_t)(st + 2) * G * IMG_U4);
-                        else if (more_tiles)
-                            stage_load(cur, tsrc + STRIDE_U4 + (size_t)(st + 2 - N_STAGES) * G * IMG_U4);
-                        if (st + 1 < N_STAGES || more_tiles) {
-                            load_frags(fr0, nxt + lane, (st + 1 < N_STAGES) ? KLF : KQF);
-                            load_frags(fr1, nxt + IMG_U4 + lane, KLF);
-                        }
-                    } else {
-                        load_frags(fr0, cur + (gi + 2) * IMG_U4 + lane, KLF);
-                        load_frags(fr1, cur + (gi + 3) * IMG_U4 + lane, KLF);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (img != 0) epilogue(acc0[0], ssum[img - 1]);
-                    epilogue(acc1[0], ssum[img]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    H2S_STAMP(3)
-                    phase_barrier();
-                    H2S_STAMP(4)
-                }
-            }
-        }
-        if (grp == 0) phase_barrier();        // group A sits out group B's last phase
-#ifdef H2S_DEBUG_STAMPS
-        if (blockIdx.x == 0 && blk == blk_begin) {
-            __syncthreads();
-            if (tid == 0)
-                for (int im = 0; im < 16; im += 2)
-                    printf("pair %2d  A: chains %4u bar %4u epi %4u bar %4u | B: chains %4u bar %4u epi %4u bar %4u | A start %u B start %u\n", im,
-                           stamp[0][1][im] - stamp[0][0][im], stamp[0][2][im] - stamp[0][1][im], stamp[0][3][im] - stamp[0][2][im], stamp[0][4][im] - stamp[0][3][im],
-                           stamp[1][1][im] - stamp[1][0][im], stamp[1][2][im] - stamp[1][1][im], stamp[1][3][im] - stamp[1][2][im], stamp[1][4][im] - stamp[1][3][im],
-                           stamp[0][0][im] - stamp[0][0][0], stamp[1][0][im] - stamp[0][0][0]);
-            __syncthreads();
-        }
-#endif
-        // ---- close (per 32-frame tile, as gmm_score_h2s_kernel) ----
-        bool bad = false;
-        float ll_keep[SB];
-#pragma unroll
-        for (int si = 0; si < SB; si++) {
-            const float tot = ssum[si] + other_half(ssum[si]);
-            const float ll2 = off + log2f(tot);
-            ll_keep[si] = LSE_LN2 * ll2;
-            const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
-            bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
-        }
-        if (__builtin_amdgcn_ballot_w64(bad) != 0) {
-            if (lane == 0 && has) {
-                const int idx = atomicAdd(a.exc_count, 1);
-                if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id, blk);
-            }
-            continue;
-        }
-#pragma unroll
-        for (int si = 0; si < SB; si++) {
-            double mine = 0.0;
-            if (valid && hh == 0 && si < sb.n_models) {
-                mine = (double)ll_keep[si];
-                if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll_keep[si];
-            }
-            mine = wave_sum_f64(mine);
-            if (lane == 0 && has && si < sb.n_models)
-                a.partial[(int64_t)tile_id * a.n_models + sb.first_model + si] = mine;
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -689,10 +477,7 @@ static void launch_h2s(const H2sLaunch &l) {
         a.tile_base = base * TILES_WG;
         const int n = std::min(wg_per_launch, n_wg - base);
         dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
-        if constexpr (WAVES == 8)
-            hipLaunchKernelGGL((gmm_score_h2s_pp_kernel<KQF, KLF>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
-        else
-            hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
+        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
     }
     a.tile_base = 0;
     // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
@@ -700,15 +485,14 @@ static void launch_h2s(const H2sLaunch &l) {
     hipLaunchKernelGGL((gmm_score_h2s_online_kernel<KQF, KLF>), dim3((unsigned)fix_grid), dim3(64), 0, ctx().stream, a);
 }
 
-// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves; 2: 8 waves, ping-pong)
+// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves)
 int h2s_resident_per_cu(int kqf, int klf, int shape) { return shape == 0 ? h2s_waves_per_eu(kqf, klf, 1, 4) : 1; }
-int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : shape == 1 ? 12 : 8; }
+int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : 12; }
 
 void launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
 #define SR_H2S_CASE(Q, L)                                       \
     if (KQF == Q && KLF == L) {                                 \
         if (l.shape == 1) return launch_h2s<Q, L, 1, 12>(l);    \
-        if (l.shape == 2) return launch_h2s<Q, L, 1, 8>(l);     \
         return launch_h2s<Q, L, 1, 4>(l);                       \
     }
     // KQF = ceil(3D/16), KLF = ceil((3D+2)/16): equal, or one apart at D = 5, 16, 21, 32, 37, 48

@@ -18,7 +18,7 @@ struct ScoreOptions {
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
     int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
-                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream); 3 = 8 waves, ping-pong
+                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
 };
 
@@ -84,7 +84,7 @@ struct H2sLaunch {
     float log2_k;
     int force_exc;
     int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
-    int shape = 0;          // 0: 4-wave workgroups; 1: 12 waves; 2: 8 waves in ping-pong (`tiles` = 32-frame tiles)
+    int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles)
 };
 void launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU
@@ -92,7 +92,7 @@ int h2s_tiles_per_wg(int shape);                        // 32-frame tiles a work
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;
-constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape the dispatcher takes for large batches (1 or 2)
+constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape the dispatcher takes for large batches
 void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT);   // a.params = the split image
 int split_max_ft(int ks);
 ScoreOptions &score_options();

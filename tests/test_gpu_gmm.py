@@ -17,7 +17,7 @@ def _gmm(g, c):
     return GMM.from_arrays(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"])
 
 
-SHAPE_NAME = {1: "waves=4>", 2: "waves=12>", 3: "waves=8pp>"}     # score_h2s_shape -> last_score_kernel()
+SHAPE_NAME = {1: "waves=4>", 2: "waves=12>"}     # score_h2s_shape -> last_score_kernel()
 
 
 @pytest.fixture(autouse=True)
@@ -428,10 +428,10 @@ def test_shared_sigma_engine_vs_oracle(built_lib, oracle_built):
         ms = ModelSet([GMM.from_arrays(*m) for m in models])
         # engine 6 = the split-fp16 shared-sigma kernel (reference-offset log-sum-exp); its third
         # entry forces every workgroup through the exception (online) pass
-        # a fourth entry = workgroup shape of engine 6 (1: 4 waves, 2: 12 waves, 3: 8 waves x 2 column tiles)
+        # a fourth entry = workgroup shape of engine 6 (1: 4 waves, 2: 12 waves sharing one LDS copy of the stream)
         for eng, G, force, cols in ((0, 0, 0, 0), (4, 1, 0, 0), (4, 2, 0, 0), (4, 3, 0, 0), (6, 1, 0, 1), (6, 2, 0, 1),
                                     (6, 3, 0, 1), (6, 0, 1, 1), (6, 1, 0, 2), (6, 2, 0, 2), (6, 3, 0, 2), (6, 0, 1, 2),
-                                    (6, 1, 0, 3), (6, 2, 0, 3), (6, 0, 1, 3), (3, 0, 0, 0), (1, 0, 0, 0)):
+                                    (3, 0, 0, 0), (1, 0, 0, 0)):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_model_groups", G)
             _lib.set_option("score_h2s_force_exc", force)
@@ -535,7 +535,7 @@ def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):
     utts = [synth.draw_frames(spk[u % S], 260 + 11 * u, 31 + u, outlier_frac=0.01 if u % 2 else 0.0) for u in range(6)]
     X = np.concatenate(utts).astype(np.float64)
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
-    for compat, cols in ((True, 1), (False, 1), (True, 2), (False, 2), (True, 3), (False, 3)):
+    for compat, cols in ((True, 1), (False, 1), (True, 2), (False, 2)):
         want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
         _lib.set_option("score_engine", 0)
         _lib.set_option("score_h2s_shape", cols)
@@ -574,7 +574,7 @@ def test_cfg3_shape_k2048_map_speakers_vs_oracle(built_lib, oracle_built):
     ms = ModelSet(gm)
     _lib.set_option("score_engine", 4)      # sets of more than 65536 mixtures pack only the layout in force at creation
     ms4 = ModelSet(gm)
-    for eng, force, cols in ((0, 0, 1), (6, 1, 1), (0, 0, 2), (6, 1, 2), (0, 0, 3), (6, 1, 3), (4, 0, 0)):
+    for eng, force, cols in ((0, 0, 1), (6, 1, 1), (0, 0, 2), (6, 1, 2), (4, 0, 0)):
         _lib.set_option("score_engine", eng)
         _lib.set_option("score_h2s_force_exc", force)
         _lib.set_option("score_h2s_shape", cols)
