@@ -47,9 +47,8 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
     const int tid = threadIdx.x;
     const int K_pad = n_records * KB;
     float *slab = slabs + (size_t)blockIdx.x * K_pad * REC;
-    const int j = tid / DP;                    // phase-B role
-    const int d = tid - j * DP;
-    const bool roleB = tid < KB * DP;
+    // phase-B roles: thread -> (mixture j of the record, dim d); KB * DP of them (one per thread up to DP = 64,
+    // a short loop for the wide rows)
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t frame = (int64_t)tile * 256 + tid;
@@ -72,7 +71,7 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
         }
         for (int r = 0; r < n_records; r++) {
             __syncthreads();                   // previous phase B done with gs / rec_s (and xs on r == 0)
-            if (tid < REC) rec_s[tid] = params[(size_t)r * REC + tid];
+            for (int i = tid; i < REC; i += 256) rec_s[i] = params[(size_t)r * REC + i];
             __syncthreads();
             float acc[KB] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -94,7 +93,9 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
             gs[2][tid] = live ? __builtin_amdgcn_exp2f(cc.z - acc[2] - lse2) : 0.f;
             gs[3][tid] = live ? __builtin_amdgcn_exp2f(cc.w - acc[3] - lse2) : 0.f;
             __syncthreads();
-            if (roleB) {
+            for (int role = tid; role < KB * DP; role += 256) {
+                const int j = role / DP;
+                const int d = role - j * DP;
                 const int k = r * KB + j;
                 const float mu = mean_f32[(size_t)k * DP + d];
                 float sd = 0.f, sdd = 0.f, sn = 0.f;
@@ -140,7 +141,7 @@ static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const flo
 #define SR_CASE(V) case V: launch_stats<V>(X, n, dim, params, n_records, mean_f32, frame_ll, slabs, n_tiles, grid); break;
     switch (DP) {
         SR_CASE(8) SR_CASE(13) SR_CASE(16) SR_CASE(24) SR_CASE(26) SR_CASE(32) SR_CASE(34)
-        SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64)
+        SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64) SR_CASE(80) SR_CASE(96) SR_CASE(128)
         default: fail("no EM kernel for padded dim %d", DP);
     }
 #undef SR_CASE

@@ -88,12 +88,13 @@ std::string gmm_format_text(const GMM &g) {
     return s;
 }
 
-static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64};
+// 8..64: every engine; 80..128: the vector-ALU engine with one frame per lane (the matrix-core layouts stop at 64)
+static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64, 80, 96, 128};
 
 int pick_padded_dim(int dim) {
     for (int d : kDims)
         if (d >= dim) return d;
-    fail("feature dim %d > 64 is not instantiated in this build", dim);
+    fail("feature dim %d > %d is not instantiated in this build", dim, MAX_DIM);
 }
 
 PackedModels pack_models(const std::vector<const GMM *> &models) {

@@ -50,7 +50,9 @@ struct ChunkDesc {
     int32_t pad;
 };
 
-int pick_padded_dim(int dim);  // smallest instantiated kernel dim >= dim; throws if > 64
+constexpr int MAX_DIM = 128;        // largest feature dimension any kernel is instantiated for
+constexpr int MAX_MATRIX_DIM = 64;  // largest one the matrix-core engines are packed for
+int pick_padded_dim(int dim);  // smallest instantiated kernel dim >= dim; throws if > MAX_DIM
 
 struct PackedModels {
     int n_models = 0;

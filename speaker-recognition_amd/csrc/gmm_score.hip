@@ -39,7 +39,7 @@ struct ScoreArgs {
 
 
 __host__ __device__ constexpr int score_waves_per_eu(int dp, int f) {
-    return (dp * f + 44 <= 128) ? 4 : (dp * f + 44 <= 168) ? 3 : 2;
+    return dp > 64 ? 2 : (dp * f + 44 <= 128) ? 4 : (dp * f + 44 <= 168) ? 3 : 2;     // wide rows: LDS chunks of 20-33 KB
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -308,6 +308,7 @@ static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
 template <int DP>
 static void dispatch_f(const ScoreArgs &a, int F, bool pk, int n_tiles, int n_groups) {
     if (F == 1) return launch_score<DP, 1, false>(a, n_tiles, n_groups);
+    if constexpr (DP > 64) return launch_score<DP, 1, false>(a, n_tiles, n_groups);     // wide rows: one frame per lane
     if (F == 2) return pk ? launch_score<DP, 2, true>(a, n_tiles, n_groups)
                           : launch_score<DP, 2, false>(a, n_tiles, n_groups);
     if constexpr (DP <= 40) {
@@ -331,12 +332,15 @@ static void dispatch(const ScoreArgs &a, int DP, int F, bool pk, int n_tiles, in
         case 48: dispatch_f<48>(a, F, pk, n_tiles, n_groups); break;
         case 56: dispatch_f<56>(a, F, pk, n_tiles, n_groups); break;
         case 64: dispatch_f<64>(a, F, pk, n_tiles, n_groups); break;
+        case 80: dispatch_f<80>(a, F, pk, n_tiles, n_groups); break;
+        case 96: dispatch_f<96>(a, F, pk, n_tiles, n_groups); break;
+        case 128: dispatch_f<128>(a, F, pk, n_tiles, n_groups); break;
         default: fail("no scoring kernel for padded dim %d", DP);
     }
 }
 
 static int auto_frames_per_lane(const SRBatch &b, int dp) {
-    const int fmax = dp <= 40 ? 4 : 2;
+    const int fmax = dp <= 40 ? 4 : dp <= 64 ? 2 : 1;
     if (b.n_utt == 0) return 1;
     const double mean_len = (double)b.n_rows / b.n_utt;
     // pick the largest F whose tiles are mostly full
@@ -374,6 +378,7 @@ void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
     s.host = pack_models(models);
     size_t n_mix = 0;
     for (const GMM *g : models) n_mix += (size_t)g->nr_mixtures;
+    if (s.host.dim > MAX_MATRIX_DIM) return;                // wide rows: the vector-ALU engine only
     const bool small = n_mix <= ((size_t)1 << 16);          // every layout is a few MB at most
     const int forced = score_options().engine;
     const bool shared_ok = (int)models.size() >= SHARED_MIN_MODELS && models[0]->dim <= 48 &&   // <= 3 + 4 contraction steps: no scratch
@@ -503,6 +508,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     const bool use_mat = use_mfma || use_split || use_shared || use_h2s;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
+    if (DP > 64) F = 1;
     int FT = opt.mfma_ft;
     if (FT == 0) {
         // measured (scripts/tune_score.py over D in {13,26,34,39}, K in {64..2048}): one 32-frame column

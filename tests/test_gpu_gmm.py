@@ -246,14 +246,15 @@ def test_streaming_shape_short_windows(built_lib, oracle_built):
 
 
 def test_edge_shapes_and_errors(built_lib, oracle_built):
-    """K = 1, K not a multiple of the 4- / 32-mixture packing, the widest supported dim (64), dims
-    that need zero padding (D=5 -> 8, D=20 -> 24), zero-weight mixtures, many tiny utterances; dim > 64
-    and dim mismatches are refused with a message (no silent truncation)."""
+    """K = 1, K not a multiple of the 4- / 32-mixture packing, the widest dim of the matrix-core engines
+    (64), dims that need zero padding (D=5 -> 8, D=20 -> 24), wide rows (65, 84 = MFCC + LPC with both
+    deltas, 128: vector-ALU engine only), zero-weight mixtures, many tiny utterances; dim > 128 and dim
+    mismatches are refused with a message (no silent truncation)."""
     from speaker_recognition_amd import _lib, synth
     from speaker_recognition_amd.core import Batch, ModelSet
     from speaker_recognition_amd.pygmm import GMM
     go = oracle_built
-    for K, D in ((1, 13), (33, 39), (5, 64), (70, 5), (64, 20)):
+    for K, D in ((1, 13), (33, 39), (5, 64), (70, 5), (64, 20), (9, 65), (33, 84), (6, 128)):
         models = [synth.synth_gmm(K, D, 900 + K + s) for s in range(3)]
         if K >= 5:
             w, mu, sg = models[1]
@@ -264,10 +265,12 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
         utts = [synth.draw_frames(models[u % 3], n, 40 + u) for u, n in enumerate([3, 130, 257, 1])]
         X = np.concatenate(utts).astype(np.float64)
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
-        for eng in (1, 2, 3):
+        for eng in ((1, 2, 3) if D <= 64 else (0, 1)):
             _lib.set_option("score_engine", eng)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
             assert ll_close(fll, want) < TOL, (K, D, eng, ll_close(fll, want))
+            if D > 64:
+                assert "vector ALU" in _lib.last_score_kernel()
     _lib.set_option("score_engine", 0)
     # 3000 utterances of 1..7 frames
     m = synth.synth_gmm(8, 13, 5)
@@ -282,8 +285,8 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
     want0 = np.array([ll0[off[i]:off[i + 1]].sum() for i in range(3000)])
     assert np.max(np.abs(sums[:, 0] - want0) / np.maximum(1, np.abs(want0))) < 1e-5
     # refused shapes
-    with pytest.raises(_lib.SRError, match="64"):
-        ModelSet([GMM.from_arrays(*synth.synth_gmm(4, 65, 1))])
+    with pytest.raises(_lib.SRError, match="128"):
+        ModelSet([GMM.from_arrays(*synth.synth_gmm(4, 129, 1))])
     g13 = GMM.from_arrays(*synth.synth_gmm(4, 13, 1))
     with pytest.raises(_lib.SRError, match="dim"):
         g13.score(np.zeros((10, 12), np.float32))

@@ -9,12 +9,14 @@ from scipy.io import wavfile
 pytestmark = pytest.mark.gpu
 
 
-def test_em_and_map_iteration_vs_oracle(built_lib, oracle_built):
-    """One EM iteration and one MAP iteration from identical starting parameters."""
+@pytest.mark.parametrize("D", [13, 84])
+def test_em_and_map_iteration_vs_oracle(built_lib, oracle_built, D):
+    """One EM iteration and one MAP iteration from identical starting parameters (13 dims, and the wide rows of
+    MFCC + LPC with both deltas: 84 dims, vector-ALU engine and the looped statistics roles)."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.pygmm import GMM
     go = oracle_built
-    true = synth.synth_gmm(8, 13, 3)
+    true = synth.synth_gmm(8, D, 3)
     X = synth.draw_frames(true, 4000, 9)
     rng = np.random.default_rng(1)
     start = go.GMMParams(np.full(8, 1 / 8), true[1] + 0.2 * rng.standard_normal(true[1].shape),
