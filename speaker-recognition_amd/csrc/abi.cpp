@@ -17,6 +17,8 @@
 #include <sstream>
 
 namespace sr {
+void burn_reference_rand(int count);     // kmeans_init.hip
+void reference_rand_sample(int *out, int count);
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed);
 }  // namespace sr
@@ -153,6 +155,7 @@ GMM *load(const char *model_file) {
     ss << fin.rdbuf();
     auto g = std::make_unique<GMM>();
     gmm_parse_text(ss.str(), *g);
+    burn_reference_rand(g->nr_mixtures);    // GMM::load seeds one Random per Gaussian from libc rand() (gmm.cc:671-676, gmm.hh:44)
     return g.release();
     SR_CATCH(nullptr)
 }
@@ -752,5 +755,13 @@ int sr_set_option(const char *key, long value) {
 }
 
 const char *sr_last_score_kernel(void) { return last_score_kernel(); }
+
+int sr_reference_rand_sample(int *out, int count) {
+    SR_TRY
+    if (!out || count < 0) fail("bad arguments");
+    reference_rand_sample(out, count);
+    return 0;
+    SR_CATCH(-1)
+}
 
 }  // extern "C"

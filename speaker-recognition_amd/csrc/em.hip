@@ -1,8 +1,8 @@
 // em.hip -- EM / MAP training on the GPU: the engine behind train_model and
 // train_model_from_ubm (src/gmm/src/pygmm.cc:63-96).  Restates
 // GMMTrainerBaseline::train / ::iteration (src/gmm/src/gmm.cc:581-653, :439-531),
-// init_gaussians (:306-361, random-frame means; the k-means|| initialiser of kmeansII.cc is
-// replaced by a seeded k-means++ draw on the host -- initialisation is outside the hot path)
+// init_gaussians (:306-361) with both of its initialisers -- random frames and k-means|| -- in
+// kmeans_init.hip, drawing the reference's own random numbers,
 // and the MAP variant GMMUBMTrainerBaseline (src/gmm/src/gmmubm.cc:29-81: means only,
 // relevance 16, weights and sigmas copied from the UBM).
 //
@@ -19,7 +19,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <random>
 
 namespace sr {
 
@@ -147,68 +146,9 @@ static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const flo
 #undef SR_CASE
 }
 
-// ---- initialisation (host) ----
-static void init_from_data(GMM &g, const float *X, long n, int dim, const Parameter &param,
-                           std::mt19937_64 &rng) {
-    const int K = g.nr_mixtures;
-    g.dim = dim;
-    // data variance, unbiased, one sigma vector shared by all mixtures (gmm.cc:309-325,352-354)
-    std::vector<double> mean(dim, 0.0), var(dim, 0.0);
-    for (long i = 0; i < n; i++)
-        for (int d = 0; d < dim; d++) mean[d] += X[(size_t)i * dim + d];
-    for (int d = 0; d < dim; d++) mean[d] /= (double)n;
-    for (long i = 0; i < n; i++)
-        for (int d = 0; d < dim; d++) {
-            const double v = X[(size_t)i * dim + d] - mean[d];
-            var[d] += v * v;
-        }
-    g.sigma.assign((size_t)K * dim, 0.0);
-    for (int k = 0; k < K; k++)
-        for (int d = 0; d < dim; d++) g.sigma[(size_t)k * dim + d] = std::sqrt(var[d] / (double)(n - 1));
-    for (double s : g.sigma)
-        if (!(s > 0)) fail("training data has zero variance in some dimension");
-    g.mean.assign((size_t)K * dim, 0.0);
-    std::vector<long> pick(K);
-    if (param.init_with_kmeans > 0) {
-        // seeded k-means++ draw (D^2 sampling) on at most 20000 frames
-        const long m = std::min<long>(n, 20000);
-        std::vector<long> cand(m);
-        for (long i = 0; i < m; i++) cand[i] = (long)((double)i * n / m);
-        std::vector<double> d2(m, 1e300);
-        std::uniform_int_distribution<long> first(0, m - 1);
-        pick[0] = cand[first(rng)];
-        for (int k = 1; k <= K; k++) {
-            const float *c = X + (size_t)pick[k - 1] * dim;
-            double total = 0;
-            for (long i = 0; i < m; i++) {
-                const float *x = X + (size_t)cand[i] * dim;
-                double s = 0;
-                for (int d = 0; d < dim; d++) {
-                    const double v = (x[d] - c[d]) / g.sigma[d];
-                    s += v * v;
-                }
-                d2[i] = std::min(d2[i], s);
-                total += d2[i];
-            }
-            if (k == K) break;
-            std::uniform_real_distribution<double> u(0.0, total);
-            double r = u(rng), run = 0;
-            long chosen = m - 1;
-            for (long i = 0; i < m; i++) {
-                run += d2[i];
-                if (run >= r) { chosen = i; break; }
-            }
-            pick[k] = cand[chosen];
-        }
-    } else {
-        std::uniform_int_distribution<long> any(0, n - 1);   // gmm.cc:346-349
-        for (int k = 0; k < K; k++) pick[k] = any(rng);
-    }
-    for (int k = 0; k < K; k++)
-        for (int d = 0; d < dim; d++) g.mean[(size_t)k * dim + d] = X[(size_t)pick[k] * dim + d];
-    g.weights.assign(K, 1.0 / K);                            // gmm.cc:356-360
-    g.single.reset();
-}
+// initialisation: kmeans_init.hip (the reference's own draws, decision for decision)
+void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Parameter &param, long seed);
+void burn_reference_rand(int count);
 
 struct EmWorkspace {
     DevBuf<float> slabs, mean_f32;
@@ -221,7 +161,6 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     ensure_device();
     if (n <= 0) fail("X.size() == 0");                       // gmm.cc:582-586
     if (dim <= 0) fail("bad dimension %d", dim);
-    std::mt19937_64 rng(seed >= 0 ? (uint64_t)seed : std::random_device{}());
     if (param.verbosity >= 1)
         printf("nr_instance: %ld nr_dim: %d nr_mixture: %d min_covar: %f threshold: %f nr_iteration: %d "
                "init_with_kmeans: %d\n", n, dim, gmm.nr_mixtures, param.min_covar, param.threshold,
@@ -235,12 +174,13 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         gmm.mean = ubm->mean;
         gmm.sigma = ubm->sigma;
         gmm.single.reset();
+        if (seed < 0) burn_reference_rand(1 + gmm.nr_mixtures);   // the legacy symbol: keep libc's stream in step with the reference
     } else if (param.init_with_kmeans < 0 && gmm.trained() && gmm.dim == dim) {
         // extension: warm start from the handle's current parameters (no re-initialisation)
     } else {
         if (gmm.nr_mixtures <= 0) fail("GMM has no mixture count");
         if (n < 2) fail("need at least 2 frames to initialise the variances");
-        init_from_data(gmm, X, n, dim, param, rng);
+        init_gmm_like_reference(gmm, X, n, dim, param, seed);
     }
     const int K = gmm.nr_mixtures;
     const double relevance = 16.0;                           // gmm.hh:118-120

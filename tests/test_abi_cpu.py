@@ -137,3 +137,22 @@ def test_header_is_plain_c_and_example_links(built_lib, tmp_path):
     import ctypes
     if built_lib.sr_device_count() <= 0:
         assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_restated_glibc_rand_matches_libc(built_lib):
+    """The reference seeds every random draw of its trainer from libc rand() (random.hh:22-25); the HIP runtime
+    draws from the process-wide generator while it initialises, so the library carries glibc's algorithm itself
+    (csrc/kmeans_init.hip).  Its stream equals rand() of a fresh process."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from speaker_recognition_amd import _lib
+    n = 5000
+    buf = (C.c_int * n)()
+    L = _lib.lib()
+    L.sr_reference_rand_sample.argtypes = [C.POINTER(C.c_int), C.c_int]
+    assert L.sr_reference_rand_sample(buf, n) == 0
+    code = "import ctypes as C; l = C.CDLL('libc.so.6'); print(' '.join(str(l.rand()) for _ in range(%d)))" % n
+    want = [int(v) for v in subprocess.check_output([sys.executable, "-c", code]).split()]
+    assert list(buf) == want
+    assert want[0] == 1804289383

@@ -7,6 +7,7 @@ import pytest
 from scipy.io import wavfile
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("D", [13, 84])
@@ -173,6 +174,41 @@ def test_em_training_vs_reference_trainer_golden(built_lib, gmm_golden):
         assert np.max(np.abs(w - g["em%d_w" % iters])) < 1e-5, iters
         assert np.max(np.abs(mu - g["em%d_mean" % iters])) < 1e-4, (iters, np.max(np.abs(mu - g["em%d_mean" % iters])))
         assert np.max(np.abs(sg - g["em%d_sigma" % iters]) / g["em%d_sigma" % iters]) < 5e-4, iters
+
+
+def test_train_from_scratch_vs_reference_trainer_golden(built_lib, tmp_path):
+    """train_model FROM SCRATCH through the legacy symbol, in a fresh process as the goldens were made with the
+    reference's compiled library (tests/golden/make_init_golden.py): both of the reference's initialisers -- K random
+    frames and k-means|| (oversampling rounds, weighted k-means++, weighted Lloyd, Lloyd on the full data) -- draw
+    the reference's own random numbers (libc rand() and the engines it seeds), also after a load() whose Gaussians
+    consumed 32 draws; the models after EM agree to the digits the text format keeps."""
+    import hashlib
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_init_golden import case_data
+    from oracle import gmm_oracle as go
+    g = np.load(os.path.join(ROOT, "tests", "golden", "init_golden.npz"))
+    pre = tmp_path / "preload.model"
+    pre.write_text(str(g["preload_text"]))
+    helper = os.path.join(ROOT, "tests", "golden", "_train_proc.py")
+    for name in g["cases"]:
+        K, iters, km, conc, preload = (int(v) for v in g[name + "_args"])
+        want_mean = g[name + "_mean"]
+        D = want_mean.shape[1]
+        n = {"rand8x13": 3000, "km8x13": 3000, "km16x20_after_load": 5000, "rand5x39_after_load": 2000, "km32x39": 20000}[str(name)]
+        X = case_data(K, D, n, 300 + K + D)
+        assert hashlib.sha256(X.astype(np.float32).tobytes()).hexdigest() == str(g[name + "_X_sha256"]), "input regenerated differently"
+        xp, out = str(tmp_path / "X.npy"), str(tmp_path / ("%s.model" % name))
+        np.save(xp, X)
+        cmd = [sys.executable, helper, "--lib", "hip", xp, str(K), str(iters), str(km), str(conc), out]
+        if preload:
+            cmd.append(str(pre))
+        subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+        got = go.parse_model_text(open(out).read())
+        assert np.max(np.abs(got.weights - g[name + "_w"])) < 2e-5, name
+        assert np.max(np.abs(got.mean - want_mean)) < 2e-4, (name, np.max(np.abs(got.mean - want_mean)))
+        assert np.max(np.abs(got.sigma - g[name + "_sigma"]) / g[name + "_sigma"]) < 1e-3, name
 
 
 def test_serving_stream_double_buffered_equals_synchronous(built_lib):
