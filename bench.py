@@ -378,7 +378,7 @@ def block_trained(_lib, ex, base):
     test = [np.rint(base[s] * g).astype(np.int16) for g in (0.55, 0.9) for s in range(n_spk)]
     sums, arg = ex.predict_batch(ms, Batch.from_pcm(test), nd=ND)
     best = np.argmax(sums[:, 1:], axis=1)
-    return {"workload": "EM (12 iterations, k-means++ start) of a %d-mixture UBM on %d frames + means-only MAP of %d speakers, on the device; "
+    return {"workload": "EM (12 iterations, k-means|| start as the reference's) of a %d-mixture UBM on %d frames + means-only MAP of %d speakers, on the device; "
                         "then %d held-out utterances identified" % (K, n_spk * 1000, n_spk, len(test)),
             "train_s": t_train, "scoring_kernel": _lib.last_score_kernel(), "model_set": ms.info(),
             "identification_accuracy": float(np.mean(best == np.arange(len(test)) % n_spk)),

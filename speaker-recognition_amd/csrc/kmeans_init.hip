@@ -208,9 +208,15 @@ void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::ve
             block_sum[b] = s;
         };
         {
+            // the blocks are independent; a few host threads share them (the reference runs one task per block)
+            const int n_threads = std::max(1, std::min({n_blocks, (int)std::thread::hardware_concurrency(), 16}));
+            auto run = [&](int t) { for (int b = t; b < n_blocks; b += n_threads) work(b); };
             std::vector<std::thread> th;
-            for (int b = 1; b < n_blocks; b++) th.emplace_back(work, b);
-            work(0);
+            if (n > 20000)
+                for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
+            else
+                for (int t = 1; t < n_threads; t++) run(t);          // small inputs: not worth a thread
+            run(0);
             for (auto &t : th) t.join();
         }
         double sum = 0;
@@ -255,8 +261,8 @@ void lloyd_weighted(const std::vector<double> &P, const std::vector<double> &wei
     const int n_blocks = (np + block - 1) / block;
     std::vector<std::vector<double>> buf((size_t)n_blocks, std::vector<double>((size_t)K * dim)), csz((size_t)n_blocks, std::vector<double>((size_t)K));
     for (int iter = 0; iter < KM_MAX_ITER; iter++) {
-        double sum = 0;
-        for (int b = 0; b < n_blocks; b++) {
+        std::vector<double> block_sum((size_t)n_blocks, 0.0);
+        auto work = [&](int b) {
             std::fill(buf[b].begin(), buf[b].end(), 0.0);
             std::fill(csz[b].begin(), csz[b].end(), 0.0);
             double s = 0;
@@ -279,8 +285,21 @@ void lloyd_weighted(const std::vector<double> &P, const std::vector<double> &wei
                 }
                 s += mind;
             }
-            sum += s;
+            block_sum[b] = s;
+        };
+        {
+            const int n_threads = std::max(1, std::min({n_blocks, (int)std::thread::hardware_concurrency(), 16}));
+            auto run = [&](int t) { for (int b = t; b < n_blocks; b += n_threads) work(b); };
+            std::vector<std::thread> th;
+            if ((size_t)np * K * dim > ((size_t)1 << 22))
+                for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
+            else
+                for (int t = 1; t < n_threads; t++) run(t);
+            run(0);
+            for (auto &t : th) t.join();
         }
+        double sum = 0;
+        for (int b = 0; b < n_blocks; b++) sum += block_sum[b];
         if (sum < best) {
             best = sum;
             best_centroids = centroids;
