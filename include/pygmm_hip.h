@@ -114,7 +114,10 @@ int sr_modelset_size(SRModelSet *set);
  * ((mu_kd - centre_d) / sigma_kd)^2 (the cancellation the expanded quadratic form has to survive in
  * fp32), [1] = dead fraction of the 32-mixture tiles, [2] = largest per-dimension sigma ratio,
  * [3] = largest scaled coefficient of the fp16 layouts, [4] = 1 if sigma and weights are shared,
- * [5] = models, [6] = device. */
+ * [5] = models, [6] = device, [7] = mixtures (of the largest model) that the hybrid form sends to the
+ * direct-form vector engine because the expanded form would cancel for them (0: no hybrid form; the other
+ * entries then describe the whole set).  A set that is ill conditioned because of a few mixtures only -- collapsed
+ * components at the sigma floor -- is scored as two sub-sets whose per-frame values are merged by a log-add-exp. */
 int sr_modelset_info(SRModelSet *set, double *out8);
 int sr_modelset_dim(SRModelSet *set);
 

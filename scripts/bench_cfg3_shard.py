@@ -29,6 +29,14 @@ def main():
     t0 = time.time()
     ubm = synth.synth_gmm(K, D, 99)
     w, mean, sigma = ubm
+    spoil = int(os.environ.get("CFG3_SPOIL", 0))      # that many UBM mixtures collapsed (sigma 0.04) and far from the centre: an ill-conditioned set
+    if spoil:
+        mean, sigma = mean.copy(), sigma.copy()
+        rng = np.random.default_rng(1)
+        for k in rng.choice(K, size=spoil, replace=False):
+            sigma[k] = 0.04
+            mean[k] = mean.mean(0) + 2.0 * rng.choice([-1.0, 1.0], size=D)
+        ubm = (w, mean, sigma)
     nk = w * 40.0 * K
     alpha = (nk / (nk + 16.0))[:, None]
     spk = []

@@ -130,7 +130,8 @@ class ModelSet:
         out = np.zeros(8)
         check(lib().sr_modelset_info(self._h, _lib.as_dp(out)), "sr_modelset_info")
         return {"amp": out[0], "pad_waste": out[1], "sigma_ratio": out[2], "coef_max": out[3],
-                "shared_sigma": bool(out[4]), "models": int(out[5]), "device": int(out[6])}
+                "shared_sigma": bool(out[4]), "models": int(out[5]), "device": int(out[6]),
+                "hybrid_vector_mixtures": int(out[7])}
 
     def score(self, feats: Batch, frame_ll: bool = False, clamp_compat: bool = True):
         """-> (sums[U, S] float64, argmax[U] int32[, frame_ll[S, n] float32])."""

@@ -364,6 +364,7 @@ int sr_modelset_info(SRModelSet *set, double *out8) {
     out8[4] = shared ? 1.0 : 0.0;
     out8[5] = set->host.n_models;
     out8[6] = set->device;
+    out8[7] = set->hy_good ? set->hy_bad_mixtures : 0;      // hybrid form: mixtures (of the largest model) on the vector engine
     return 0;
     SR_CATCH(-1)
 }

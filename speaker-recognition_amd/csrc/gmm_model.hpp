@@ -196,5 +196,10 @@ struct SRModelSet {
     sr::DevBuf<float> d_h2s_center, d_h2s_scale, d_h2s_ref_center, d_h2s_ref_scale;
     sr::DevBuf<sr::ChunkDesc> d_h2s_ref_chunks;
     sr::DevBuf<int> d_h2s_ref_gcb;
+    // Hybrid form of an ill-conditioned set (score.hpp): the mixtures whose expanded form would cancel in fp32 (tight and
+    // far from the centre) as one sub-set on the direct-form vector engine, the rest as another on the matrix cores;
+    // the two per-frame log-likelihoods are merged by a log-add-exp.  Empty unless the set needed it.
+    std::unique_ptr<SRModelSet> hy_good, hy_bad;
+    int hy_bad_mixtures = 0;         // mixtures of the set's largest model that went to the vector engine
     int device = -1;
 };

@@ -270,6 +270,41 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
     if (threadIdx.x == 0) argmax[u] = (te > tb && si[0] != 0x7fffffff) ? si[0] : -1;
 }
 
+// Hybrid sets: LL = ln(exp(LL_a) + exp(LL_b)) per frame and model, the per-tile float64 sums for gmm_finalize_kernel, and
+// (optionally) the merged per-frame values.  With the reference's clamp on, a part whose mixtures all fell below
+// DBL_MIN reports ln(1e-15) (lse.hpp): both -> ln(1e-15); one -> the other part alone, as the reference's linear-domain
+// sum of the surviving terms.
+__global__ __launch_bounds__(256)
+void gmm_merge_kernel(const float *__restrict__ A, const float *__restrict__ B, const TileDesc *__restrict__ tiles,
+                      int n_models, int64_t n_frames, int clamp, double *__restrict__ partial, float *__restrict__ out) {
+    __shared__ double part[4];
+    const TileDesc tile = tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool valid = tid < tile.count;
+    const int64_t row = tile.start + (valid ? tid : 0);
+    for (int s = 0; s < n_models; s++) {
+        double mine = 0.0;
+        if (valid) {
+            const float a = A[(int64_t)s * n_frames + row], b = B[(int64_t)s * n_frames + row];
+            float ll;
+            const bool sa = clamp && a == LSE_LN_1E_15, sb = clamp && b == LSE_LN_1E_15;
+            if (sa || sb) {
+                ll = sa ? b : a;                      // (both: ln 1e-15)
+            } else {
+                const float hi = fmaxf(a, b), lo = fminf(a, b);
+                ll = hi + LSE_LN2 * log2f(1.0f + __builtin_amdgcn_exp2f((lo - hi) * 1.4426950408889634f));
+            }
+            if (out) out[(int64_t)s * n_frames + row] = ll;
+            mine = (double)ll;
+        }
+        mine = wave_sum_f64(mine);
+        __syncthreads();                              // the previous model's reader is done with part[]
+        if (lane == 0) part[wave] = mine;
+        __syncthreads();
+        if (tid == 0) partial[(int64_t)blockIdx.x * n_models + s] = ((part[0] + part[1]) + part[2]) + part[3];
+    }
+}
+
 // ---------------- host side ----------------
 
 struct LastKernel {
@@ -294,6 +329,7 @@ struct ScoreWorkspace {
     DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
     DevBuf<double> ref_partial;
     DevBuf<int> exc_list, exc_count;     // ... and its (tile, block) exception list
+    DevBuf<float> hy_a, hy_b;            // hybrid sets: per-frame LL of the two sub-sets
 };
 static ScoreWorkspace &ws() { return per_device<ScoreWorkspace>(); }   // one per device, leaked on purpose
 
@@ -358,6 +394,8 @@ void upload_model_set(SRModelSet &s) {
     s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
     sync_stream();
     s.device = ctx().device;
+    if (s.hy_good) upload_model_set(*s.hy_good);
+    if (s.hy_bad) upload_model_set(*s.hy_bad);
 }
 
 // The expanded-form (matrix-core) layout is packed lazily: only sets that take that engine pay.
@@ -374,7 +412,112 @@ static bool h2s_ok(const PackedH2Shared &p) {
            p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
 }
 
+static bool f16_ok(const PackedSplit &p);
+static bool f16_ok_fwd(const PackedSplit &p) { return f16_ok(p); }
+
+// amp_k = sum_d ((mu_kd - centre_d) / sigma_kd)^2 with the centre the matrix-core layouts use (mean of all means)
+static std::vector<std::vector<double>> mixture_amps(const std::vector<const GMM *> &models) {
+    const int dim = models[0]->dim;
+    std::vector<double> centre(dim, 0.0);
+    size_t cnt = 0;
+    for (const GMM *g : models) {
+        for (int k = 0; k < g->nr_mixtures; k++)
+            for (int d = 0; d < dim; d++) centre[d] += g->mean[(size_t)k * dim + d];
+        cnt += (size_t)g->nr_mixtures;
+    }
+    for (int d = 0; d < dim; d++) centre[d] = (double)(float)(centre[d] / (double)cnt);
+    std::vector<std::vector<double>> amp(models.size());
+    for (size_t s = 0; s < models.size(); s++) {
+        const GMM &g = *models[s];
+        amp[s].assign(g.nr_mixtures, 0.0);
+        for (int k = 0; k < g.nr_mixtures; k++)
+            for (int d = 0; d < dim; d++) {
+                const double v = (g.mean[(size_t)k * dim + d] - centre[d]) / g.sigma[(size_t)k * dim + d];
+                amp[s][k] += v * v;
+            }
+    }
+    return amp;
+}
+
+static void pack_model_set_plain(SRModelSet &s, const std::vector<const GMM *> &models);
+
+// true when the dispatcher would send the (plainly packed) set to the vector engine because of its conditioning alone
+static bool ill_conditioned_only(const SRModelSet &s) {
+    const bool any_ok = (h2s_ok(s.h2s)) ||
+                        (!s.shared.params.empty() && s.shared.amp <= MFMA_MAX_AMP && s.shared.pad_waste <= MFMA_MAX_PAD_WASTE) ||
+                        f16_ok_fwd(s.h2) ||
+                        (!s.bx3.params.empty() && s.bx3.amp <= MFMA_MAX_AMP && s.bx3.pad_waste <= MFMA_MAX_PAD_WASTE);
+    if (any_ok) return false;
+    const double amp = !s.bx3.params.empty() ? s.bx3.amp : !s.shared.params.empty() ? s.shared.amp : 0.0;
+    const double waste = !s.bx3.params.empty() ? s.bx3.pad_waste : !s.shared.params.empty() ? s.shared.pad_waste : 1.0;
+    return amp > MFMA_MAX_AMP && waste <= MFMA_MAX_PAD_WASTE;
+}
+
 void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models) {
+    pack_model_set_plain(s, models);
+    if (score_options().engine != 0 || s.host.dim > MAX_MATRIX_DIM || !ill_conditioned_only(s)) return;
+    // ---- hybrid form: the few offending mixtures on the vector engine, the rest on the matrix cores ----
+    const int dim = models[0]->dim;
+    const auto amp = mixture_amps(models);
+    const bool shared = models.size() > 1 && models_share_sigma_and_weights(models);
+    std::vector<std::vector<char>> bad(models.size());
+    for (size_t m = 0; m < models.size(); m++) {
+        bad[m].assign(models[m]->nr_mixtures, 0);
+        for (int k = 0; k < models[m]->nr_mixtures; k++) bad[m][k] = amp[m][k] > 0.5 * F16_MAX_AMP;     // margin: the centre moves
+    }
+    if (shared)     // keep the sub-sets shared-sigma: the same mixtures leave every model
+        for (int k = 0; k < models[0]->nr_mixtures; k++) {
+            char any = 0;
+            for (size_t m = 0; m < models.size(); m++) any |= bad[m][k];
+            for (size_t m = 0; m < models.size(); m++) bad[m][k] = any;
+        }
+    size_t n_bad = 0, n_all = 0;
+    int worst = 0;
+    for (size_t m = 0; m < models.size(); m++) {
+        int b = 0;
+        for (char c : bad[m]) b += c;
+        if (b == models[m]->nr_mixtures) return;             // a model made of such mixtures only: nothing to gain
+        n_bad += (size_t)b;
+        n_all += (size_t)models[m]->nr_mixtures;
+        worst = std::max(worst, b);
+    }
+    if (n_bad == 0 || (double)n_bad > HYBRID_MAX_BAD_FRACTION * (double)n_all) return;
+    std::vector<GMM> good_m(models.size()), bad_m(models.size());
+    for (size_t m = 0; m < models.size(); m++) {
+        const GMM &g = *models[m];
+        for (int side = 0; side < 2; side++) {
+            GMM &o = side ? bad_m[m] : good_m[m];
+            o.dim = dim;
+            for (int k = 0; k < g.nr_mixtures; k++) {
+                if ((bad[m][k] != 0) != (side != 0)) continue;
+                o.weights.push_back(g.weights[k]);            // un-normalised on purpose: the two parts add up to the model
+                o.mean.insert(o.mean.end(), g.mean.begin() + (size_t)k * dim, g.mean.begin() + (size_t)(k + 1) * dim);
+                o.sigma.insert(o.sigma.end(), g.sigma.begin() + (size_t)k * dim, g.sigma.begin() + (size_t)(k + 1) * dim);
+            }
+            if (o.weights.empty()) {                          // a model without such mixtures: one dead mixture (weight 0 adds nothing)
+                o.weights.push_back(0.0);
+                o.mean.insert(o.mean.end(), g.mean.begin(), g.mean.begin() + dim);
+                o.sigma.insert(o.sigma.end(), g.sigma.begin(), g.sigma.begin() + dim);
+            }
+            o.nr_mixtures = (int)o.weights.size();
+        }
+    }
+    std::vector<const GMM *> gp, bp;
+    for (size_t m = 0; m < models.size(); m++) {
+        gp.push_back(&good_m[m]);
+        bp.push_back(&bad_m[m]);
+    }
+    auto good = std::make_unique<SRModelSet>();
+    pack_model_set_plain(*good, gp);
+    if (ill_conditioned_only(*good)) return;                  // still ill conditioned without them: stay on the vector engine
+    auto badset = std::make_unique<SRModelSet>();
+    badset->host = pack_models(bp);                           // vector layout only
+    s.hy_good = std::move(good);
+    s.hy_bad = std::move(badset);
+    s.hy_bad_mixtures = worst;
+}
+
+static void pack_model_set_plain(SRModelSet &s, const std::vector<const GMM *> &models) {
     s.host = pack_models(models);
     size_t n_mix = 0;
     for (const GMM *g : models) n_mix += (size_t)g->nr_mixtures;
@@ -446,7 +589,9 @@ static void ensure_bx3_layout(SRModelSet &s) {
     sync_stream();
 }
 
-ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags) {
+static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags, float *frame_ll_dst);
+
+ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags, float *frame_ll_dst) {
     ensure_device();
     if (feat.kind != SRBatch::FEATURES) fail("scoring needs a feature batch");
     feat.bind_device();
@@ -454,6 +599,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         fail("model set lives on device %d, the calling thread is on device %d", set.device, ctx().device);
     if (feat.dim != set.host.dim)
         fail("feature dim %d != model dim %d", feat.dim, set.host.dim);
+    if (set.hy_good && score_options().engine == 0) return score_hybrid(set, feat, want_frame_ll, flags, frame_ll_dst);
     const int S = set.host.n_models;
     const int DP = set.host.dp;
     const ScoreOptions &opt = score_options();
@@ -535,6 +681,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 
     auto &w = ws();
     bool used_oor = false;
+    if (frame_ll_dst) want_frame_ll = true;
     w.sums.ensure((size_t)std::max(1, U) * S);
     w.argmax.ensure((size_t)std::max(1, U));
     if (tt.n_tiles > 0) {
@@ -571,7 +718,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             uploaded = true;
         }
         w.partial.ensure((size_t)tt.n_tiles * S * ((use_split || use_shared || use_h2s) ? 1 : 4));
-        if (want_frame_ll) w.frame_ll.ensure((size_t)S * feat.n_rows);
+        if (want_frame_ll && !frame_ll_dst) w.frame_ll.ensure((size_t)S * feat.n_rows);
+        float *const fll = !want_frame_ll ? nullptr : frame_ll_dst ? frame_ll_dst : w.frame_ll.p;
 
         if (use_h2s) {
             ensure_h2s_layout(set);
@@ -621,7 +769,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.l_desc = set.d_h2s_ldesc.p;
             a.ref_ll = w.ref_ll.p;
             a.partial = w.partial.p;
-            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.frame_ll = fll;
             a.oor_flag = w.oor.p;
             a.exc_list = w.exc_list.p;
             a.exc_count = w.exc_count.p;
@@ -653,7 +801,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.group_block_begin = w.group_chunk_begin.p;
             a.center = set.d_shared_center.p;
             a.partial = w.partial.p;
-            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.frame_ll = fll;
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;
@@ -685,7 +833,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 used_oor = true;
             }
             a.partial = w.partial.p;
-            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.frame_ll = fll;
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;
@@ -713,7 +861,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.chunks = set.d_chunks.p;
             a.group_chunk_begin = w.group_chunk_begin.p;
             a.partial = w.partial.p;
-            a.frame_ll = want_frame_ll ? w.frame_ll.p : nullptr;
+            a.frame_ll = fll;
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;
@@ -735,8 +883,52 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     ScoreResult r;
     r.d_sums = w.sums.p;
     r.d_argmax = w.argmax.p;
-    r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? w.frame_ll.p : nullptr;
+    r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? (frame_ll_dst ? frame_ll_dst : w.frame_ll.p) : nullptr;
     r.d_oor = used_oor ? w.oor.p : nullptr;
+    return r;
+}
+
+// The two sub-sets of a hybrid set, then the merge (gmm_merge_kernel) and the usual finalize.
+static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags, float *frame_ll_dst) {
+    auto &w = ws();
+    const int S = set.host.n_models;
+    const int U = feat.n_utt;
+    const size_t n = (size_t)S * (size_t)std::max<int64_t>(1, feat.n_rows);
+    w.hy_a.ensure(n);
+    w.hy_b.ensure(n);
+    // the ill-conditioned mixtures first (vector engine: the only layout that sub-set carries), then the rest -- so
+    // that the fp16 engines' saturation flag of the second call is the one left in the workspace
+    score_device(*set.hy_bad, feat, true, flags, w.hy_b.p);
+    const ScoreResult good = score_device(*set.hy_good, feat, true, flags, w.hy_a.p);
+    char good_name[sizeof(LastKernel::name)];
+    snprintf(good_name, sizeof(good_name), "%s", g_last_kernel);
+    TileTable &tt = feat.tiles_for(256);
+    w.sums.ensure((size_t)std::max(1, U) * S);
+    w.argmax.ensure((size_t)std::max(1, U));
+    float *out = nullptr;
+    if (want_frame_ll || frame_ll_dst) {
+        if (!frame_ll_dst) w.frame_ll.ensure(n);
+        out = frame_ll_dst ? frame_ll_dst : w.frame_ll.p;
+    }
+    if (tt.n_tiles > 0) {
+        w.partial.ensure((size_t)tt.n_tiles * S);
+        ScopedKernelTimer t(T_SCORE);
+        hipLaunchKernelGGL(gmm_merge_kernel, dim3((unsigned)tt.n_tiles), dim3(256), 0, ctx().stream, w.hy_a.p, w.hy_b.p,
+                           tt.d_tiles.p, S, feat.n_rows, (flags & 1) ? 1 : 0, w.partial.p, out);
+        SR_HIP(hipGetLastError());
+    }
+    if (U > 0) {
+        ScopedKernelTimer t(T_FINALIZE);
+        hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream, w.partial.p,
+                           tt.d_utt_tile_begin.p, S, 1, w.sums.p, w.argmax.p);
+        SR_HIP(hipGetLastError());
+    }
+    snprintf(g_last_kernel, sizeof(LastKernel::name), "hybrid: %d ill-conditioned mixtures on the vector ALU + %.150s", set.hy_bad_mixtures, good_name);
+    ScoreResult r;
+    r.d_sums = w.sums.p;
+    r.d_argmax = w.argmax.p;
+    r.d_frame_ll = (out && tt.n_tiles > 0) ? out : nullptr;
+    r.d_oor = good.d_oor;
     return r;
 }
 

@@ -31,6 +31,10 @@ constexpr double MFMA_MAX_PAD_WASTE = 0.25;
 // moderate, every dimension's sigmas stay within a factor the gradual-underflow error analysis
 // covers, and the scaled coefficients fit fp16.
 constexpr double F16_MAX_AMP = 1000.0;
+// Hybrid form: a set the expanded form is ill conditioned for (amp above the limits) because of FEW of its mixtures
+// -- collapsed components at the sigma floor, outlier catchers -- is cut in two: those mixtures (at most
+// HYBRID_MAX_BAD_FRACTION of them) run on the direct-form vector engine, the rest on the matrix cores.
+constexpr double HYBRID_MAX_BAD_FRACTION = 0.25;
 constexpr double F16_MAX_SIGMA_RATIO = 256.0;
 constexpr double F16_MAX_COEF = 30000.0;
 // internal scoring flag (beside SR_CLAMP_COMPAT): keep to the fp32-grade engines (EM, serving stream)
@@ -107,7 +111,8 @@ struct ScoreResult {
 };
 
 // Scores every utterance of `feat` against every model of `set`; leaves results on the device.
-ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags);
+// `frame_ll_dst`: device buffer [S][n_frames] the per-frame values go to instead of the workspace's own.
+ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int flags, float *frame_ll_dst = nullptr);
 // Same, then copies what the caller asked for to host memory.
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags);

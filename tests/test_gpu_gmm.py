@@ -588,3 +588,61 @@ def test_cfg3_shape_k2048_map_speakers_vs_oracle(built_lib, oracle_built):
             w = want[:, off[u]:off[u + 1]].sum(axis=1)
             assert np.max(np.abs(sums[u] - w) / np.abs(w)) < 2e-5, (eng, u)
             assert arg[u] == int(np.argmax(w)), (eng, u)
+
+
+def test_hybrid_form_of_ill_conditioned_sets(built_lib, oracle_built):
+    """A set whose expanded form would cancel in fp32 because of a FEW mixtures (collapsed components at a tiny sigma,
+    far from the centre: amp = sum_d (mu'/sigma)^2 in the tens of thousands) is cut in two: those mixtures on the
+    direct-form vector engine, the rest on the matrix cores, the per-frame values merged by a log-add-exp.  Per-frame
+    LL (also of frames that belong to the tight mixtures, and of +60 sigma outliers under the reference's clamp), sums
+    and argmax against the oracle -- for independent models and for a UBM + MAP speakers (the rest takes the
+    shared-sigma split-fp16 engine); forcing the vector engine gives the same answers; sets made of such mixtures
+    only stay on the vector engine."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+
+    def spoil(model, ks, seed):
+        w, mu, sg = (a.copy() for a in model)
+        rng = np.random.default_rng(seed)
+        for k in ks:
+            sg[k] = 0.04 + 0.01 * rng.random(sg.shape[1])
+            mu[k] = np.round(mu.mean(0) + 2.0 * rng.choice([-1.0, 1.0], size=mu.shape[1]), 4)
+        return w, mu, np.round(sg, 5)
+
+    K, D = 64, 20
+    indep = [spoil(synth.synth_gmm(K, D, 4100 + s), (3, 40 + s), s) for s in range(5)]
+    ubm = spoil(synth.synth_gmm(K, D, 4200), (5, 33), 77)
+    shared = [ubm] + [synth.synth_map_speaker(ubm, 4300 + s) for s in range(14)]
+    for models, expect in ((indep, "split_kernel"), (shared, "h2s")):
+        utts = [synth.draw_frames(models[u % len(models)], n, 70 + u, outlier_frac=0.01 if u % 2 else 0.0)
+                for u, n in enumerate([300, 1, 257, 40, 513])]
+        X = np.concatenate(utts).astype(np.float64)
+        off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        assert ms.info()["hybrid_vector_mixtures"] == 2
+        for compat in (True, False):
+            want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
+            _lib.set_option("score_engine", 0)
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+            name = _lib.last_score_kernel()
+            assert name.startswith("hybrid") and expect in name, name
+            assert ll_close(fll, want) < TOL, (expect, compat, ll_close(fll, want))
+            again = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+            assert np.array_equal(again[0], sums) and np.array_equal(again[2], fll)
+            for u in range(len(utts)):
+                w_ = want[:, off[u]:off[u + 1]].sum(axis=1)
+                assert np.max(np.abs(sums[u] - w_) / np.maximum(1.0, np.abs(w_))) < 2e-5
+                assert arg[u] == int(np.argmax(w_))
+            _lib.set_option("score_engine", 1)
+            s1, a1, f1 = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+            assert "vector ALU" in _lib.last_score_kernel() and not _lib.last_score_kernel().startswith("hybrid")
+            assert np.array_equal(a1, arg) and ll_close(f1, want) < TOL
+        _lib.set_option("score_engine", 0)
+    # every mixture tight and far: nothing to gain, the whole set stays on the vector engine
+    allbad = [spoil(synth.synth_gmm(8, D, 4400 + s), range(8), s) for s in range(3)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in allbad])
+    assert ms.info()["hybrid_vector_mixtures"] == 0
+    ms.score(Batch.from_features([synth.draw_frames(allbad[0], 100, 1)]))
+    assert "vector ALU" in _lib.last_score_kernel() and not _lib.last_score_kernel().startswith("hybrid")
