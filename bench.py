@@ -168,6 +168,9 @@ def score_roofline(kname, n_frames, S, K, D, avg_s, hbm_measured):
         peak, note = FP32_PEAK_TFLOPS, "compute-bound; fp32 engine: peak = fp32 MFMA = fp32 vector peak"
     r = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0.0,
          "note": note, "avg_launch_ms": 1e3 * avg_s,
+         # long grids of the shared-sigma kernel are cut into several launches per pass (DESIGN.md 2.1 point 4): rocprofv3's
+         # per-call average is avg_launch_ms / launches_per_pass
+         "launches_per_pass": int(kname.split("[")[1].split()[0]) if "launches per pass" in kname else 1,
          "traffic": None, "traffic_note": "PMC passes are separate runs: see profiles/ (FETCH_SIZE x2 + WRITE_SIZE per launch)",
          "achieved_over_fp32_peak": ach / FP32_PEAK_TFLOPS,
          "hbm": {"achieved_GBps": byts / avg_s / 1e9 if avg_s > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS,
@@ -248,6 +251,56 @@ def block_cfg1(_lib, ex, base, hbm, preq):
             "roofline": score_roofline(kname, n_frames, CFG1_MODELS, CFG1_MIX, DIM, kt["gmm_score"]["ms_per_step"] * 1e-3, hbm),
             "mfcc_roofline": mfcc_roofline(CFG1_UTTS * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
             "parity": None}
+
+
+def block_legacy(_lib):
+    """The reference's own calling pattern through the ten legacy symbols (gmmset.py:95-99, pygmm.py:120-132): one
+    `score_all(gmm_s, double **X, n, dim, concurrency)` per speaker and utterance, rows handed over as a pointer array
+    of float64 rows.  The library keeps the last uploaded utterance on the device (fp32, keyed by a hash of its
+    contents), so the S calls of an utterance upload it once.  Timed beside the fused call on the same work."""
+    import ctypes as C
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    raw = [synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s) for s in range(CFG1_MODELS)]
+    gm = [GMM.from_arrays(*m) for m in raw]
+    utts = [np.ascontiguousarray(synth.draw_frames(raw[u], FRAMES_PER_UTT, 9000 + u), dtype=np.float64) for u in range(8)]
+    L = C.CDLL(_lib.LIB_PATH)                       # the bare C ABI, bound the way the reference binds it
+    pp = C.POINTER(C.POINTER(C.c_double))
+    L.score_all.restype = C.c_double
+    L.score_all.argtypes = [C.c_void_p, pp, C.c_int, C.c_int, C.c_int]
+
+    def rows(X):
+        arr = (C.POINTER(C.c_double) * len(X))()
+        base = X.ctypes.data
+        for i in range(len(X)):
+            arr[i] = C.cast(base + i * X.shape[1] * 8, C.POINTER(C.c_double))
+        return arr
+    ptrs = [rows(X) for X in utts]
+
+    def legacy():
+        out = np.empty((len(utts), len(gm)))
+        for u, X in enumerate(utts):
+            for s, g in enumerate(gm):
+                out[u, s] = L.score_all(g.gmm, ptrs[u], len(X), DIM, 1)
+        return out
+    legacy()
+    t0 = time.perf_counter()
+    got = legacy()
+    t_legacy = time.perf_counter() - t0
+    ms = ModelSet(gm)
+    fb = Batch.from_features([u.astype(np.float32) for u in utts])
+    ms.score(fb)
+    t0 = time.perf_counter()
+    sums, arg = ms.score(fb)
+    t_fused = time.perf_counter() - t0
+    n = len(utts) * FRAMES_PER_UTT
+    return {"workload": "%d utterances x %d frames x %d dims against %d models x %d mixtures: one legacy score_all(double **) call per "
+                        "(utterance, speaker) as gmmset.py:95-99, vs one fused sr_score_batch_set call" % (len(utts), FRAMES_PER_UTT, DIM, len(gm), CFG1_MIX),
+            "legacy_calls": len(utts) * len(gm), "legacy_s": t_legacy, "legacy_us_per_call": 1e6 * t_legacy / (len(utts) * len(gm)),
+            "legacy_frames_per_s_all_models": n / t_legacy, "fused_s": t_fused, "fused_frames_per_s_all_models": n / t_fused,
+            "argmax_equal": bool(np.array_equal(np.argmax(got, axis=1), arg)),
+            "max_rel_sum_diff_legacy_vs_fused": float(np.max(np.abs(got - sums) / np.maximum(1.0, np.abs(sums))))}
 
 
 def block_cfg3(_lib, hbm, preq):
@@ -578,6 +631,7 @@ def main():
                          ("configs[3]_rank_shard_subsample", lambda: block_cfg3(_lib, hbm, preq)),
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
                          ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
+                         ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
             try:
                 blocks[name] = fn()

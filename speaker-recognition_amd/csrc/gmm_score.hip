@@ -790,7 +790,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                      "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf,
                      h2s_shape == 1 ? "waves=12" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
-            launch_score_h2_shared(a, h.kqf, h.klf);
+            const int n_launches = launch_score_h2_shared(a, h.kqf, h.klf);
+            const size_t len = strlen(g_last_kernel);
+            snprintf(g_last_kernel + len, sizeof(LastKernel::name) - len, " [%d launches per pass]", n_launches);
         } else if (use_shared) {
             ensure_shared_layout(set);
             SharedLaunch a;

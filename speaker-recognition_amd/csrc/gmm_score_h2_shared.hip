@@ -440,7 +440,7 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 }
 
 template <int KQF, int KLF, int COLS, int WAVES>
-static void launch_h2s(const H2sLaunch &l) {
+static int launch_h2s(const H2sLaunch &l) {
     H2sArgs a;
     a.X = l.X;
     a.tiles = l.tiles;
@@ -473,7 +473,9 @@ static void launch_h2s(const H2sLaunch &l) {
     const int n_wg = (l.n_tiles + TILES_WG - 1) / TILES_WG;
     int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)
                         : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
+    int n_launches = 0;
     for (int base = 0; base < n_wg; base += wg_per_launch) {
+        n_launches++;
         a.tile_base = base * TILES_WG;
         const int n = std::min(wg_per_launch, n_wg - base);
         dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
@@ -483,13 +485,15 @@ static void launch_h2s(const H2sLaunch &l) {
     // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
     const int fix_grid = std::max(1, std::min(l.exc_cap, ctx().n_cu * 8));
     hipLaunchKernelGGL((gmm_score_h2s_online_kernel<KQF, KLF>), dim3((unsigned)fix_grid), dim3(64), 0, ctx().stream, a);
+    return n_launches;
 }
 
 // workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves)
 int h2s_resident_per_cu(int kqf, int klf, int shape) { return shape == 0 ? h2s_waves_per_eu(kqf, klf, 1, 4) : 1; }
 int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : 12; }
 
-void launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
+// returns the number of launches of the main kernel the pass was cut into
+int launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
 #define SR_H2S_CASE(Q, L)                                       \
     if (KQF == Q && KLF == L) {                                 \
         if (l.shape == 1) return launch_h2s<Q, L, 1, 12>(l);    \

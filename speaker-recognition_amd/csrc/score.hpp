@@ -90,7 +90,7 @@ struct H2sLaunch {
     int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
     int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles)
 };
-void launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
+int launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU
 int h2s_tiles_per_wg(int shape);                        // 32-frame tiles a workgroup of that shape takes
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
