@@ -304,6 +304,33 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int r = 0; r < 4; r++) radix4(u[0][r], u[1][r], u[2][r], u[3][r], v[r], v[r + 4], v[r + 8], v[r + 12]);
 }
 
+// In-register forward DFT of N1 = 16, 8 or 4 points, natural order in and out (pass 1 of the register-resident FFT:
+// N1 = complex points / 64).  NZ = leading nonzero inputs the caller guarantees.
+template <int N1, int NZ>
+__device__ __forceinline__ void dft_n1(float2 (&v)[16]) {
+    if constexpr (N1 == 16) {
+        dft16<NZ>(v);
+    } else if constexpr (N1 == 8) {
+        constexpr float H = 0.70710678118654752440f;
+        float2 e[4], o[4];
+        radix4(v[0], v[2], v[4], v[6], e[0], e[1], e[2], e[3]);
+        radix4(v[1], v[3], v[5], v[7], o[0], o[1], o[2], o[3]);
+        o[1] = cmul(o[1], make_float2(H, -H));
+        o[2] = mul_mi(o[2]);
+        o[3] = cmul(o[3], make_float2(-H, -H));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = cadd(e[k], o[k]);
+            v[k + 4] = csub(e[k], o[k]);
+        }
+    } else {
+        static_assert(N1 == 4, "pass-1 DFT sizes: 16, 8, 4");
+        float2 y0, y1, y2, y3;
+        radix4(v[0], v[1], v[2], v[3], y0, y1, y2, y3);
+        v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+    }
+}
+
 // Mel rows are contiguous column runs; for the fast kernel they are re-laid as 4 passes x 16 bands,
 // every run of a pass zero-padded to the same multiple of 16 columns, so that 4 lanes sweep a band
 // with plain (unclamped) reads; element i of band b sits at pass_base[pass] + (i/4)*64 + (b%16)*4 + i%4,
@@ -337,23 +364,28 @@ __host__ __device__ constexpr int mel_preset_steps(int preset, int pass) {
 // WPB = waves per workgroup: 4 (per-lane twiddle constants in registers, 2 waves/SIMD) or 12 (the
 // pass-1 and untangle twiddles read from LDS instead: <= 168 VGPRs, 3 waves/SIMD; one workgroup per
 // CU, its tables shared by 12 waves).
-template <typename PcmT, int NZ1, int MP, int WPB>
+// N1 = complex points / 64: 16 (FFT_SIZE 2048, the reference's default), 8 (1024) or 4 (512).  The transform is
+// n = 64 n1 + lane -> N1-point DFT over n1 -> twiddle -> 64-point DFT over the lane index as 4 x 16 through two
+// LDS exchanges; with N1 < 16 pass 2 has N1/4 rows per lane and pass 3 runs on the first 4 N1 lanes.
+template <typename PcmT, int NZ1, int MP, int WPB, int N1 = 16>
 __global__ __launch_bounds__(64 * WPB, WPB == 4 ? 2 : 3)
 void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__restrict__ sample_off,
                                 const int64_t *__restrict__ frame_off, int n_utt, int64_t n_frames,
                                 int64_t frames_per_wave, MfccDev p, MelRuns mr, float *__restrict__ raw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NC = 1024;
-    float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_2048^k, k < 1024
+    constexpr int NC = 64 * N1;                                         // complex points; FFT_SIZE = 2 NC
+    static_assert(N1 == 16 || N1 == 8 || N1 == 4, "FFT_SIZE 2048, 1024 or 512");
+    static_assert(NZ1 <= N1 && (MP == 0 || N1 == 16), "the mel presets belong to FFT_SIZE 2048");
+    float2 *s_tw = reinterpret_cast<float2 *>(smem);                    // W_{2 NC}^k, k < NC
     float *s_melval = reinterpret_cast<float *>(s_tw + NC);
     float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
     constexpr int DCT_LD = MFCC_DCT_LD;
     const int dct_pad = 16 * DCT_LD;
     constexpr bool LDS_TW = WPB != 4;                                // twiddle constants in LDS, not registers
-    float2 *s_wk = reinterpret_cast<float2 *>(s_dct + dct_pad);      // [16][64] W_1024^(lane*k1) (LDS_TW only)
+    float2 *s_wk = reinterpret_cast<float2 *>(s_dct + dct_pad);      // [N1][64] W_NC^(lane*k1) (LDS_TW only)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float2 *slab = s_wk + (LDS_TW ? 16 * 64 : 0) + (size_t)wave * WAVE_SLAB_C;
+    float2 *slab = s_wk + (LDS_TW ? N1 * 64 : 0) + (size_t)wave * WAVE_SLAB_C;
     float *pbuf = reinterpret_cast<float *>(slab);          // power spectrum, 1025 floats
     float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
 
@@ -365,24 +397,24 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     }
     __syncthreads();
     if (LDS_TW) {
-        for (int i = threadIdx.x; i < 16 * 64; i += 64 * WPB) s_wk[i] = tw(s_tw, (2 * (i & 63) * (i >> 6)) & 2047, NC);
+        for (int i = threadIdx.x; i < N1 * 64; i += 64 * WPB) s_wk[i] = tw(s_tw, (2 * (i & 63) * (i >> 6)) & (2 * NC - 1), NC);
         __syncthreads();
     }
 
     // ---- per-lane constants ----
-    float2 wk[LDS_TW ? 1 : 16];        // W_1024^(lane*k1)
+    float2 wk[LDS_TW ? 1 : N1];        // W_NC^(lane*k1)
     if (!LDS_TW) {
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) wk[k1] = tw(s_tw, (2 * lane * k1) & 2047, NC);
+        for (int k1 = 0; k1 < N1; k1++) wk[k1] = tw(s_tw, (2 * lane * k1) & (2 * NC - 1), NC);
     }
     const int bb = lane & 15, gg = lane >> 4;
     float2 w64[4];        // W_64^(b*c)
 #pragma unroll
-    for (int c = 0; c < 4; c++) w64[c] = tw(s_tw, (32 * bb * c) & 2047, NC);
-    float2 utw[LDS_TW ? 1 : 16];       // untangle twiddles W_2048^(lane + 64 j)
+    for (int c = 0; c < 4; c++) w64[c] = tw(s_tw, (2 * N1 * bb * c) & (2 * NC - 1), NC);
+    float2 utw[LDS_TW ? 1 : N1];       // untangle twiddles W_{2 NC}^(lane + 64 j)
     if (!LDS_TW) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) utw[j] = s_tw[lane + 64 * j];
+        for (int j = 0; j < N1; j++) utw[j] = s_tw[lane + 64 * j];
     }
     const int L = p.frame_len;
     // window taps of this lane's samples: y[i0] = w0 x[i0] - wm x[i0-1], y[i0+1] = w1 x[i0+1] - w0p x[i0]
@@ -467,18 +499,18 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             }
             fetch(utt_s0 + (nf - utt_f0) * p.frame_shift, cm, c0, c1);
         }
-        // ---- pass 1: 16-point DFT over n1, twiddle, exchange ----
-        dft16<(NZ1 <= 4 ? 4 : 16)>(v);
+        // ---- pass 1: N1-point DFT over n1, twiddle, exchange ----
+        dft_n1<N1, (NZ1 <= 4 ? 4 : 16)>(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], LDS_TW ? s_wk[k1 * 64 + lane] : wk[k1]);
+        for (int k1 = 1; k1 < N1; k1++) v[k1] = cmul(v[k1], LDS_TW ? s_wk[k1 * 64 + lane] : wk[k1]);
         wave_sync();      // previous frame's readers are done with the slab
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) slab[k1 * 68 + lane] = v[k1];
+        for (int k1 = 0; k1 < N1; k1++) slab[k1 * 68 + lane] = v[k1];
         wave_sync();
-        // ---- pass 2: radix-4 over a for (k1 = 4g+i, b), twiddle W_64^(bc), exchange ----
+        // ---- pass 2: radix-4 over a for (k1 = (N1/4) g + i, b), twiddle W_64^(bc), exchange ----
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float2 *rowp = slab + (4 * gg + i) * 68 + bb;
+        for (int i = 0; i < N1 / 4; i++) {
+            const float2 *rowp = slab + ((N1 / 4) * gg + i) * 68 + bb;
             radix4(rowp[0], rowp[16], rowp[32], rowp[48], v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
             v[4 * i + 1] = cmul(v[4 * i + 1], w64[1]);
             v[4 * i + 2] = cmul(v[4 * i + 2], w64[2]);
@@ -486,24 +518,29 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         }
         wave_sync();
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < N1 / 4; i++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) slab[((4 * gg + i) + 16 * c) * 17 + bb] = v[4 * i + c];
+            for (int c = 0; c < 4; c++) slab[(((N1 / 4) * gg + i) + N1 * c) * 17 + bb] = v[4 * i + c];
         wave_sync();
-        // ---- pass 3: lane l = k1 + 16c holds C[k1][b][c], b = 0..15 -> Z[l + 64 d] ----
+        // ---- pass 3: lane l = k1 + N1 c (the first 4 N1 lanes) holds C[k1][b][c], b = 0..15 -> Z[l + 4 N1 d] ----
+        if (N1 == 16 || lane < 4 * N1) {
 #pragma unroll
-        for (int b = 0; b < 16; b++) v[b] = slab[lane * 17 + b];
-        dft16<16>(v);
+            for (int b = 0; b < 16; b++) v[b] = slab[lane * 17 + b];
+            dft16<16>(v);
+        }
         wave_sync();
+        if (N1 == 16 || lane < 4 * N1) {
 #pragma unroll
-        for (int d = 0; d < 16; d++) slab[lane + 64 * d] = v[d];
+            for (int d = 0; d < 16; d++) slab[lane + 4 * N1 * d] = v[d];
+        }
         wave_sync();
-        // ---- real-FFT untangle + power spectrum (MFCC.py:66): bins lane + 64 j, and bin 1024 ----
-        float pw[16];
+        // ---- real-FFT untangle + power spectrum (MFCC.py:66): bins lane + 64 j, and bin NC ----
+        float pw[N1];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < N1; j++) {
             const int k = lane + 64 * j;
-            const float2 zk = v[j];                              // Z[lane + 64 j] is this lane's own output
+            float2 zk;
+            if constexpr (N1 == 16) zk = v[j]; else zk = slab[k];   // N1 = 16: Z[lane + 64 j] is this lane's own output
             const float2 zr = slab[(NC - k) & (NC - 1)];
             // 2 X[k] = (Zk + conj Zr) - i W^k (Zk - conj Zr): the factor 1/2 is left out here and the
             // resulting 4x in the power is folded into the mel weights on the host (x 0.25)
@@ -515,10 +552,10 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
             pw[j] = fmaf(xr, xr, xi * xi);
         }
         const float2 z0 = slab[0];
-        const float nyq = 4.0f * (z0.x - z0.y) * (z0.x - z0.y);   // X[1024] = Re Z0 - Im Z0 (x4: same scale as the other bins)
+        const float nyq = 4.0f * (z0.x - z0.y) * (z0.x - z0.y);   // X[NC] = Re Z0 - Im Z0 (x4: same scale as the other bins)
         wave_sync();
 #pragma unroll
-        for (int j = 0; j < 16; j++) pbuf[lane + 64 * j] = pw[j];
+        for (int j = 0; j < N1; j++) pbuf[lane + 64 * j] = pw[j];
         if (lane == 0) pbuf[NC] = nyq;
         wave_sync();
         // ---- mel filterbank (MFCC.py:67-69): 4 lanes sweep one band's column run, 16 bands per pass ----
@@ -852,7 +889,10 @@ void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmv
 
     if (NF > 0) {
         auto &tabs = *std::static_pointer_cast<MfccDeviceTables>(m.dev[current_device()]);
-        const bool fast = m.fft_size == 2048 && tabs.runs_contiguous && m.n_ceps <= 16 && !mfcc_force_generic();
+        // the register-resident kernel: FFT_SIZE 2048 (the reference's default), 1024 or 512, frames that fit the transform
+        const int n1 = m.fft_size / 128;               // complex points / 64
+        const bool fast = (m.fft_size == 2048 || m.fft_size == 1024 || m.fft_size == 512) && m.frame_len <= m.fft_size &&
+                          tabs.runs_contiguous && m.n_ceps <= 16 && !mfcc_force_generic();
         ScopedKernelTimer t(T_MFCC);
         if (fast) {
             MelRuns mr;
@@ -864,8 +904,8 @@ void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmv
                 mr.pass_len[ps] = tabs.pass_len[ps];
             }
             auto lds_for = [&](int w) {
-                return (size_t)1024 * sizeof(float2) + (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
-                       (w == 4 ? 0 : (size_t)16 * 64 * sizeof(float2)) + (size_t)w * WAVE_SLAB_C * sizeof(float2);
+                return (size_t)(64 * n1) * sizeof(float2) + (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
+                       (w == 4 ? 0 : (size_t)n1 * 64 * sizeof(float2)) + (size_t)w * WAVE_SLAB_C * sizeof(float2);
             };
             int wpb = mfcc_waves_per_block();
             if (wpb == 12 && lds_for(12) > (size_t)160 * 1024) wpb = 4;      // a very wide filterbank: tables too big for one 12-wave workgroup
@@ -878,34 +918,38 @@ void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmv
             const int grid = (int)((n_waves + wpb - 1) / wpb);
             const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
             int preset = 0;
-            for (int pr = 1; pr <= 2 && !preset; pr++) {
+            for (int pr = 1; pr <= 2 && !preset && n1 == 16; pr++) {
                 bool same = true;
                 for (int ps = 0; ps < 4; ps++) same = same && tabs.pass_len[ps] == 16 * mel_preset_steps(pr, ps);
                 if (same) preset = pr;
             }
 #define SR_LAUNCH_FAST(PT, NZ, PCMPTR)                                                              \
     do {                                                                                             \
-        if (preset == 1) SR_LAUNCH_FAST_P(PT, NZ, 1, PCMPTR);                                        \
-        else if (preset == 2) SR_LAUNCH_FAST_P(PT, NZ, 2, PCMPTR);                                   \
-        else SR_LAUNCH_FAST_P(PT, NZ, 0, PCMPTR);                                                    \
+        if (preset == 1) SR_LAUNCH_FAST_P(PT, NZ, 1, 16, PCMPTR);                                    \
+        else if (preset == 2) SR_LAUNCH_FAST_P(PT, NZ, 2, 16, PCMPTR);                               \
+        else SR_LAUNCH_FAST_P(PT, NZ, 0, 16, PCMPTR);                                                \
     } while (0)
-#define SR_LAUNCH_FAST_P(PT, NZ, MPV, PCMPTR)                                                       \
+#define SR_LAUNCH_FAST_P(PT, NZ, MPV, N1V, PCMPTR)                                                  \
     do {                                                                                             \
-        if (wpb == 12) SR_LAUNCH_FAST_W(PT, NZ, MPV, 12, PCMPTR); else SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, PCMPTR); \
+        if (wpb == 12) SR_LAUNCH_FAST_W(PT, NZ, MPV, 12, N1V, PCMPTR); else SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, N1V, PCMPTR); \
     } while (0)
-#define SR_LAUNCH_FAST_W(PT, NZ, MPV, W, PCMPTR)                                                    \
+#define SR_LAUNCH_FAST_W(PT, NZ, MPV, W, N1V, PCMPTR)                                               \
     do {                                                                                             \
-        auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV, W>;                                      \
+        auto kern = mfcc_frames_fft2048_kernel<PT, NZ, MPV, W, N1V>;                                 \
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                             \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W), lds, ctx().stream, PCMPTR, d_pcm_off, \
                            w.raw_off.p, U, NF, frames_per_wave, dev, mr, w.raw.p);                   \
     } while (0)
-            if (pcm.kind == SRBatch::PCM16) {
-                if (nz1 <= 4) SR_LAUNCH_FAST(int16_t, 4, pcm.pcm16.p); else SR_LAUNCH_FAST(int16_t, 16, pcm.pcm16.p);
-            } else {
-                if (nz1 <= 4) SR_LAUNCH_FAST(float, 4, pcm.data.p); else SR_LAUNCH_FAST(float, 16, pcm.data.p);
-            }
+#define SR_LAUNCH_FAST_N(PT, PCMPTR)                                                                \
+    do {                                                                                             \
+        if (n1 == 16) { if (nz1 <= 4) SR_LAUNCH_FAST(PT, 4, PCMPTR); else SR_LAUNCH_FAST(PT, 16, PCMPTR); }                     \
+        else if (n1 == 8) { if (nz1 <= 4) SR_LAUNCH_FAST_P(PT, 4, 0, 8, PCMPTR); else SR_LAUNCH_FAST_P(PT, 8, 0, 8, PCMPTR); } \
+        else SR_LAUNCH_FAST_P(PT, 4, 0, 4, PCMPTR);                                                  \
+    } while (0)
+            if (pcm.kind == SRBatch::PCM16) SR_LAUNCH_FAST_N(int16_t, pcm.pcm16.p);
+            else SR_LAUNCH_FAST_N(float, pcm.data.p);
+#undef SR_LAUNCH_FAST_N
 #undef SR_LAUNCH_FAST
 #undef SR_LAUNCH_FAST_P
 #undef SR_LAUNCH_FAST_W
