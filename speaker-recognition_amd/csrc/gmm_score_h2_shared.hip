@@ -24,9 +24,9 @@
 //     results do not depend on the batch around it.
 //  3. The stream is staged through LDS G images per barrier; the unit of work is a 32-frame tile per wave
 //     (tiles never straddle utterances, workgroups may), so a workgroup can be 4 waves (three of them per
-//     CU, each with its own copy of the stream in LDS) or 12 / 8 waves -- ONE per CU, one copy of the
-//     stream for all of them: a third / a quarter of the L2 -> LDS traffic, which is what the 4-wave form
-//     stalls on (profiles/r02_h2s_stalls.txt).
+//     CU, each with its own copy of the stream in LDS) or 12 waves -- ONE per CU, one copy of the stream
+//     for all of them: a third of the L2 -> LDS traffic, which is what the 4-wave form stalls on
+//     (profiles/r02_h2s_stalls.txt).
 //
 // Stream order per block of 15 models, per mixture tile: [Q][L_0]...[L_14], 16 images of KF KiB
 // ([ks][lane][8 x fp16]: one ds_read_b128 per lane and MFMA).
@@ -46,12 +46,12 @@ constexpr float H2S_SUM_LO = 7.8886090522101181e-31f;    // 2^-100
 constexpr float H2S_SUM_HI = 1.2676506002282294e+30f;    // 2^100
 constexpr float H2S_LOG2E = 1.4426950408889634f;
 
-// KN steps of one flat chain on `acc`; `init` is the C operand of the first MFMA
-// The chain on A fragments already in registers: KN MFMAs back to back (a dependent chain on one
-// accumulator issues every 32 cycles only when nothing sits between its links: putting the
-// previous image's epilogue into the gaps was measured 30 % SLOWER, profiles/r02_h2s_variants.txt).
-// With COLS = 2 column tiles per wave the two chains share every A fragment and alternate, so a link's
-// predecessor is two issue slots back.
+// KN steps of one flat chain per column tile on A fragments already in registers; `init` is the C operand of the
+// first MFMA.  The MFMAs go back to back: a wave cannot hide its own vector work behind its own MFMAs (two chains
+// with the previous epilogues between the links: 904 cycles per 16 MFMAs + 64 vector ops against 1 024 one after
+// the other, scripts/ubench/mfma_lse_inwave.hip), and a dependent chain keeps its 32-cycle cadence only when nothing
+// sits between its links.  COLS = 2 (two column tiles per wave sharing every A fragment) was measured slower and is
+// not instantiated.
 template <int KN, int KM, int COLS>
 __device__ __forceinline__ void h2s_chain_regs(f32x16 (&acc)[COLS], const f32x16 (&init)[COLS], const uint4 (&fr)[KM],
                                                const f16x8 (&b)[COLS][KN]) {
