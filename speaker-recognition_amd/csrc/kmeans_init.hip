@@ -99,13 +99,13 @@ constexpr int KM_MAX_ITER = 200;   // kmeans.cc:172, :272
 // closer (kmeansII.cc:59-72; with dist preset to DBL_MAX it is the full search of kmeans.cc:87-99).
 __global__ __launch_bounds__(256)
 void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const double *__restrict__ C,
-                          int c_begin, int c_end, double *__restrict__ dist, int *__restrict__ belong) {
+                          int c_begin, int c_end, double *__restrict__ dist, int *__restrict__ belong, int reset) {
     extern __shared__ double cs[];               // [KM_CH][dim]
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
     const float *x = X + (valid ? i : 0) * dim;
-    double best = valid ? dist[i] : 0.0;
-    int best_j = valid ? belong[i] : 0;
+    double best = reset ? 1.7976931348623157e308 : valid ? dist[i] : 0.0;     // reset: a fresh search (DBL_MAX, no centre yet)
+    int best_j = reset ? -1 : valid ? belong[i] : 0;
     for (int c0 = c_begin; c0 < c_end; c0 += KM_CH) {
         const int nc = min(KM_CH, c_end - c0);
         __syncthreads();
@@ -149,14 +149,15 @@ void device_assign(long n, int dim, const std::vector<double> &C, int c_begin, i
     auto &w = kws();
     w.C.upload(C.data(), (size_t)c_end * dim);
     if (reset) {
-        std::fill(dist.begin(), dist.end(), std::numeric_limits<double>::max());
-        std::fill(belong.begin(), belong.end(), -1);
+        w.dist.ensure((size_t)n);
+        w.belong.ensure((size_t)n);
+    } else {
+        w.dist.upload(dist.data(), (size_t)n);
+        w.belong.upload(belong.data(), (size_t)n);
     }
-    w.dist.upload(dist.data(), (size_t)n);
-    w.belong.upload(belong.data(), (size_t)n);
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(kmeans_assign_kernel, dim3(grid), dim3(256), (size_t)KM_CH * dim * sizeof(double), ctx().stream,
-                       w.X.p, n, dim, w.C.p, c_begin, c_end, w.dist.p, w.belong.p);
+                       w.X.p, n, dim, w.C.p, c_begin, c_end, w.dist.p, w.belong.p, reset ? 1 : 0);
     SR_HIP(hipGetLastError());
     w.dist.download(dist.data(), (size_t)n);
     w.belong.download(belong.data(), (size_t)n);
