@@ -1,7 +1,11 @@
 """CPU: pins the oracle (oracle/) against the known-answer vectors generated from the
 reference itself (tests/golden/make_golden.py)."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import mfcc_oracle as mo
 
@@ -204,3 +208,50 @@ def test_ltsd_oracle_properties():
     from speaker_recognition_amd.filters.ltsd import voiced_runs
     assert voiced_runs(np.array([0, 3, 3, 9, 3, 0, 3, 3, 0, 9.0]), 2.0, 5.0) == [(1, 4), (9, 9)]
     assert voiced_runs(np.array([]), 1.0, 2.0) == []
+
+
+def test_glibc_rand_restatement_matches_libc():
+    """oracle/init_oracle.py carries glibc's rand() (the reference seeds every draw of its trainer from it,
+    random.hh:22-25): equal to the C library's own, from the default seed of a fresh process."""
+    import subprocess
+    import sys
+    from oracle import init_oracle as io
+    code = "import ctypes as C; l = C.CDLL('libc.so.6'); print(' '.join(str(l.rand()) for _ in range(3000)))"
+    want = [int(v) for v in subprocess.check_output([sys.executable, "-c", code]).split()]
+    r = io.GlibcRand()
+    assert [r() for _ in range(3000)] == want
+
+
+def test_init_oracle_matches_reference_trainer(oracle_built):
+    """Training FROM SCRATCH: the numpy restatement of the reference's initialisers (K random frames; k-means|| +
+    weighted k-means++ + Lloyd) with its random streams, then the oracle's EM iterations under the reference's stop
+    rule, against the models its compiled trainer produced in fresh processes (tests/golden/make_init_golden.py) --
+    also after a load() whose 32 Gaussians each consumed a draw."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_init_golden import CASES, case_data
+    from oracle import init_oracle as io
+    go = oracle_built
+    g = np.load(os.path.join(ROOT, "tests", "golden", "init_golden.npz"))
+    for name, K, D, n, iters, km, conc, preload in CASES:
+        X = case_data(K, D, n, 300 + K + D)
+        assert hashlib.sha256(X.astype(np.float32).tobytes()).hexdigest() == str(g[name + "_X_sha256"])
+        rand = io.GlibcRand()
+        if preload:
+            for _ in range(32):
+                rand()                                 # GMM::load: one Random per Gaussian (gmm.cc:671-676, gmm.hh:44)
+        w, mu, sg = io.init_gaussians(X, K, km, conc, rand)
+        p = go.GMMParams(w, mu, sg)
+        last = -np.finfo(np.float64).max
+        for it in range(iters):                        # GMMTrainerBaseline::train, gmm.cc:619-650
+            p = go.em_iteration(p, X)
+            if it % 2 == 0:
+                continue
+            ll = go.score_all(p, X)
+            if abs(ll - last) / abs(ll) < 0.01 and ll - last < 0.01:
+                break
+            last = ll
+        assert np.max(np.abs(p.weights - g[name + "_w"])) < 2e-6, name
+        assert np.max(np.abs(p.mean - g[name + "_mean"])) < 2e-5, (name, np.max(np.abs(p.mean - g[name + "_mean"])))
+        assert np.max(np.abs(p.sigma - g[name + "_sigma"]) / g[name + "_sigma"]) < 2e-5, name
