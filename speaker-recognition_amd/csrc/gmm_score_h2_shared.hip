@@ -127,8 +127,13 @@ __host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, i
     return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf > 16) ? 2 : 3;
 }
 __host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) {
-    // a wide workgroup has the CU's LDS to itself: two stages of 8 images while they fit in 160 KiB
-    return waves == 4 ? 2 : ((kqf > klf ? kqf : klf) <= 8 ? 8 : 4);
+    // 4-wave form: 2 images per stage (three workgroups per CU share the LDS); 12-wave form: 4 (measured on the
+    // configs[2]-shaped 5 M-frame pass: 8 images 0.145 s, 4 images 0.137 s, 2 images 0.138 s)
+#ifdef H2S_WIDE_G                 /* experiment: images per stage of the wide form */
+    return waves == 4 ? 2 : H2S_WIDE_G;
+#else
+    return waves == 4 ? 2 : 4;
+#endif
 }
 
 template <int KQF, int KLF, int COLS, int WAVES>
@@ -471,7 +476,10 @@ static int launch_h2s(const H2sLaunch &l) {
     constexpr int TILES_WG = WAVES * COLS;
     const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES));
     const int n_wg = (l.n_tiles + TILES_WG - 1) / TILES_WG;
+    // (the 12-wave form has one workgroup per CU sweeping the stream: nothing drifts apart, 1 / 3 / 5 / 9 / 18 launches
+    // per configs[2] pass all take 0.281-0.283 s -- one launch)
     int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)
+                        : WAVES > 4 ? std::max(8, (n_wg + 7) / 8 * 8)
                         : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
     int n_launches = 0;
     for (int base = 0; base < n_wg; base += wg_per_launch) {
