@@ -353,8 +353,14 @@ PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme
                 std::fill(sq.begin(), sq.end(), 0.0f);
                 std::fill(lin.begin(), lin.end(), 0.0f);
                 float cst_f = dead;
-                if (k < K) {
-                    double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                // fp16 layouts cannot say "minus infinity" (-60000 is as low as a constant goes, and a frame far from every
+                // mixture scores BELOW that): a padding mixture (k >= K) or one of weight 0 is a copy of a real mixture
+                // pushed 60000 log2 units down -- always 2^-60000 of something that is in the sum already
+                const bool f16_dead = scheme == SPLIT_F16X2 && (k >= K || !(g.weights[k < K ? k : K - 1] > 0));
+                const int ksrc = f16_dead ? (k < K ? k : K - 1) : k;
+                if (k < K || f16_dead) {
+                    const int k = ksrc;                              // (shadows: the coefficients of the source mixture)
+                    double cst = f16_dead ? 0.0 : g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
                     double a = 0.0;
                     for (int d = 0; d < dim; d++) {
                         const double sg = g.sigma[(size_t)k * dim + d];
@@ -369,8 +375,11 @@ PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme
                     }
                     pm.amp = std::max(pm.amp, a);
                     cst *= LOG2E;
-                    if (std::isfinite(cst) && cst > (double)dead) cst_f = (float)cst;
-                    if (cst_f != dead) pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
+                    if (f16_dead)
+                        cst_f = (float)std::max(cst + (double)F16_NEG_BIG, -65000.0);
+                    else if (std::isfinite(cst) && cst > (double)dead)
+                        cst_f = (float)cst;
+                    if (cst_f != dead && !f16_dead) pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
                 }
                 lin[(size_t)KS * 8 - 1] = cst_f;
                 for (int d = 0; d < KS * 8; d++) {
@@ -578,9 +587,9 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
         std::vector<uint16_t> slots((size_t)pm.kqf * 16);
         for (int t = 0; t < pm.n_tiles; t++)
             for (int i = 0; i < MT; i++) {
-                const int k = t * MT + i;
+                const int k = std::min(t * MT + i, K - 1);           // padding mixtures copy the last real one (see the linear images)
                 std::fill(slots.begin(), slots.end(), 0);
-                if (k < K)
+                {
                     for (int d = 0; d < dim; d++) {
                         const double sg = g0.sigma[(size_t)k * dim + d];
                         const double us = 1.0 / (double)pm.scale[d];
@@ -592,6 +601,7 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                         slots[dim + d] = parts[0];
                         slots[2 * dim + d] = parts[0];
                     }
+                }
                 put_flat_row(qimg.data() + (size_t)t * img_u16, pm.kqf, i, slots);
             }
     }
@@ -611,12 +621,16 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                 uint16_t *lt = tp + (size_t)(1 + si) * img_u16;
                 const int s = b * SHARED_SB + si;
                 for (int i = 0; i < MT; i++) {
-                    const int k = t * MT + i;
+                    const int kk = t * MT + i;
                     std::fill(slots.begin(), slots.end(), 0);
                     float cst_f = F16_NEG_BIG;
-                    if (s < S && k < K) {
+                    // padding mixtures and mixtures of weight 0: a copy of a real mixture 60000 log2 units down (a bare
+                    // constant of -60000 would OUTSCORE the real mixtures on a frame far from all of them)
+                    const int k = std::min(kk, K - 1);
+                    const bool f16_dead = s < S && (kk >= K || !(models[s]->weights[k] > 0));
+                    if (s < S) {
                         const GMM &g = *models[s];
-                        double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                        double cst = f16_dead ? 0.0 : std::log(g.weights[k]);
                         double a = 0.0;
                         for (int d = 0; d < dim; d++) {
                             const double sg = g.sigma[(size_t)k * dim + d];
@@ -635,7 +649,9 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                         }
                         pm.amp = std::max(pm.amp, a);
                         cst *= LOG2E;
-                        if (std::isfinite(cst) && cst > (double)F16_NEG_BIG) {
+                        if (f16_dead) {
+                            cst_f = (float)std::max(cst + (double)F16_NEG_BIG, -65000.0);
+                        } else if (std::isfinite(cst) && cst > (double)F16_NEG_BIG) {
                             cst_f = (float)cst;
                             pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
                         }

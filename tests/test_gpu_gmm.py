@@ -646,3 +646,35 @@ def test_hybrid_form_of_ill_conditioned_sets(built_lib, oracle_built):
     assert ms.info()["hybrid_vector_mixtures"] == 0
     ms.score(Batch.from_features([synth.draw_frames(allbad[0], 100, 1)]))
     assert "vector ALU" in _lib.last_score_kernel() and not _lib.last_score_kernel().startswith("hybrid")
+
+
+def test_fp16_padding_mixtures_never_outscore_real_ones(built_lib, oracle_built):
+    """fp16 layouts cannot hold "minus infinity": the padding of a 32-mixture tile (K = 190, 27) and mixtures of weight 0
+    are copies of a real mixture 60000 log2 units down, not a bare constant of -60000 -- which a frame 60 sigma from every
+    mixture (true log2 density ~ -2e5) would score BELOW.  Found by scripts/debug/fuzz_shared.py; only visible with the
+    reference's clamp OFF (with it on both sides of the comparison are ln 1e-15)."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    for K, D, S in ((190, 32, 28), (27, 45, 22), (33, 39, 3)):
+        ubm = synth.synth_gmm(K, D, 5000 + K)
+        if S >= 12:
+            models = [ubm] + [synth.synth_map_speaker(ubm, 5100 + s) for s in range(S - 1)]
+        else:
+            models = [synth.synth_gmm(K, D, 5200 + s) for s in range(S)]
+            w, mu, sg = models[1]
+            w = w.copy()
+            w[4] = 0.0
+            models[1] = (w, mu, sg)
+        utts = [synth.draw_frames(models[u % S], n, 5300 + u, outlier_frac=0.05) for u, n in enumerate([257, 100, 33])]
+        X = np.concatenate(utts).astype(np.float64)
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        for compat in (False, True):
+            want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
+            assert compat or want.min() < -60000 * np.log(2)          # the outliers really are below the fp16 floor
+            for eng in ((0, 5, 6) if S >= 12 else (0, 5)):
+                _lib.set_option("score_engine", eng)
+                sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
+                assert ll_close(fll, want) < TOL, (K, D, S, compat, eng, ll_close(fll, want), _lib.last_score_kernel())
+    _lib.set_option("score_engine", 0)
