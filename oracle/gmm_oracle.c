@@ -156,7 +156,9 @@ void oracle_gmm_score_batch(const double *weights, const double *mean, const dou
             double m = -INFINITY;
             double *v = (double *)malloc(sizeof(double) * (size_t)K);
             for (int k = 0; k < K; k++) {
-                v[k] = safe_log(weights[k]) +
+                /* a mixture of weight 0 adds exactly 0 to the reference's linear-domain sum (gmm.cc:237-244): -inf here,
+                 * not safe_log's ln(1e-15) -- found by scripts/debug/fuzz_generic.py */
+                v[k] = (weights[k] > 0 ? log(weights[k]) : -INFINITY) +
                        gaussian_logprob(x, mean + (long)k * D, sigma + (long)k * D, D);
                 if (v[k] > m) m = v[k];
             }
@@ -170,9 +172,9 @@ void oracle_gmm_score_batch(const double *weights, const double *mean, const dou
             const double minlog = -7.08396418532264106224e2;
             double s = 0;
             for (int k = 0; k < K; k++)
-                if (!clamp_compat || v[k] >= minlog)
+                if ((!clamp_compat || v[k] >= minlog) && v[k] > -INFINITY)
                     s += exp(v[k] - m);
-            double ll = m + log(s);
+            double ll = (m > -INFINITY) ? m + log(s) : -INFINITY;
             free(v);
             if (clamp_compat && m < minlog)
                 ll = log(1e-15);

@@ -34,7 +34,8 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 template <int DP>
 __global__ __launch_bounds__(256)
 void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
-                     const float4 *__restrict__ params, int n_records,
+                     const float4 *__restrict__ params, const float *__restrict__ center /* [DP], of the packed set */,
+                     int n_records,
                      const float *__restrict__ mean_f32 /* [K_pad][DP] */,
                      const float *__restrict__ frame_ll /* natural log, no clamp */,
                      float *__restrict__ slabs /* [grid][K_pad][2*DP+1] */, int n_tiles) {
@@ -59,8 +60,9 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
             const float *src = X + (valid ? frame : 0) * dim;
 #pragma unroll
             for (int dd = 0; dd < DP; dd++) {
-                x[dd] = (dd < dim) ? src[dd] : 0.f;
-                xs[tid * XS + dd] = valid ? x[dd] : 0.f;
+                const float raw = (dd < dim) ? src[dd] : 0.f;
+                x[dd] = raw - center[dd];                  // the densities work on x - center (gmm_model.hpp); the sums on x itself
+                xs[tid * XS + dd] = valid ? raw : 0.f;
             }
             if (valid) {
                 const float ll = frame_ll[frame];
@@ -127,17 +129,17 @@ void em_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n_elem,
 }
 
 template <int DP>
-static void launch_stats(const float *X, int64_t n, int dim, const float4 *params, int n_records,
+static void launch_stats(const float *X, int64_t n, int dim, const float4 *params, const float *center, int n_records,
                          const float *mean_f32, const float *frame_ll, float *slabs, int n_tiles,
                          int grid) {
     hipLaunchKernelGGL((em_stats_kernel<DP>), dim3(grid), dim3(256), 0, ctx().stream, X, n, dim,
-                       params, n_records, mean_f32, frame_ll, slabs, n_tiles);
+                       params, center, n_records, mean_f32, frame_ll, slabs, n_tiles);
 }
 
-static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const float4 *params,
+static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const float4 *params, const float *center,
                            int n_records, const float *mean_f32, const float *frame_ll,
                            float *slabs, int n_tiles, int grid) {
-#define SR_CASE(V) case V: launch_stats<V>(X, n, dim, params, n_records, mean_f32, frame_ll, slabs, n_tiles, grid); break;
+#define SR_CASE(V) case V: launch_stats<V>(X, n, dim, params, center, n_records, mean_f32, frame_ll, slabs, n_tiles, grid); break;
     switch (DP) {
         SR_CASE(8) SR_CASE(13) SR_CASE(16) SR_CASE(24) SR_CASE(26) SR_CASE(32) SR_CASE(34)
         SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64) SR_CASE(80) SR_CASE(96) SR_CASE(128)
@@ -223,7 +225,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         SR_HIP(hipMemsetAsync(w.slabs.p, 0, (size_t)grid * n_elem * sizeof(float), ctx().stream));
         {
             ScopedKernelTimer t(T_ESTEP);
-            dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p),
+            dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p,
                            n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
         }
         SR_HIP(hipGetLastError());

@@ -107,6 +107,18 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
     const size_t rec_f4 = (size_t)2 * DP + 1;
     const double LOG2E = 1.4426950408889634073599;
     const double SQRT_2_PI = 2.5066282746310002;  // gmm.cc:22
+    pm.center.assign(DP, 0.0f);
+    {
+        std::vector<double> acc(pm.dim, 0.0);
+        size_t cnt = 0;
+        for (const GMM *g : models) {
+            if (!g->trained() || g->dim != pm.dim) continue;        // reported below
+            for (int k = 0; k < g->nr_mixtures; k++)
+                for (int d = 0; d < pm.dim; d++) acc[d] += g->mean[(size_t)k * pm.dim + d];
+            cnt += (size_t)g->nr_mixtures;
+        }
+        for (int d = 0; d < pm.dim && cnt; d++) pm.center[d] = (float)(acc[d] / (double)cnt);
+    }
     pm.model_chunk_begin.push_back(0);
     for (int s = 0; s < pm.n_models; s++) {
         const GMM &g = *models[s];
@@ -130,7 +142,7 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
                 double c = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
                 for (int d = 0; d < pm.dim; d++) {
                     const double sg = g.sigma[(size_t)k * pm.dim + d];
-                    const double mu = g.mean[(size_t)k * pm.dim + d];
+                    const double mu = g.mean[(size_t)k * pm.dim + d] - (double)pm.center[d];
                     const double sc = std::sqrt(LOG2E * 0.5) / sg;
                     // record layout: dim d -> two float4: {s0,m0,s1,m1} {s2,m2,s3,m3}
                     float *pair = rec + (size_t)d * 8 + (size_t)j * 2;

@@ -33,9 +33,9 @@ std::string gmm_format_text(const GMM &g);
 
 // ---- packed parameters ----
 // A record holds KB=4 mixtures for all (padded) dims: for d in [0,DP): float4 pair
-//   {s0,m0,s1,m1}, {s2,m2,s3,m3}      with s = sqrt(log2(e)/2)/sigma, m = -mean*s
+//   {s0,m0,s1,m1}, {s2,m2,s3,m3}      with s = sqrt(log2(e)/2)/sigma, m = -(mean - center)*s
 // followed by one float4 {c0,c1,c2,c3}, c = log2(e) * (ln w - sum_d ln(sqrt(2 pi) sigma_d)),
-// so that  log2-density_k(x) = c_k - sum_d (x_d*s_kd + m_kd)^2     (2 FMAs per (d,k)).
+// so that  log2-density_k(x) = c_k - sum_d (x'_d*s_kd + m_kd)^2,  x' = x - center   (2 FMAs per (d,k)).
 // Padded mixtures carry c = -1e30 (contribute 2^-inf = 0); padded dims carry s = m = 0.
 // Record size = (2*DP+1) float4.  A chunk = up to CB consecutive records of ONE model and is
 // what a workgroup copies into LDS at a time.
@@ -59,6 +59,8 @@ struct PackedModels {
     int dim = 0;  // actual feature dim
     int dp = 0;   // padded dim the kernels are instantiated for
     std::vector<float> params;      // float4-granular
+    std::vector<float> center;      // [dp] the set's centre (mean of all mixture means): the kernels work on x - center,
+                                    // so that a feature space far from the origin costs no digits in x*s + m
     std::vector<ChunkDesc> chunks;  // all models, in model order
     std::vector<int> model_chunk_begin;  // [S+1]
 };
@@ -173,7 +175,7 @@ float f16_to_f32(uint16_t h);
 // Device-resident speaker set (C ABI handle `SRModelSet *`).
 struct SRModelSet {
     sr::PackedModels host;
-    sr::DevBuf<float> d_params;
+    sr::DevBuf<float> d_params, d_center0;     // vector layout and its centre
     sr::DevBuf<sr::ChunkDesc> d_chunks;
     sr::PackedMfma mfma;             // expanded-form layout for the matrix-core engine
     sr::DevBuf<float> d_mfma_params, d_center;

@@ -27,6 +27,7 @@ struct ScoreArgs {
     const float *X;            // [n_frames][dim] row-major fp32
     const TileDesc *tiles;
     const float4 *params;
+    const float *center;       // [DP] subtracted from every frame (PackedModels::center)
     const ChunkDesc *chunks;
     const int *group_chunk_begin;  // [G+1]
     double *partial;           // [n_tiles][S][4]  per-wave partial sums
@@ -71,7 +72,8 @@ template <> struct Lanes<true> {
 template <int DP, int F, bool PK>
 __global__ __launch_bounds__(256, score_waves_per_eu(DP, F))
 void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ tiles,
-                      const float4 *__restrict__ params, const ChunkDesc *__restrict__ chunks,
+                      const float4 *__restrict__ params, const float *__restrict__ center,
+                      const ChunkDesc *__restrict__ chunks,
                       const int *__restrict__ group_chunk_begin, double *__restrict__ partial,
                       float *__restrict__ frame_ll, int64_t n_frames, int dim, int n_models,
                       int clamp, int n_groups, int n_tiles) {
@@ -132,10 +134,10 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
         const float *src = X + row[f] * dim;
         if (dim == DP) {
 #pragma unroll
-            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, src[d]);
+            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, src[d] - center[d]);
         } else {
 #pragma unroll
-            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, (d < dim) ? src[d] : 0.0f);
+            for (int d = 0; d < DP; d++) L::set(x[f / W][d], f % W, (d < dim) ? src[d] - center[d] : 0.0f);
         }
     }
 
@@ -337,7 +339,7 @@ template <int DP, int F, bool PK>
 static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
     dim3 grid((unsigned)((int64_t)n_groups * ((n_tiles + 7) / 8) * 8));   // 1-D, XCD-aware order
     hipLaunchKernelGGL((gmm_score_kernel<DP, F, PK>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
-                       a.params, a.chunks, a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames,
+                       a.params, a.center, a.chunks, a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames,
                        a.dim, a.n_models, a.clamp, n_groups, n_tiles);
 }
 
@@ -391,6 +393,7 @@ static int auto_frames_per_lane(const SRBatch &b, int dp) {
 void upload_model_set(SRModelSet &s) {
     ensure_device();
     s.d_params.upload(s.host.params.data(), s.host.params.size());
+    s.d_center0.upload(s.host.center.data(), s.host.center.size());
     s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
     sync_stream();
     s.device = ctx().device;
@@ -863,6 +866,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
             a.params = reinterpret_cast<const float4 *>(set.d_params.p);
+            a.center = set.d_center0.p;
             a.chunks = set.d_chunks.p;
             a.group_chunk_begin = w.group_chunk_begin.p;
             a.partial = w.partial.p;

@@ -678,3 +678,28 @@ def test_fp16_padding_mixtures_never_outscore_real_ones(built_lib, oracle_built)
                 sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
                 assert ll_close(fll, want) < TOL, (K, D, S, compat, eng, ll_close(fll, want), _lib.last_score_kernel())
     _lib.set_option("score_engine", 0)
+
+
+def test_feature_space_far_from_origin(built_lib, oracle_built):
+    """Means 40 units from the origin with sigmas of 0.01-0.08 (|mu| / sigma in the thousands): every engine works on
+    x - centre (the set's mean of means), so x*s + m keeps its digits -- the vector engine's direct form lost 3 of them
+    on raw x (2.3e-3 relative; found by scripts/debug/fuzz_generic.py).  Per-frame LL against the oracle."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    r6 = np.vectorize(lambda v: float("%g" % v))
+    for D, shift, scale in ((61, -40.0, 0.05), (24, -40.0, 0.05), (14, 5.0, 0.05), (30, -40.0, 30.0)):
+        models = []
+        for s in range(3):
+            w, mu, sg = synth.synth_gmm(40 + 30 * s, D, 6000 + 10 * D + s)
+            models.append((w, r6(mu * scale + shift), r6(sg * scale)))
+        utts = [synth.draw_frames(models[u % 3], n, 6100 + u) for u, n in enumerate([300, 129, 64])]
+        X = np.concatenate(utts).astype(np.float64)
+        want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP) for m in models])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        for eng in (0, 1, 3):
+            _lib.set_option("score_engine", eng)
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            assert ll_close(fll, want) < TOL, (D, shift, scale, eng, ll_close(fll, want), _lib.last_score_kernel())
+    _lib.set_option("score_engine", 0)

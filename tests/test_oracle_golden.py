@@ -255,3 +255,22 @@ def test_init_oracle_matches_reference_trainer(oracle_built):
         assert np.max(np.abs(p.weights - g[name + "_w"])) < 2e-6, name
         assert np.max(np.abs(p.mean - g[name + "_mean"])) < 2e-5, (name, np.max(np.abs(p.mean - g[name + "_mean"])))
         assert np.max(np.abs(p.sigma - g[name + "_sigma"]) / g[name + "_sigma"]) < 2e-5, name
+
+
+def test_oracle_zero_weight_mixture_adds_nothing(oracle_built):
+    """A mixture of weight 0 contributes exactly 0 in the reference (w_k p_k in the linear domain, gmm.cc:237-244): the
+    log-sum-exp mode of the oracle agrees with its reference-faithful modes also when the frame sits ON that mixture
+    (it used safe_log's ln 1e-15 as the weight; found by scripts/debug/fuzz_generic.py)."""
+    go = oracle_built
+    rng = np.random.default_rng(3)
+    K, D = 6, 5
+    w = np.full(K, 1.0 / (K - 1))
+    w[2] = 0.0
+    mu = rng.normal(0, 3, (K, D))
+    sg = rng.uniform(0.5, 1.0, (K, D))
+    X = np.vstack([mu[2] + 0.01, mu[0] + 0.3, rng.normal(0, 1, D)])
+    p = go.GMMParams(w, mu, sg)
+    a = go.score_batch(p, X, go.MODE_LOGSUMEXP)
+    b = go.score_batch(p, X, go.MODE_FASTEXP)
+    c = go.score_batch(p, X, 1)
+    assert np.max(np.abs(a - c)) < 1e-9 and np.max(np.abs(a - b) / np.maximum(1, np.abs(b))) < 1e-4
