@@ -236,6 +236,47 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         w.stats.download(stats.data(), n_elem);
         sync_stream();
 
+        // Mixtures without support: a responsibility below fp32's range (~1e-38) is 0 on the device, while the
+        // reference's float64 keeps it down to DBL_MIN -- its N_k is then tiny but not 0, and the mixture's mean
+        // jumps to the responsibility-weighted mean of the frames (gmm.cc:396-412) instead of staying put.  Such
+        // mixtures (rare: more mixtures than the data supports) get their three sums again on the host, in float64,
+        // with the reference's rules (terms below DBL_MIN are 0; frames whose likelihood underflowed carry none).
+        {
+            std::vector<int> weak;
+            for (int k = 0; k < K; k++)
+                if (stats[(size_t)k * REC + 2 * DP] < 1e-25) weak.push_back(k);
+            if (!weak.empty()) {
+                std::vector<float> ll((size_t)n);
+                SR_HIP(hipMemcpyAsync(ll.data(), sres.d_frame_ll, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+                sync_stream();
+                const double SQRT_2_PI = 2.5066282746310002, MINLOG = -708.396418532264;
+                for (int k : weak) {
+                    double *st = stats.data() + (size_t)k * REC;
+                    for (int e = 0; e < REC; e++) st[e] = 0.0;
+                    const double *mu = gmm.mean.data() + (size_t)k * dim, *sg = gmm.sigma.data() + (size_t)k * dim;
+                    double c = gmm.weights[k] > 0 ? std::log(gmm.weights[k]) : -INFINITY;
+                    for (int d = 0; d < dim; d++) c -= std::log(SQRT_2_PI * sg[d]);
+                    for (long i = 0; i < n; i++) {
+                        if (!(ll[i] >= (float)MINLOG)) continue;
+                        const float *x = X + (size_t)i * dim;
+                        double lp = c;
+                        for (int d = 0; d < dim; d++) {
+                            const double v = ((double)x[d] - mu[d]) / sg[d];
+                            lp -= 0.5 * v * v;
+                        }
+                        if (!(lp >= MINLOG)) continue;
+                        const double gam = std::exp(lp - (double)ll[i]);
+                        for (int d = 0; d < dim; d++) {
+                            const double dv = (double)x[d] - (double)(float)mu[d];       // centred on the fp32 mean the device used
+                            st[d] += gam * dv;
+                            st[DP + d] += gam * dv * dv;
+                        }
+                        st[2 * DP] += gam;
+                    }
+                }
+            }
+        }
+
         // ---- M-step (float64, host; O(K*D)) ----
         std::vector<double> Nk(K);
         for (int k = 0; k < K; k++) {

@@ -41,6 +41,29 @@ def test_em_and_map_iteration_vs_oracle(built_lib, oracle_built, D):
     assert np.max(np.abs(mu2 - want_map.mean)) < 1e-4
 
 
+def test_em_mixtures_without_support_follow_the_reference(built_lib, oracle_built):
+    """More mixtures than the data supports (23 mixtures, 128 dims, 50 frames): responsibilities fall below fp32's range
+    for most (frame, mixture) pairs.  The reference's float64 keeps them down to DBL_MIN, so such a mixture's mean moves
+    to the weighted mean of the frames; the device's sums are 0 there and are redone on the host in float64 (em.hip).
+    One EM iteration against the oracle (found by scripts/debug/fuzz_train.py)."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(10)
+    K, D, n = 23, 128, 50
+    true = synth.synth_gmm(K, D, 11)
+    X = synth.draw_frames(true, n, 12)
+    start = go.GMMParams(np.full(K, 1.0 / K), true[1] + 0.2 * rng.standard_normal(true[1].shape), np.full_like(true[2], 0.9))
+    want = go.em_iteration(start, X.astype(np.float64))
+    g = GMM.from_arrays(start.weights, start.mean, start.sigma)
+    g.nr_iteration, g.init_with_kmeans = 1, -1
+    assert g.fit(X) == 1
+    w, mu, sg = g.params()
+    assert np.max(np.abs(w - want.weights)) < 2e-5
+    assert np.max(np.abs(mu - want.mean)) < 3e-4, np.max(np.abs(mu - want.mean))
+    assert np.max(np.abs(sg - want.sigma) / want.sigma) < 2e-3
+
+
 def test_em_converges_and_improves(built_lib):
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.pygmm import GMM
