@@ -20,6 +20,11 @@ worst = 0.0
 for c in range(cases):
     K, D, S = int(rng.integers(20, 200)), int(rng.integers(5, 49)), int(rng.integers(12, 36))
     ubm = synth.synth_gmm(K, D, int(rng.integers(1 << 30)))
+    if rng.random() < 0.3:                      # a mixture of weight 0, shared by every model of the set
+        w, mu, sg = ubm
+        w = w.copy()
+        w[int(rng.integers(K))] = 0.0
+        ubm = (w, mu, sg)
     spoil = rng.random() < 0.3
     if spoil:
         w, mu, sg = (a.copy() for a in ubm)
