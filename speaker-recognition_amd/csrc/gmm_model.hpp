@@ -201,6 +201,8 @@ struct SRModelSet {
     // Hybrid form of an ill-conditioned set (score.hpp): the mixtures whose expanded form would cancel in fp32 (tight and
     // far from the centre) as one sub-set on the direct-form vector engine, the rest as another on the matrix cores;
     // the two per-frame log-likelihoods are merged by a log-add-exp.  Empty unless the set needed it.
+    std::vector<int> gcb_host;       // model-group table of the last scoring call (chunk / block index per group) ...
+    sr::DevBuf<int> d_gcb;           // ... and its device copy
     std::unique_ptr<SRModelSet> hy_good, hy_bad;
     int hy_bad_mixtures = 0;         // mixtures of the set's largest model that went to the vector engine
     int device = -1;

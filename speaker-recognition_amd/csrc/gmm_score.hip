@@ -321,11 +321,9 @@ ScoreOptions &score_options() {
 }
 
 struct ScoreWorkspace {
-    std::vector<int> gcb_host;           // what group_chunk_begin currently holds
     DevBuf<double> partial;
     DevBuf<double> sums;
     DevBuf<int> argmax;
-    DevBuf<int> group_chunk_begin;
     DevBuf<float> frame_ll;
     DevBuf<int> oor;                     // saturation flag of the fp16 engines
     DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
@@ -718,9 +716,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             }
         }
         bool uploaded = false;
-        if (w.gcb_host != gcb) {
-            w.gcb_host = gcb;
-            w.group_chunk_begin.upload(w.gcb_host.data(), w.gcb_host.size());
+        // the group table lives with the SET (a hybrid set's two halves, or sets scored in turn, each keep theirs: no
+        // re-upload -- and no stream synchronisation, which a captured serving tick could not take -- in steady state)
+        if (set.gcb_host != gcb) {
+            set.gcb_host = gcb;
+            set.d_gcb.upload(set.gcb_host.data(), set.gcb_host.size());
             uploaded = true;
         }
         w.partial.ensure((size_t)tt.n_tiles * S * ((use_split || use_shared || use_h2s) ? 1 : 4));
@@ -768,7 +768,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.tiles = tt.d_tiles.p;
             a.params = set.d_h2s_params.p;
             a.blocks = set.d_h2s_blocks.p;
-            a.group_block_begin = w.group_chunk_begin.p;
+            a.group_block_begin = set.d_gcb.p;
             a.center = set.d_h2s_center.p;
             a.scale = set.d_h2s_scale.p;
             a.q_desc = set.d_h2s_qdesc.p;
@@ -806,7 +806,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.tiles = tt.d_tiles.p;
             a.params = set.d_shared_params.p;
             a.blocks = set.d_shared_blocks.p;
-            a.group_block_begin = w.group_chunk_begin.p;
+            a.group_block_begin = set.d_gcb.p;
             a.center = set.d_shared_center.p;
             a.partial = w.partial.p;
             a.frame_ll = fll;
@@ -831,7 +831,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                        : use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
                                  : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
             a.chunks = use_h2 ? set.d_h2_chunks.p : use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
-            a.group_chunk_begin = w.group_chunk_begin.p;
+            a.group_chunk_begin = set.d_gcb.p;
             a.center = use_h2 ? set.d_h2_center.p : use_bx3 ? set.d_bx3_center.p : set.d_center.p;
             if (use_h2) {
                 w.oor.ensure(1);
@@ -868,7 +868,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.params = reinterpret_cast<const float4 *>(set.d_params.p);
             a.center = set.d_center0.p;
             a.chunks = set.d_chunks.p;
-            a.group_chunk_begin = w.group_chunk_begin.p;
+            a.group_chunk_begin = set.d_gcb.p;
             a.partial = w.partial.p;
             a.frame_ll = fll;
             a.n_frames = feat.n_rows;

@@ -370,3 +370,35 @@ def test_cfg0_at_stated_size_cli_vs_cpu_restatement(built_lib, tmp_path):
         assert m.gmmset.y[int(np.argmax(scores))] == label
         dev = np.array(m.gmmset.predict_one_scores(m._features(fs, sig))) / len(feat)
         assert np.max(np.abs(dev - np.array(scores)) / np.abs(scores)) < 2e-3
+
+
+def test_serving_stream_with_hybrid_set_under_graph_capture(built_lib):
+    """A set in the hybrid form scores as two sub-sets per call; their model-group tables live with the sub-sets, so a
+    serving tick -- also replayed as a captured hipGraph, which cannot take a stream synchronisation -- re-uploads
+    nothing in steady state (the shared workspace table used to flip between the two halves on every call; found by
+    scripts/debug/fuzz_stream.py).  Stream results equal the synchronous call bit for bit."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, ServingStream
+    from speaker_recognition_amd.pygmm import GMM
+    fs, nwin = 8000, 3
+    w, mu, sg = (a.copy() for a in synth.synth_gmm(64, 13, 99))
+    sg[3] = 0.04
+    mu[3] = mu.mean(0) + 2.0
+    ubm = (w, mu, sg)
+    ms = ModelSet([GMM.from_arrays(*ubm)] + [GMM.from_arrays(*synth.synth_map_speaker(ubm, 70 + s)) for s in range(14)])
+    assert ms.info()["hybrid_vector_mixtures"] >= 1
+    ex = MfccExtractor(fs)
+    audio = synth.synth_speech(4, 8.0, fs)
+    ticks = [np.stack([audio[(t * nwin + j) * 2400:(t * nwin + j) * 2400 + fs] for j in range(nwin)]) for t in range(4)]
+    want = [ex.predict_batch(ms, Batch.from_pcm(list(tk)), nd=0) for tk in ticks]
+    assert _lib.last_score_kernel().startswith("hybrid")
+    for graph in (False, True):
+        st = ServingStream(ex, ms, nwin, fs, graph=graph)
+        st.submit(ticks[0])
+        got = []
+        for t in range(1, 4):
+            st.submit(ticks[t])
+            got.append(st.collect())
+        got.append(st.collect())
+        for t in range(4):
+            assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1]), (graph, t)
