@@ -1,13 +1,29 @@
 // gmm_model.cpp -- text model format + parameter packing (host, float64 -> fp32 tables).
 #include "gmm_model.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace sr {
 
 namespace {
+
+// Packing a configs[3]-sized set (1001 models x 2048 mixtures) is ~10^8 log/divide/split steps: the independent pieces
+// (models, blocks of 15 models) are shared by a few host threads.  `work(i)` must only write what belongs to piece i.
+template <class F>
+void host_parallel_for(int n, size_t cost_per_piece, F work) {
+    const size_t total = (size_t)n * cost_per_piece;
+    const int n_threads = total < ((size_t)1 << 22) ? 1 : std::max(1, std::min({n, (int)std::thread::hardware_concurrency(), 32}));
+    auto run = [&](int t) { for (int i = t; i < n; i += n_threads) work(i, t); };
+    if (n_threads == 1) return run(0);
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
+    run(0);
+    for (auto &x : th) x.join();
+}
 
 struct Tok {
     const char *p;
@@ -120,16 +136,32 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
         for (int d = 0; d < pm.dim && cnt; d++) pm.center[d] = (float)(acc[d] / (double)cnt);
     }
     pm.model_chunk_begin.push_back(0);
+    std::vector<size_t> base(pm.n_models);
+    size_t total_f4 = 0;
     for (int s = 0; s < pm.n_models; s++) {
         const GMM &g = *models[s];
         if (!g.trained()) fail("model %d of the set is untrained/empty", s);
         if (g.dim != pm.dim) fail("model %d has dim %d, set has %d", s, g.dim, pm.dim);
+        const int n_rec = (g.nr_mixtures + KB - 1) / KB;
+        base[s] = total_f4;
+        for (int r0 = 0; r0 < n_rec; r0 += CB) {
+            ChunkDesc cd;
+            cd.offset_f4 = (uint32_t)(total_f4 + (size_t)r0 * rec_f4);
+            cd.n_records = std::min(CB, n_rec - r0);
+            cd.model_done = (r0 + CB >= n_rec) ? s : -1;
+            cd.pad = 0;
+            pm.chunks.push_back(cd);
+        }
+        pm.model_chunk_begin.push_back((int)pm.chunks.size());
+        total_f4 += (size_t)n_rec * rec_f4;
+    }
+    pm.params.assign(total_f4 * 4, 0.0f);
+    host_parallel_for(pm.n_models, (size_t)models[0]->nr_mixtures * pm.dim, [&](int s, int) {
+        const GMM &g = *models[s];
         const int K = g.nr_mixtures;
         const int n_rec = (K + KB - 1) / KB;
-        const size_t base_f4 = pm.params.size() / 4;
-        pm.params.resize(pm.params.size() + (size_t)n_rec * rec_f4 * 4, 0.0f);
         for (int r = 0; r < n_rec; r++) {
-            float *rec = pm.params.data() + (base_f4 + (size_t)r * rec_f4) * 4;
+            float *rec = pm.params.data() + (base[s] + (size_t)r * rec_f4) * 4;
             for (int j = 0; j < KB; j++) {
                 const int k = r * KB + j;
                 float *cslot = rec + (size_t)2 * DP * 4 + j;
@@ -154,16 +186,7 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
                 *cslot = (std::isfinite(c) && c > (double)NEG_BIG) ? (float)c : NEG_BIG;
             }
         }
-        for (int r0 = 0; r0 < n_rec; r0 += CB) {
-            ChunkDesc cd;
-            cd.offset_f4 = (uint32_t)(base_f4 + (size_t)r0 * rec_f4);
-            cd.n_records = std::min(CB, n_rec - r0);
-            cd.model_done = (r0 + CB >= n_rec) ? s : -1;
-            cd.pad = 0;
-            pm.chunks.push_back(cd);
-        }
-        pm.model_chunk_begin.push_back((int)pm.chunks.size());
-    }
+    });
     return pm;
 }
 
@@ -617,15 +640,27 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                 put_flat_row(qimg.data() + (size_t)t * img_u16, pm.kqf, i, slots);
             }
     }
-    std::vector<uint16_t> slots((size_t)pm.klf * 16);
     for (int b = 0; b < n_blocks; b++) {
-        uint16_t *bp = pm.params.data() + (size_t)b * block_u16;
         SharedBlock sb;
         sb.offset_u4 = (uint32_t)(((size_t)b * block_u16) / 8);
         sb.first_model = b * SHARED_SB;
         sb.n_models = std::min(SHARED_SB, S - b * SHARED_SB);
         sb.pad = 0;
         pm.blocks.push_back(sb);
+    }
+    // sigma is common to the set: its logarithms and reciprocals once, not once per model
+    std::vector<double> lsg((size_t)K * dim), ivs((size_t)K * dim);
+    for (size_t e = 0; e < (size_t)K * dim; e++) {
+        const double sg = g0.sigma[e];
+        lsg[e] = std::log(SQRT_2_PI * sg);
+        ivs[e] = 1.0 / (sg * sg);
+    }
+    constexpr int MAX_T = 32;
+    double amp_t[MAX_T] = {0}, coef_t[MAX_T] = {0};
+    host_parallel_for(n_blocks, (size_t)SHARED_SB * K * dim, [&](int b, int thr) {
+        std::vector<uint16_t> slots((size_t)pm.klf * 16);
+        double amp_l = amp_t[thr], coef_l = coef_t[thr];
+        uint16_t *bp = pm.params.data() + (size_t)b * block_u16;
         for (int t = 0; t < pm.n_tiles; t++) {
             uint16_t *tp = bp + (size_t)t * (1 + SHARED_SB) * img_u16;
             std::memcpy(tp, qimg.data() + (size_t)t * img_u16, img_u16 * sizeof(uint16_t));
@@ -645,27 +680,26 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                         double cst = f16_dead ? 0.0 : std::log(g.weights[k]);
                         double a = 0.0;
                         for (int d = 0; d < dim; d++) {
-                            const double sg = g.sigma[(size_t)k * dim + d];
                             const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
-                            const double iv = 1.0 / (sg * sg);
+                            const double iv = ivs[(size_t)k * dim + d];
                             const double us = 1.0 / (double)pm.scale[d];
                             const float a1 = (float)(LOG2E * mu * iv * us);
-                            pm.coef_max = std::max(pm.coef_max, (double)std::fabs(a1));
+                            coef_l = std::max(coef_l, (double)std::fabs(a1));
                             uint16_t parts[2];
                             split_f16x2(a1, parts);
                             slots[d] = parts[1];
                             slots[(dim + 1) + d] = parts[0];
                             slots[(2 * dim + 1) + d] = parts[0];
-                            cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
+                            cst -= lsg[(size_t)k * dim + d] + 0.5 * mu * mu * iv;
                             a += mu * mu * iv;
                         }
-                        pm.amp = std::max(pm.amp, a);
+                        amp_l = std::max(amp_l, a);
                         cst *= LOG2E;
                         if (f16_dead) {
                             cst_f = (float)std::max(cst + (double)F16_NEG_BIG, -65000.0);
                         } else if (std::isfinite(cst) && cst > (double)F16_NEG_BIG) {
                             cst_f = (float)cst;
-                            pm.coef_max = std::max(pm.coef_max, (double)std::fabs(cst_f));
+                            coef_l = std::max(coef_l, (double)std::fabs(cst_f));
                         }
                     }
                     uint16_t parts[2];
@@ -676,6 +710,12 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                 }
             }
         }
+        amp_t[thr] = amp_l;
+        coef_t[thr] = coef_l;
+    });
+    for (int t = 0; t < MAX_T; t++) {
+        pm.amp = std::max(pm.amp, amp_t[t]);
+        pm.coef_max = std::max(pm.coef_max, coef_t[t]);
     }
     pm.pad_waste = 1.0 - ((double)K * S) / ((double)pm.n_tiles * MT * n_blocks * SHARED_SB);
     pm.ref = pack_models_split({models[0]}, SPLIT_F16X2);
