@@ -25,6 +25,125 @@ void host_parallel_for(int n, size_t cost_per_piece, F work) {
     for (auto &x : th) x.join();
 }
 
+// ---- decimal <-> double for the text model format.  A configs[3] enrolment is 1001 models x 160 k numbers: strtod and
+// printf would cost more than scoring the rank's shard.  Both directions stay EXACT: the short cuts cover the cases in
+// which one correctly rounded IEEE operation gives the correctly rounded result, everything else goes to libc.
+const double P10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                        1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+// <= 15 significant digits and |decimal exponent| <= 22: mantissa and power of ten are exact doubles, their product or
+// quotient is rounded once (Clinger's fast path) -- all that "%g" ever writes.  false = not taken, nothing consumed.
+inline bool fast_decimal(const char *p, const char *end, const char *&next, double &out) {
+    const char *s = p;
+    bool neg = false;
+    if (s < end && (*s == '-' || *s == '+')) neg = *s++ == '-';
+    uint64_t m = 0;
+    int nd = 0, e10 = 0;
+    bool any = false;
+    for (; s < end && *s >= '0' && *s <= '9'; s++) {
+        any = true;
+        if (m == 0 && *s == '0') continue;
+        if (++nd > 15) return false;
+        m = m * 10 + (uint64_t)(*s - '0');
+    }
+    if (s < end && *s == '.') {
+        for (s++; s < end && *s >= '0' && *s <= '9'; s++) {
+            any = true;
+            e10--;
+            if (m == 0 && *s == '0') continue;
+            if (++nd > 15) return false;
+            m = m * 10 + (uint64_t)(*s - '0');
+        }
+    }
+    if (!any) return false;                                   // nan, inf, garbage: libc decides
+    if (s < end && (*s == 'e' || *s == 'E')) {
+        const char *t = s + 1;
+        bool eneg = false;
+        if (t < end && (*t == '-' || *t == '+')) eneg = *t++ == '-';
+        if (t < end && *t >= '0' && *t <= '9') {
+            int ev = 0;
+            for (; t < end && *t >= '0' && *t <= '9'; t++)
+                if ((ev = ev * 10 + (*t - '0')) > 9999) return false;
+            e10 += eneg ? -ev : ev;
+            s = t;
+        }
+    }
+    if (s < end && (*s == '.' || *s == 'x' || *s == 'X' || *s == 'p' || *s == 'P')) return false;   // hex floats and the like
+    if (m == 0) e10 = 0;
+    if (e10 < -22 || e10 > 22) return false;
+    const double v = e10 < 0 ? (double)m / P10[-e10] : (double)m * P10[e10];
+    out = neg ? -v : v;
+    next = s;
+    return true;
+}
+
+// printf("%g") of a finite non-zero double, without printf: the 6 significant digits come from ONE correctly rounded
+// scaling by a power of ten (exact up to 10^22); a scaled value within 1e-8 of a rounding tie (the scaling's own error is
+// < 2e-10) is left to libc.  Returns the length written, 0 = not taken.
+inline int fast_g6(char *buf, double v) {
+    if (!(v == v) || v == 0.0) return 0;
+    const double a = std::fabs(v);
+    if (!(a >= 1e-12 && a < 1e17)) return 0;
+    int e2;
+    std::frexp(a, &e2);
+    int x = (int)std::floor((e2 - 1) * 0.30102999566398120);  // floor(log10 a) or one less: the loop settles it
+    double scaled = 0.0;
+    for (int tries = 0; tries < 3; tries++) {
+        const int n = 5 - x;
+        scaled = n >= 0 ? a * P10[n] : a / P10[-n];
+        if (scaled < 1e5) x--;
+        else if (scaled >= 1e6) x++;
+        else break;
+    }
+    if (!(scaled >= 1e5 && scaled < 1e6)) return 0;
+    const double fl = std::floor(scaled), fr = scaled - fl;
+    if (std::fabs(fr - 0.5) < 1e-8) return 0;
+    uint32_t dig = (uint32_t)fl + (fr > 0.5 ? 1u : 0u);
+    if (dig == 1000000u) {
+        dig = 100000u;
+        x++;
+    }
+    char d[6];
+    for (int i = 5; i >= 0; i--) {
+        d[i] = (char)('0' + dig % 10);
+        dig /= 10;
+    }
+    int last = 5;                                             // trailing zeros go (no '#' flag)
+    while (last > 0 && d[last] == '0') last--;
+    char *o = buf;
+    if (v < 0) *o++ = '-';
+    if (x < -4 || x >= 6) {                                   // scientific
+        *o++ = d[0];
+        if (last > 0) {
+            *o++ = '.';
+            for (int i = 1; i <= last; i++) *o++ = d[i];
+        }
+        *o++ = 'e';
+        int ex = x;
+        if (ex < 0) {
+            *o++ = '-';
+            ex = -ex;
+        } else {
+            *o++ = '+';
+        }
+        if (ex >= 100) *o++ = (char)('0' + ex / 100);
+        *o++ = (char)('0' + ex / 10 % 10);
+        *o++ = (char)('0' + ex % 10);
+    } else if (x >= 0) {
+        for (int i = 0; i <= x; i++) *o++ = d[i];
+        if (last > x) {
+            *o++ = '.';
+            for (int i = x + 1; i <= last; i++) *o++ = d[i];
+        }
+    } else {
+        *o++ = '0';
+        *o++ = '.';
+        for (int i = 0; i < -x - 1; i++) *o++ = '0';
+        for (int i = 0; i <= last; i++) *o++ = d[i];
+    }
+    return (int)(o - buf);
+}
+
 struct Tok {
     const char *p;
     const char *end;
@@ -38,8 +157,10 @@ struct Tok {
     double num(const char *what) {
         skip();
         if (p >= end) fail("model text truncated while reading %s", what);
+        double v;
+        if (fast_decimal(p, end, p, v)) return v;
         char *q = nullptr;
-        double v = std::strtod(p, &q);
+        v = std::strtod(p, &q);
         if (q == p) fail("model text: cannot parse %s near '%.16s'", what, p);
         p = q;
         return v;
@@ -82,10 +203,12 @@ void gmm_parse_text(const std::string &text, GMM &out) {
     out.single.reset();
 }
 
-static void put(std::string &s, double v) {
+static void put(std::string &s, double v) {   // `out << v << ' '` at default precision = "%g "
     char buf[64];
-    snprintf(buf, sizeof buf, "%g ", v);  // `out << v << ' '` at default precision
-    s += buf;
+    int n = fast_g6(buf, v);
+    if (n == 0) n = snprintf(buf, sizeof buf, "%g", v);
+    buf[n++] = ' ';
+    s.append(buf, (size_t)n);
 }
 
 std::string gmm_format_text(const GMM &g) {

@@ -61,6 +61,52 @@ def test_text_format_host_side(built_lib, oracle_built, gmm_golden, tmp_path):
         GMM.loads("3\n0.5 0.5\n")                 # truncated
 
 
+def test_text_numbers_equal_libc(built_lib):
+    """The model text is written and read without printf / strtod (csrc/gmm_model.cpp fast_g6, fast_decimal): every number
+    must still come out as `out << v` (= "%g") writes it and go in as `in >> v` reads it -- checked against Python's own
+    '%g' and float(), which are libc's, over magnitudes, rounding ties at the 7th digit and odd spellings."""
+    from speaker_recognition_amd.pygmm import GMM
+    rng = np.random.default_rng(3)
+    K, D = 512, 39
+    n = K * D
+    v = np.concatenate([
+        (rng.random(n // 4) - 0.5) * 20,
+        10.0 ** ((rng.random(n // 4) - 0.5) * 44) * rng.choice([-1.0, 1.0], n // 4),
+        (np.floor(rng.random(n // 4) * 1e6) + 0.5) * 10.0 ** rng.integers(-12, 12, n // 4),      # ties at the 7th digit
+        np.round(rng.random(n - 3 * (n // 4)) * 2e6) * 10.0 ** rng.integers(-15, 15, n - 3 * (n // 4)),
+    ])
+    v[:8] = [0.0, -0.0, 1e-310, 999999.5, 9999995.0, 0.0001, 0.00009999995, 123456.5]
+    mean = v.reshape(K, D)
+    sigma = np.abs(rng.permutation(v)).reshape(K, D) + 1e-300
+    m = GMM.from_arrays(np.full(K, 1.0 / K), mean, sigma)
+    tok = m.dumps().split("\n")
+    got_mean = " ".join(tok[3 + 3 * k] for k in range(K)).split()
+    got_sigma = " ".join(tok[4 + 3 * k] for k in range(K)).split()
+    assert got_mean == ["%g" % x for x in mean.ravel()]
+    assert got_sigma == ["%g" % x for x in sigma.ravel()]
+    # reading: what "%g", "%.15g" and "%.17g" write, plus spellings strtod accepts
+    for fmt in ("%g", "%.15g", "%.17g", "%.3e", "%f"):
+        vals = np.where(np.abs(v) < 1e30, v, 1.0) if fmt == "%f" else v
+        words = [fmt % x for x in vals]
+        text = "%d\n%s\n" % (K, " ".join(["%g" % (1.0 / K)] * K))
+        for k in range(K):
+            text += "%d 1\n%s\n%s\n" % (D, " ".join(words[k * D:(k + 1) * D]), " ".join(["1"] * D))
+        _, mu, _ = GMM.loads(text).params()
+        want = np.array([float(w) for w in words]).reshape(K, D)
+        assert np.array_equal(mu.view(np.int64), want.view(np.int64)), fmt
+    odd = ["+1.5", "-.5", "5.", "1e5", "1E-3", "0x10", "1e", "00012.50", "1.7976931348623157e308", "4.9e-324", "nan", "inf", "-inf",
+           "123456789012345678", "0.000000000000000000000000000001"]
+    for w in odd:
+        text = "1\n1\n1 1\n%s\n1\n" % w
+        try:
+            _, mu, _ = GMM.loads(text).params()
+        except Exception:
+            assert w in ("0x10", "1e")            # strtod stops inside the word: what follows is no number
+            continue
+        want = float.fromhex(w) if w.startswith("0x") else float(w)
+        assert np.array_equal(np.array([mu[0, 0]]).view(np.int64), np.array([want]).view(np.int64)), w
+
+
 def test_new_gmm_rejects_non_diagonal(built_lib):
     L = built_lib
     assert not L.new_gmm(4, 2)                    # gmm.cc:211-215 throws; here: NULL + message
