@@ -17,6 +17,7 @@
 #include "../../include/pygmm_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -31,6 +32,8 @@ constexpr float LOG2E_F = 1.4426950408889634f;
 // into LDS.  Phase B (thread = (mixture j, dim d)): sweep the 256 frames of the tile out of LDS.
 // Per-workgroup slabs in global memory take the running sums (only this workgroup touches its
 // slab, in a fixed order -> deterministic); a second kernel adds the slabs in float64.
+// Few tiles (a MAP enrolment is one utterance, ~12 tiles): gridDim.y cuts the records into ranges, so that the chip is
+// busy anyway -- the workgroups of one tile then write disjoint mixture ranges of the same slab.
 template <int DP>
 __global__ __launch_bounds__(256)
 void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
@@ -47,6 +50,9 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
     const int tid = threadIdx.x;
     const int K_pad = n_records * KB;
     float *slab = slabs + (size_t)blockIdx.x * K_pad * REC;
+    const int rec_per = (n_records + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int r_begin = (int)blockIdx.y * rec_per, r_end = min(n_records, r_begin + rec_per);
+    if (r_begin >= r_end) return;              // (whole workgroup, before any barrier)
     // phase-B roles: thread -> (mixture j of the record, dim d); KB * DP of them (one per thread up to DP = 64,
     // a short loop for the wide rows)
 
@@ -70,8 +76,8 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
                 lse2 = ll * LOG2E_F;
             }
         }
-        for (int r = 0; r < n_records; r++) {
-            __syncthreads();                   // previous phase B done with gs / rec_s (and xs on r == 0)
+        for (int r = r_begin; r < r_end; r++) {
+            __syncthreads();                   // previous phase B done with gs / rec_s (and xs on the first record)
             for (int i = tid; i < REC; i += 256) rec_s[i] = params[(size_t)r * REC + i];
             __syncthreads();
             float acc[KB] = {0.f, 0.f, 0.f, 0.f};
@@ -132,7 +138,8 @@ template <int DP>
 static void launch_stats(const float *X, int64_t n, int dim, const float4 *params, const float *center, int n_records,
                          const float *mean_f32, const float *frame_ll, float *slabs, int n_tiles,
                          int grid) {
-    hipLaunchKernelGGL((em_stats_kernel<DP>), dim3(grid), dim3(256), 0, ctx().stream, X, n, dim,
+    const int gy = std::max(1, std::min(n_records, (4 * ctx().n_cu + grid - 1) / grid));
+    hipLaunchKernelGGL((em_stats_kernel<DP>), dim3(grid, gy), dim3(256), 0, ctx().stream, X, n, dim,
                        params, center, n_records, mean_f32, frame_ll, slabs, n_tiles);
 }
 
@@ -205,16 +212,24 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
 
     double last_ll = -std::numeric_limits<double>::max();
     int it = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool trace = param.verbosity >= 2;                 // phase times of every iteration on stdout
     for (; it < param.nr_iteration; it++) {
         // ---- E-step ----
+        const double t0 = now();
         SRModelSet set;
         set.host = pack_models({&gmm});
+        const double t1 = now();
         upload_model_set(set);
+        if (trace) sync_stream();
+        const double t2 = now();
         const int DP = set.host.dp;
         const int n_records = (K + KB - 1) / KB;
         const int K_pad = n_records * KB;
         const int REC = 2 * DP + 1;
         const ScoreResult sres = score_device(set, feat, true, SCORE_PRECISE);
+        if (trace) sync_stream();
+        const double t3 = now();
         std::vector<float> mean_f32((size_t)K_pad * DP, 0.f);
         for (int k = 0; k < K; k++)
             for (int d = 0; d < dim; d++) mean_f32[(size_t)k * DP + d] = (float)gmm.mean[(size_t)k * dim + d];
@@ -235,6 +250,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         std::vector<double> stats(n_elem);
         w.stats.download(stats.data(), n_elem);
         sync_stream();
+        const double t4 = now();
 
         // Mixtures without support: a responsibility below fp32's range (~1e-38) is 0 on the device, while the
         // reference's float64 keeps it down to DBL_MIN -- its N_k is then tiny but not 0, and the mixture's mean
@@ -312,6 +328,9 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
             }
         }
         gmm.single.reset();
+        if (trace)
+            printf("iter %d: pack %.2f ms, upload %.2f ms, posteriors' denominators %.2f ms, statistics %.2f ms, M-step %.2f ms\n", it,
+                   (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
 
         if (it % 2 == 0) continue;                           // gmm.cc:622-623
         // total log-likelihood under the updated model (gmm.cc:631-641), reference clamp on

@@ -147,7 +147,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
         m[f] = NEG_BIG;
         ssum[f] = 0.0f;
     }
-    const float near_thr = lse_near_threshold(clamp);
+    const float drop_thr = clamp ? LSE_MINLOG2 : -3.0e38f;      // wave-uniform
     dma_publish_barrier();   // drains the LDS-DMA of chunk 0 (hipcc emits vmcnt(0) before the barrier)
 
     // One chunk: stage the next one into `other`, run all records of `cur`, close the model
@@ -189,18 +189,16 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                 const float v3 = cc.w - L::get(acc[f / W][3], f % W);
                 const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
                 const float mn = fmaxf(m[f], mx);
-                float e0 = __builtin_amdgcn_exp2f(v0 - mn), e1 = __builtin_amdgcn_exp2f(v1 - mn);
-                float e2 = __builtin_amdgcn_exp2f(v2 - mn), e3 = __builtin_amdgcn_exp2f(v3 - mn);
-                float keep = ssum[f];
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(mn < near_thr) != 0, 0)) {
-                    // next to DBL_MIN the reference's sub-DBL_MIN terms are exactly 0 (lse.hpp)
-                    e0 = v0 >= LSE_MINLOG2 ? e0 : 0.0f;
-                    e1 = v1 >= LSE_MINLOG2 ? e1 : 0.0f;
-                    e2 = v2 >= LSE_MINLOG2 ? e2 : 0.0f;
-                    e3 = v3 >= LSE_MINLOG2 ? e3 : 0.0f;
-                    keep = m[f] >= LSE_MINLOG2 ? keep : 0.0f;
-                }
-                ssum[f] = fmaf(keep, __builtin_amdgcn_exp2f(m[f] - mn), (e0 + e1) + (e2 + e3));
+                // the reference's sub-DBL_MIN terms are exactly 0 (lse.hpp).  Branch-free on purpose: a wave-uniform "only
+                // next to the boundary" branch here, inside the unrolled frame loop, cost this kernel 300-800 dwords of
+                // scratch per lane (1240 B at D = 39, F = 4: 10x slower); four selects per frame and record are ~4 %.
+                // (a running maximum below the boundary means every earlier term was dropped: ssum is already 0)
+                // (the select sits on exp2's ARGUMENT -- 2^-1e30 = 0 -- so that the compiler has nothing expensive to branch around)
+                const float e0 = __builtin_amdgcn_exp2f(v0 >= drop_thr ? v0 - mn : LSE_NEG_BIG);
+                const float e1 = __builtin_amdgcn_exp2f(v1 >= drop_thr ? v1 - mn : LSE_NEG_BIG);
+                const float e2 = __builtin_amdgcn_exp2f(v2 >= drop_thr ? v2 - mn : LSE_NEG_BIG);
+                const float e3 = __builtin_amdgcn_exp2f(v3 >= drop_thr ? v3 - mn : LSE_NEG_BIG);
+                ssum[f] = fmaf(ssum[f], __builtin_amdgcn_exp2f(m[f] - mn), (e0 + e1) + (e2 + e3));
                 m[f] = mn;
             }
         }
@@ -343,15 +341,18 @@ static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
 
 template <int DP>
 static void dispatch_f(const ScoreArgs &a, int F, bool pk, int n_tiles, int n_groups) {
-    if (F == 1) return launch_score<DP, 1, false>(a, n_tiles, n_groups);
-    if constexpr (DP > 64) return launch_score<DP, 1, false>(a, n_tiles, n_groups);     // wide rows: one frame per lane
-    if (F == 2) return pk ? launch_score<DP, 2, true>(a, n_tiles, n_groups)
-                          : launch_score<DP, 2, false>(a, n_tiles, n_groups);
-    if constexpr (DP <= 40) {
-        if (F == 4) return pk ? launch_score<DP, 4, true>(a, n_tiles, n_groups)
-                              : launch_score<DP, 4, false>(a, n_tiles, n_groups);
+    if constexpr (DP > 64) {
+        return launch_score<DP, 1, false>(a, n_tiles, n_groups);     // wide rows: one frame per lane
+    } else {
+        if (F == 1) return launch_score<DP, 1, false>(a, n_tiles, n_groups);
+        if (F == 2) return pk ? launch_score<DP, 2, true>(a, n_tiles, n_groups)
+                              : launch_score<DP, 2, false>(a, n_tiles, n_groups);
+        if constexpr (DP <= 40) {
+            if (F == 4) return pk ? launch_score<DP, 4, true>(a, n_tiles, n_groups)
+                                  : launch_score<DP, 4, false>(a, n_tiles, n_groups);
+        }
+        fail("frames_per_lane=%d not instantiated for dim %d", F, DP);
     }
-    fail("frames_per_lane=%d not instantiated for dim %d", F, DP);
 }
 
 static void dispatch(const ScoreArgs &a, int DP, int F, bool pk, int n_tiles, int n_groups) {
@@ -656,6 +657,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     if (DP > 64) F = 1;
+    // few workgroups (one utterance against one model: every E-step of a MAP enrolment): a lane that holds F frames runs
+    // F times as long, so the frames go to more workgroups first (3000 frames x 1 model: 3 workgroups at F = 4, 12 at F = 1)
+    if (!opt.frames_per_lane)
+        while (F > 1 && ((feat.n_rows + 256 * F - 1) / (256 * F)) * (int64_t)std::max(1, S) < 2 * (int64_t)ctx().n_cu) F >>= 1;
     int FT = opt.mfma_ft;
     if (FT == 0) {
         // measured (scripts/tune_score.py over D in {13,26,34,39}, K in {64..2048}): one 32-frame column

@@ -107,6 +107,59 @@ def test_text_numbers_equal_libc(built_lib):
         assert np.array_equal(np.array([mu[0, 0]]).view(np.int64), np.array([want]).view(np.int64)), w
 
 
+def _kernel_resources(name):
+    """{mangled kernel name: {vgpr, scratch, occupancy}} from the remarks the build keeps next to every object (csrc/Makefile)."""
+    import re
+    path = os.path.join(ROOT, "speaker-recognition_amd", "build", name + ".resources")
+    assert os.path.exists(path), "the build did not leave %s" % path
+    out, cur = {}, None
+    for line in open(path):
+        m = re.search(r" Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgpr", r"\bVGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    assert out, "no kernel remarks in %s" % path
+    return out
+
+
+def test_no_hot_kernel_spills(built_lib):
+    """Scratch (register spills) per lane of the kernels on the hot paths, as the compiler reports it for gfx950.  Parity tests
+    cannot see a spill; this one caught nothing in time once: the vector engine ran 10x slower for most of a round behind a
+    wave-uniform branch in its log-sum-exp (1240 B of scratch per lane at D = 39, F = 4)."""
+    import re
+    vec = _kernel_resources("gmm_score")
+    seen = 0
+    for name, r in vec.items():
+        m = re.search(r"gmm_score_kernelILi(\d+)ELi(\d+)ELb(\d)", name)
+        if not m:
+            continue
+        seen += 1
+        dp, f, pk = (int(v) for v in m.groups())
+        assert r["scratch"] <= (64 if (dp, f, pk) == (56, 2, 1) else 0), (dp, f, pk, r)
+    assert seen >= 40
+    for name, r in _kernel_resources("em").items():
+        assert r["scratch"] == 0, (name, r)
+    for name, r in _kernel_resources("gmm_score_split").items():
+        assert r["scratch"] <= 32, (name, r)
+    for name, r in _kernel_resources("gmm_score_mfma").items():
+        assert r["scratch"] == 0, (name, r)
+    h2s = _kernel_resources("gmm_score_h2_shared")
+    # the shared-sigma engine's frame-operand prologue spills (its image loop holds ONE scratch load: checked in the ISA,
+    # profiles/r02_h2s_stalls.txt); a bound, so that it cannot grow unnoticed.  configs[2] / [3]: <8,8,*>
+    for name, r in h2s.items():
+        m = re.search(r"gmm_score_h2s_kernelILi(\d+)ELi(\d+)E", name)
+        if m and (int(m.group(1)), int(m.group(2))) <= (8, 8):
+            assert r["scratch"] <= 400 and r["occupancy"] >= 3, (name, r)
+    mf = _kernel_resources("mfcc")
+    head = [r for n, r in mf.items() if "mfcc_frames_fft2048_kernelIsLi4ELi1ELi12ELi16E" in n]
+    assert len(head) == 1 and head[0]["scratch"] <= 128 and head[0]["occupancy"] >= 3, head
+
+
 def test_new_gmm_rejects_non_diagonal(built_lib):
     L = built_lib
     assert not L.new_gmm(4, 2)                    # gmm.cc:211-215 throws; here: NULL + message
