@@ -1,0 +1,162 @@
+// Host-side checks of csrc/gmm_model.cpp, built by tests/test_host_sanitizers.py with -fsanitize=address,undefined (and once
+// with -fsanitize=thread): the model packers (every layout, threaded and not), the text parser on mutated model texts, and
+// the printf / strtod-free number conversions against libc.  Test infrastructure: not part of lib/pygmm.so.
+#include "gmm_model.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <stdexcept>
+
+namespace sr {
+void fail(const char *fmt, ...) {                      // the library's throws sr::Error; any exception type serves here
+    char b[256];
+    va_list a;
+    va_start(a, fmt);
+    vsnprintf(b, sizeof b, fmt, a);
+    va_end(a);
+    throw std::runtime_error(b);
+}
+}  // namespace sr
+using namespace sr;
+
+static std::vector<GMM> make_set(int S, int K, int D, bool shared, unsigned seed) {
+    std::mt19937 r(seed);
+    std::normal_distribution<double> nd;
+    std::vector<GMM> ms(S);
+    for (int s = 0; s < S; s++) {
+        GMM &g = ms[s];
+        g.nr_mixtures = K;
+        g.dim = D;
+        if (s == 0 || !shared) {
+            g.weights.assign(K, 1.0 / K);
+            g.mean.resize((size_t)K * D);
+            g.sigma.resize((size_t)K * D);
+            for (auto &v : g.mean) v = nd(r) * 3;
+            for (auto &v : g.sigma) v = 0.5 + std::abs(nd(r));
+        } else {
+            g = ms[0];
+            for (size_t i = 0; i < g.mean.size(); i += 3) g.mean[i] += 0.1 * nd(r);
+        }
+    }
+    return ms;
+}
+
+static int check_packers(int S, int K, int D) {
+    for (int shared = 0; shared < 2; shared++) {
+        auto ms = make_set(S, K, D, shared != 0, 7 + shared);
+        ms[S / 2].weights[K / 2] = 0.0;                 // a dead mixture
+        std::vector<const GMM *> v;
+        for (auto &g : ms) v.push_back(&g);
+        auto host = pack_models(v);
+        auto mf = pack_models_mfma(v, host.dp);
+        auto b3 = pack_models_split(v, SPLIT_BF16X3);
+        auto h2 = pack_models_split(v, SPLIT_F16X2);
+        if (host.params.empty() || mf.params.empty() || b3.params.empty() || h2.params.empty()) return 1;
+        if (models_share_sigma_and_weights(v) != (shared != 0 && false)) {
+            // (the dead mixture breaks weight sharing on purpose: both answers are exercised below)
+        }
+        ms[S / 2].weights[K / 2] = 1.0 / K;
+        if (shared) {
+            if (!models_share_sigma_and_weights(v)) return 2;
+            auto sh = pack_models_bx3_shared(v);
+            auto hs = pack_models_h2_shared(v);
+            if (sh.params.empty() || hs.params.empty() || !(hs.amp > 0)) return 3;
+        }
+    }
+    return 0;
+}
+
+static int check_parser(int iters) {
+    std::mt19937 r(3);
+    auto ms = make_set(1, 5, 7, false, 11);
+    const std::string base = gmm_format_text(ms[0]);
+    GMM back;
+    gmm_parse_text(base, back);
+    if (gmm_format_text(back) != base) return 1;
+    const char junk[] = "0123456789.eE+-xX nanif\n\t,;:pP";
+    long parsed = 0;
+    for (int it = 0; it < iters; it++) {
+        std::string t = base;
+        const int nmut = 1 + (int)(r() % 4);
+        for (int m = 0; m < nmut; m++) {
+            switch (r() % 4) {
+            case 0: t.resize(r() % (t.size() + 1)); break;
+            case 1: if (!t.empty()) t[r() % t.size()] = junk[r() % (sizeof junk - 1)]; break;
+            case 2: if (!t.empty()) t.insert(r() % t.size(), 1, junk[r() % (sizeof junk - 1)]); break;
+            default: if (!t.empty()) t.erase(r() % t.size(), 1 + r() % 3);
+            }
+        }
+        try {
+            GMM h;
+            gmm_parse_text(std::string(t.data(), t.size()), h);
+            parsed++;
+            if (h.trained() && h.dim <= 64) (void)pack_models({&h});
+        } catch (const std::exception &) {
+        }
+    }
+    return parsed > 0 ? 0 : 2;
+}
+
+// the text format's numbers against printf("%g") / strtod, through the only doors the file has: format and parse
+static int check_numbers(int n) {
+    std::mt19937_64 r(7);
+    std::uniform_real_distribution<double> u(0, 1);
+    GMM g;
+    g.nr_mixtures = 1;
+    g.dim = n;
+    g.weights = {1.0};
+    g.mean.resize(n);
+    g.sigma.assign(n, 1.0);
+    for (int i = 0; i < n; i++) {
+        double v;
+        switch (i % 5) {
+        case 0: v = (u(r) - 0.5) * 20; break;
+        case 1: v = std::pow(10.0, (u(r) - 0.5) * 40) * (u(r) < 0.5 ? -1 : 1); break;
+        case 2: v = (std::floor(u(r) * 1e6) + 0.5) * std::pow(10.0, (int)(u(r) * 24) - 12); break;   // ties at the 7th digit
+        case 3: v = (double)(long)(u(r) * 2000000) * std::pow(10.0, (int)(u(r) * 30) - 15); break;
+        default: { uint64_t b = r(); std::memcpy(&v, &b, 8); if (!(std::fabs(v) < 1e300)) v = 1.0; }
+        }
+        g.mean[i] = v;
+    }
+    const std::string text = gmm_format_text(g);
+    // line 0: "1", line 1: weights, line 2: "dim cov", line 3: means
+    size_t pos = 0;
+    for (int l = 0; l < 3; l++) pos = text.find('\n', pos) + 1;
+    const char *p = text.c_str() + pos;
+    for (int i = 0; i < n; i++) {
+        char want[64];
+        const int len = snprintf(want, sizeof want, "%g", g.mean[i]);
+        if (std::strncmp(p, want, (size_t)len) != 0 || p[len] != ' ') {
+            fprintf(stderr, "format of %.17g: got '%.24s', libc '%s'\n", g.mean[i], p, want);
+            return 1;
+        }
+        p += len + 1;
+    }
+    GMM back;
+    gmm_parse_text(text, back);
+    for (int i = 0; i < n; i++) {
+        char w[64];
+        snprintf(w, sizeof w, "%g", g.mean[i]);
+        const double ref = std::strtod(w, nullptr);
+        if (std::memcmp(&ref, &back.mean[i], 8) != 0) {
+            fprintf(stderr, "parse of '%s': %.17g, libc %.17g\n", w, back.mean[i], ref);
+            return 2;
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const bool big = argc > 1 && std::strcmp(argv[1], "threads") == 0;     // sizes at which the packers go multi-threaded
+    int rc = big ? check_packers(150, 1024, 39) : (check_packers(17, 37, 13) | check_packers(31, 64, 39));
+    if (rc) return printf("packers: %d\n", rc), 10 + rc;
+    if (!big) {
+        if ((rc = check_parser(20000))) return printf("parser: %d\n", rc), 20 + rc;
+        if ((rc = check_numbers(300000))) return printf("numbers: %d\n", rc), 30 + rc;
+    }
+    printf("host checks ok\n");
+    return 0;
+}
