@@ -38,7 +38,8 @@ struct Parameter {
     int nr_iteration;
     int init_with_kmeans;
     int concurrency;
-    int verbosity;
+    int verbosity;          /* >= 1: the reference's progress lines (gmm.cc:588-590, :641); >= 2 (extension): the phase
+                               times of every EM / MAP iteration on stdout */
 };
 
 /* ---------------- Part 1: legacy symbols (pygmm.hh:28-41) ---------------- */
