@@ -93,12 +93,17 @@ int sr_gmm_dumps(GMM *gmm, char *buf, long buflen, long *needed);     /* text fo
 GMM *sr_gmm_loads(const char *text);
 
 /* Contiguous fp32 scoring of ONE model (frames row-major [n][dim], host memory).
- * flags: SR_CLAMP_COMPAT reproduces the reference's underflow behaviour: its mixture sum runs in
- * the linear domain under FTZ arithmetic, so a term w_k p_k(x) below DBL_MIN = exp(-708.396) counts
- * as 0 and an all-zero sum returns ln(1e-15) (gmm.cc:34-38, :237-244; pinned by reference-DSO
- * vectors, tests/golden/make_clamp_golden.py).  Not reproduced: the reference's flush of partial
- * products in dimension order and its per-dimension exponent floor (fastexp.cc:104-131), which only
- * differ for frames ~37 sigma away from every mixture.
+ * flags: SR_CLAMP_COMPAT reproduces the reference's underflow behaviour: its densities and its mixture
+ * sum are formed in the linear domain under FTZ arithmetic, so a term w_k p_k(x) below DBL_MIN =
+ * exp(-708.396) counts as 0 and an all-zero sum returns ln(1e-15) (gmm.cc:34-38, :237-244; pinned by
+ * reference-DSO vectors, tests/golden/make_clamp_golden.py) -- and so does a term any PARTIAL product of
+ * which dips below DBL_MIN (gmm.cc:192-195), or one dimension of which reaches the exponent floor of
+ * fastexp.cc:104-131, although its full product would be representable.  The frames this can matter
+ * for (log-likelihood within a few tens of nats of -708.4: frames ~37 sigma from every mixture) are found
+ * by every engine and re-evaluated with the reference's own arithmetic (csrc/gmm_flush.hip; pinned by
+ * tests/golden/make_flush_golden.py on the DSO).  Which partial products exist is the compiler's choice under
+ * the reference's -ffast-math: option "flush_order" 2 (default) = the DSO as g++ 11 builds it from the
+ * reference's flags (even / odd dimension lanes), 1 = the source's order.
  * SR_SCORE_PRECISE keeps to the fp32-grade engines (the split-fp16 ones carry 22 significand bits). */
 #define SR_CLAMP_COMPAT 1
 #define SR_SCORE_PRECISE 0x200
@@ -242,8 +247,12 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *   "score_mfma_ft" column tiles per wave, "score_h2s_force_exc" 1 (testing: everything through the
  *   exception pass of engine 6), "score_h2s_shape" 1 (4-wave workgroups) | 2 (12-wave workgroups) of engine 6,
  *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
- *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel). */
+ *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
+ *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT). */
 int sr_set_option(const char *key, long value);
+/* Counters of the partial-product path since the library was loaded: resolve calls, (frame tile, model) pairs
+ * noted by the engines, frames re-evaluated.  Any pointer may be NULL. */
+void sr_flush_stats(long *calls, long *pairs, long *frames);
 /* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */
 const char *sr_last_score_kernel(void);
 /* The first `count` values of the random stream train_model / load draw from when no seed is given: glibc's rand()

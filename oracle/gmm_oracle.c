@@ -47,9 +47,11 @@ static double flush(double v, int ftz)
  * clamp to [minlog, maxlog] (:104-105,128-131), a = x*log2e (:134-137),
  * k = trunc(a - (a<0)) (:140-149), x -= k*C1, x -= k*C2 (:152-161),
  * degree-5 polynomial in Horner form (:164-192), scale by 2^k built from the
- * exponent bits (:195-206).
+ * exponent bits (:195-206).  Under FTZ the last product flushes: at the lower clamp
+ * (x = minlog, k = -1022, polynomial = w0 < 1) the result is below DBL_MIN, i.e. exactly 0 --
+ * a dimension whose exponent reaches the floor zeroes its whole mixture.
  */
-static double remez5_exp(double x)
+static double remez5_exp(double x, int ftz)
 {
     const double maxlog = 7.09782712893383996843e2;
     const double minlog = -7.08396418532264106224e2;
@@ -79,22 +81,56 @@ static double remez5_exp(double x)
     uint64_t bits = ((uint64_t)(uint32_t)(k + 1023)) << 52;
     double scale;
     memcpy(&scale, &bits, sizeof scale);
-    return a * scale;
+    return flush(a * scale, ftz);
 }
 
 /* src/gmm/src/gmm.cc:176-202 -- Gaussian::probability_of_fast_exp:
- * buf[i] = -d*d/(2 s s) (:186-190), vector exp (:191), prod buf[i]/(sqrt(2pi) s) (:192-195). */
+ * buf[i] = -d*d/(2 s s) (:186-190), vector exp (:191), prod buf[i]/(sqrt(2pi) s) (:192-195).
+ *
+ * WHICH partial products exist -- and therefore which of them can flush to zero under the DSO's
+ * FTZ arithmetic -- is decided by the compiler, not by the source: -ffast-math lets it reassociate.
+ *   order 1: the source's order, one running product over the dimensions, p_i = e_i / (sqrt(2 pi) s_i).
+ *   order 2: what g++ 11 -O3 -ffast-math -msse2 (the reference's flags, oracle/Makefile) emits, read
+ *            off the disassembly of oracle/_ref/pygmm_ref.so: buf[i] = (x-m)(m-x) 0.5 / (s s);
+ *            p_i = (e_i * 0.3989422804014327) / s_i  (a multiply by the folded 1/sqrt(2 pi), THEN
+ *            the division -- the multiply can flush although the quotient would not); two running
+ *            products, one over the even and one over the odd dimensions (mulpd on pairs), then
+ *            even * odd, then -- dim odd -- the last dimension's factor.
+ * Every operation's result flushes when `ftz`.  Pinned against the DSO by
+ * tests/golden/make_flush_golden.py. */
 static double gaussian_prob_fastexp(const double *x, const double *mean, const double *sigma,
-                                    int dim, int ftz)
+                                    int dim, int ftz, int order)
 {
-    double prob = 1.0;
+    if (order == 1) {
+        double prob = 1.0;
+        for (int i = 0; i < dim; i++) {
+            double s = sigma[i];
+            double d = x[i] - mean[i];
+            double e = remez5_exp(flush(-d * d / (2 * s * s), ftz), ftz);
+            double p = flush(e / (SQRT_2_PI * s), ftz);
+            prob = flush(prob * p, ftz);
+        }
+        return prob;
+    }
+    const double inv_sqrt_2pi = 0.3989422804014327;   /* 0x3FD9884533D43651, the DSO's folded constant */
+    double lane[2] = {1.0, 1.0};
+    double tail = 1.0;
+    const int paired = dim & ~1;
     for (int i = 0; i < dim; i++) {
         double s = sigma[i];
-        double d = x[i] - mean[i];
-        double e = remez5_exp(-d * d / (2 * s * s));
-        double p = e / (SQRT_2_PI * s);
-        prob = flush(prob * p, ftz);
+        double t = flush((x[i] - mean[i]) * (mean[i] - x[i]), ftz);
+        t = flush(t * 0.5, ftz);
+        double b = flush(t / flush(s * s, ftz), ftz);
+        double e = remez5_exp(b, ftz);
+        double p = flush(flush(e * inv_sqrt_2pi, ftz) / s, ftz);
+        if (i < paired)
+            lane[i & 1] = flush(lane[i & 1] * p, ftz);
+        else
+            tail = p;
     }
+    double prob = flush(lane[0] * lane[1], ftz);
+    if (dim & 1)
+        prob = flush(prob * tail, ftz);
     return prob;
 }
 
@@ -137,6 +173,10 @@ static double gaussian_logprob(const double *x, const double *mean, const double
  * Layout: weights[K], mean[K*D], sigma[K*D] (sigma = standard deviations, gmm.hh:24-46),
  * X[n*D] row-major, out[n].
  */
+static int g_flush_order = 2;
+/* 1 = source order, 2 = as compiled (see gaussian_prob_fastexp); the default is what the DSO does */
+void oracle_set_flush_order(int order) { g_flush_order = order == 1 ? 1 : 2; }
+
 void oracle_gmm_score_batch(const double *weights, const double *mean, const double *sigma,
                             int K, int D, const double *X, long n, double *out,
                             int mode, int ftz, int clamp_compat)
@@ -147,7 +187,7 @@ void oracle_gmm_score_batch(const double *weights, const double *mean, const dou
             double prob = 0;
             for (int k = 0; k < K; k++) {
                 double p = (mode == 0)
-                    ? gaussian_prob_fastexp(x, mean + (long)k * D, sigma + (long)k * D, D, ftz)
+                    ? gaussian_prob_fastexp(x, mean + (long)k * D, sigma + (long)k * D, D, ftz, g_flush_order)
                     : gaussian_prob_libm(x, mean + (long)k * D, sigma + (long)k * D, D, ftz);
                 prob += flush(weights[k] * p, ftz);
             }
@@ -217,7 +257,7 @@ void oracle_gmm_em_iteration(double *weights, double *mean, double *sigma, int K
     for (int k = 0; k < K; k++)
         for (long i = 0; i < n; i++)
             resp[(long)k * n + i] = weights[k] *
-                gaussian_prob_fastexp(X + i * (long)D, mean + (long)k * D, sigma + (long)k * D, D, ftz);
+                gaussian_prob_fastexp(X + i * (long)D, mean + (long)k * D, sigma + (long)k * D, D, ftz, g_flush_order);
     for (long i = 0; i < n; i++) {
         double sum = 0;
         for (int k = 0; k < K; k++)

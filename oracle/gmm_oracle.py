@@ -107,6 +107,8 @@ def _lib():
         lib.oracle_gmm_em_iteration.argtypes = [dp, dp, dp, C.c_int, C.c_int, dp, C.c_long,
                                                 C.c_double, C.c_double, dp, dp, C.c_int]
         lib.oracle_gmm_em_iteration.restype = None
+        lib.oracle_set_flush_order.argtypes = [C.c_int]
+        lib.oracle_set_flush_order.restype = None
         _oracle = lib
     return _oracle
 
@@ -128,6 +130,12 @@ def score_batch(p: GMMParams, X: np.ndarray, mode: int = MODE_FASTEXP, ftz: bool
     _lib().oracle_gmm_score_batch(_dp(w), _dp(mu), _dp(sg), p.K, p.D, _dp(X), n, _dp(out),
                                   mode, int(ftz), int(clamp_compat))
     return out
+
+
+def set_flush_order(order: int) -> None:
+    """Which partial products mode 0 forms (and flushes): 2 = as the reference DSO's compiler does (default), 1 = the
+    source's order; oracle/gmm_oracle.c gaussian_prob_fastexp."""
+    _lib().oracle_set_flush_order(int(order))
 
 
 def score_all(p: GMMParams, X: np.ndarray, mode: int = MODE_FASTEXP, ftz: bool = True,

@@ -30,7 +30,7 @@ EXT_SYMBOLS = [
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
     "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
-    "sr_hbm_copy_gbps", "sr_reference_rand_sample",
+    "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -123,6 +123,7 @@ def lib():
         "sr_profile_get": (i32, [i32, dp, C.POINTER(C.c_long)]),
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
+        "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
         "sr_reference_rand_sample": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
         "sr_ltsd_num_windows": (i64, [i64, i32]),
         "sr_ltsd_noise_spectrum": (i32, [vp, i32, fp]),
@@ -214,6 +215,13 @@ def synchronize() -> None:
 
 def set_option(key: str, value: int) -> None:
     check(lib().sr_set_option(key.encode(), int(value)), "sr_set_option")
+
+
+def flush_stats():
+    """(resolve calls, (tile, model) pairs noted, frames re-evaluated) of the partial-product path (csrc/gmm_flush.hip)."""
+    v = [C.c_long(0) for _ in range(3)]
+    lib().sr_flush_stats(*[C.byref(x) for x in v])
+    return tuple(int(x.value) for x in v)
 
 
 def last_score_kernel() -> str:

@@ -53,13 +53,14 @@ using namespace sr;
 static SRModelSet &single_set(GMM *g) {
     if (!g) fail("null GMM handle");
     if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
-    if (!g->single || g->single->device != ctx().device) {
+    auto &slot = g->single[current_device()];          // one per device: the caller holds this device's lock
+    if (!slot || slot->device != ctx().device) {
         auto s = std::make_shared<SRModelSet>();
         pack_model_set(*s, {g});
         upload_model_set(*s);
-        g->single = s;
+        slot = s;
     }
-    return *g->single;
+    return *slot;
 }
 
 static std::unique_ptr<SRBatch> feature_batch(const float *X, int64_t n, int dim,
@@ -96,20 +97,27 @@ static std::vector<float> rows_to_f32(double **X, long n, int dim) {
 // The legacy ABI scores ONE model per call, and its callers loop over the speakers with the same
 // utterance (gmmset.py:59-64, :95-99: S calls of score_all(x)): re-uploading x S times would make
 // the drop-in path pay S H2D copies and S tile-table builds.  The last uploaded matrix stays on the
-// device, keyed by shape and a 64-bit FNV-1a hash of its fp32 contents (~0.1 ms per MB on the host).
+// device, keyed by shape and a 64-bit FNV-1a hash of its fp32 contents (~0.1 ms per MB on the host); a hit is confirmed
+// by comparing the contents with the host copy kept beside it (a hash alone would score the wrong utterance on a
+// collision).  Matrices above LEGACY_CACHE_MAX_BYTES are not kept (neither copy outlives the call).
+constexpr size_t LEGACY_CACHE_MAX_BYTES = (size_t)256 << 20;
 struct LegacyFeatureCache {
     uint64_t hash = 0;
     long n = -1;
     int dim = -1;
+    std::vector<float> host;
     std::unique_ptr<SRBatch> batch;
 };
 
 static uint64_t fnv1a(const void *p, size_t bytes) {
-    const uint64_t *w = static_cast<const uint64_t *>(p);
+    const unsigned char *b = static_cast<const unsigned char *>(p);
     uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i < bytes / 8; i++) h = (h ^ w[i]) * 1099511628211ull;
-    const unsigned char *c = static_cast<const unsigned char *>(p) + (bytes & ~(size_t)7);
-    for (size_t i = 0; i < (bytes & 7); i++) h = (h ^ c[i]) * 1099511628211ull;
+    for (size_t i = 0; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);                     // (the caller's floats are 4-byte aligned)
+        h = (h ^ w) * 1099511628211ull;
+    }
+    for (size_t i = bytes & ~(size_t)7; i < bytes; i++) h = (h ^ b[i]) * 1099511628211ull;
     return h;
 }
 
@@ -118,17 +126,27 @@ static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, do
     SRModelSet &set = single_set(g);
     if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
     auto &cache = per_device<LegacyFeatureCache>();
-    const uint64_t h = fnv1a(X, (size_t)n * dim * sizeof(float));
-    if (!cache.batch || cache.n != n || cache.dim != dim || cache.hash != h) {
+    const size_t bytes = (size_t)n * dim * sizeof(float);
+    const uint64_t h = fnv1a(X, bytes);
+    const bool hit = cache.batch && cache.n == n && cache.dim == dim && cache.hash == h &&
+                     cache.host.size() * sizeof(float) == bytes && std::memcmp(cache.host.data(), X, bytes) == 0;
+    if (!hit) {
         const int64_t off[2] = {0, n};
+        cache.batch.reset();                               // (frees the previous matrix before the new one is allocated)
         cache.batch = feature_batch(X, n, dim, off, 1);
         cache.n = n;
         cache.dim = dim;
         cache.hash = h;
+        if (bytes <= LEGACY_CACHE_MAX_BYTES) cache.host.assign(X, X + (size_t)n * dim);
+        else std::vector<float>().swap(cache.host);
     }
     double sum = 0.0;
     score_batch_set(set, *cache.batch, &sum, nullptr, ll_out, flags);
     if (sum_out) *sum_out = sum;
+    if (bytes > LEGACY_CACHE_MAX_BYTES) {                  // too large to pin in HBM between calls
+        cache.batch.reset();
+        cache.n = -1;
+    }
 }
 
 extern "C" {
@@ -545,12 +563,10 @@ static void predict_unpipelined(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd
     SRBatch *feat_ws = &per_device<SRBatch>();   // reused across steps: the serving loop allocates nothing
     mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
     const ScoreResult r = score_device(*set, *feat_ws, false, flags);
-    if (!fetch_results(r, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
-                       argmax_out, nullptr)) {
+    if (!fetch_results(*set, *feat_ws, flags, r, sums_out, argmax_out, nullptr)) {
         // a frame left the fp16 engine's range: score the batch again on the fp32-grade engines
         const ScoreResult r2 = score_device(*set, *feat_ws, false, flags | SCORE_PRECISE);
-        fetch_results(r2, (size_t)feat_ws->n_utt, (size_t)set->host.n_models, (size_t)feat_ws->n_rows, sums_out,
-                      argmax_out, nullptr);
+        fetch_results(*set, *feat_ws, flags | SCORE_PRECISE, r2, sums_out, argmax_out, nullptr);
     }
 }
 
@@ -590,10 +606,10 @@ void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_
     bound[chunks] = U;
     pp.sums.ensure((size_t)std::max(1, U) * S);
     pp.argmax.ensure((size_t)std::max(1, U));
-    pp.oor.ensure(PredictPipe::MAX_CHUNKS);
+    pp.oor.ensure(2 * PredictPipe::MAX_CHUNKS);
     for (int c = 0; c < chunks; c++) {
         if (!pp.ready[c]) SR_HIP(hipEventCreateWithFlags(&pp.ready[c], hipEventDisableTiming));
-        pp.oor.p[c] = 0;
+        pp.oor.p[c] = pp.oor.p[PredictPipe::MAX_CHUNKS + c] = 0;
     }
     {
         StreamScope feature_stage(ctx().aux);
@@ -610,10 +626,20 @@ void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_
         SR_HIP(hipMemcpyAsync(pp.sums.p + (size_t)u0 * S, r.d_sums, (size_t)n * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         SR_HIP(hipMemcpyAsync(pp.argmax.p + u0, r.d_argmax, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
         if (r.d_oor) SR_HIP(hipMemcpyAsync(pp.oor.p + c, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        if (r.d_flush_count)
+            SR_HIP(hipMemcpyAsync(pp.oor.p + PredictPipe::MAX_CHUNKS + c, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
     }
     sync_stream();
-    bool saturated = false;
-    for (int c = 0; c < chunks; c++) saturated |= pp.oor.p[c] != 0;
+    bool saturated = false, band = false;
+    for (int c = 0; c < chunks; c++) {
+        saturated |= pp.oor.p[c] != 0;
+        band |= pp.oor.p[PredictPipe::MAX_CHUNKS + c] != 0;
+    }
+    if (band && !saturated) {
+        // frames in the band where the reference's partial-product flushes decide (lse.hpp): one pass, resolved there
+        predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags);
+        return;
+    }
     if (saturated) {
         // a frame left the fp16 engine's range: the whole batch again, one pass, fp32-grade engines
         predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags | SCORE_PRECISE);
@@ -744,6 +770,11 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");
         score_options().mfma_ft = (int)value;
+    } else if (k == "flush_order") {
+        if (value != 1 && value != 2)
+            fail("flush_order must be 2 (partial products as the reference DSO's compiler forms them: even / odd dimensions) or "
+                 "1 (the source's order, gmm.cc:192-195)");
+        flush_order_option() = (int)value;
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
     } else if (k == "mfcc_generic") {
@@ -756,6 +787,8 @@ int sr_set_option(const char *key, long value) {
 }
 
 const char *sr_last_score_kernel(void) { return last_score_kernel(); }
+
+void sr_flush_stats(long *calls, long *pairs, long *frames) { flush_stats(calls, pairs, frames); }
 
 int sr_reference_rand_sample(int *out, int count) {
     SR_TRY

@@ -22,6 +22,7 @@ struct TileTable {
     int n_tiles = 0;
     DevBuf<TileDesc> d_tiles;
     DevBuf<int> d_utt_tile_begin;  // [U+1]
+    std::vector<TileDesc> h_tiles; // host copy (the partial-product path maps noted tiles back to utterances)
 };
 
 }  // namespace sr
@@ -42,6 +43,9 @@ struct SRBatch {
     sr::TileTable &tiles_for(int frames_per_tile);
     // binds an empty batch to the calling thread's device / refuses one that lives elsewhere
     void bind_device() {
+        // HIP's current device is per host thread: a thread that chose device d and whose first library call is one that
+        // only (re)fills a batch must not allocate on device 0 (ensure_device is what calls hipSetDevice)
+        sr::ensure_device();
         if (device < 0) device = sr::current_device();
         if (device != sr::current_device())
             sr::fail("batch lives on device %d, the calling thread is on device %d", device, sr::current_device());

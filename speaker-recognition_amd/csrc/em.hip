@@ -182,7 +182,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         gmm.weights = ubm->weights;
         gmm.mean = ubm->mean;
         gmm.sigma = ubm->sigma;
-        gmm.single.reset();
+        gmm.drop_single();
         if (seed < 0) burn_reference_rand(1 + gmm.nr_mixtures);   // the legacy symbol: keep libc's stream in step with the reference
     } else if (param.init_with_kmeans < 0 && gmm.trained() && gmm.dim == dim) {
         // extension: warm start from the handle's current parameters (no re-initialisation)
@@ -327,7 +327,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
                 }
             }
         }
-        gmm.single.reset();
+        gmm.drop_single();
         if (trace)
             printf("iter %d: pack %.2f ms, upload %.2f ms, posteriors' denominators %.2f ms, statistics %.2f ms, M-step %.2f ms\n", it,
                    (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);

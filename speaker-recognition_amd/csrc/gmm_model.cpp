@@ -200,7 +200,7 @@ void gmm_parse_text(const std::string &text, GMM &out) {
     out.weights = std::move(w);
     out.mean = std::move(mean);
     out.sigma = std::move(sigma);
-    out.single.reset();
+    out.drop_single();
 }
 
 static void put(std::string &s, double v) {   // `out << v << ' '` at default precision = "%g "
@@ -279,6 +279,7 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
         total_f4 += (size_t)n_rec * rec_f4;
     }
     pm.params.assign(total_f4 * 4, 0.0f);
+    std::vector<double> lift(pm.n_models, 0.0);             // per model: max_k sum_d max(0, -ln sigma_kd)
     host_parallel_for(pm.n_models, (size_t)models[0]->nr_mixtures * pm.dim, [&](int s, int) {
         const GMM &g = *models[s];
         const int K = g.nr_mixtures;
@@ -295,8 +296,10 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
                 // c = log2e * (ln w - sum ln(sqrt(2pi) sigma)); ln of a non-positive weight is
                 // treated as -inf -> NEG_BIG (the reference's linear-domain sum just adds 0).
                 double c = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
+                double up = 0.0;
                 for (int d = 0; d < pm.dim; d++) {
                     const double sg = g.sigma[(size_t)k * pm.dim + d];
+                    up += std::max(0.0, -std::log(sg));
                     const double mu = g.mean[(size_t)k * pm.dim + d] - (double)pm.center[d];
                     const double sc = std::sqrt(LOG2E * 0.5) / sg;
                     // record layout: dim d -> two float4: {s0,m0,s1,m1} {s2,m2,s3,m3}
@@ -307,9 +310,13 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
                 }
                 c *= LOG2E;
                 *cslot = (std::isfinite(c) && c > (double)NEG_BIG) ? (float)c : NEG_BIG;
+                if (std::isfinite(up)) lift[s] = std::max(lift[s], up);
             }
         }
     });
+    int kmax = 1;
+    for (const GMM *g : models) kmax = std::max(kmax, g->nr_mixtures);
+    pm.flush_band = *std::max_element(lift.begin(), lift.end()) + std::log((double)kmax) + 17.5;
     return pm;
 }
 

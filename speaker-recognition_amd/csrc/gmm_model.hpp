@@ -20,7 +20,12 @@ struct GMM {
     std::vector<double> weights;  // [K]
     std::vector<double> mean;     // [K*D]
     std::vector<double> sigma;    // [K*D]
-    std::shared_ptr<SRModelSet> single;  // lazily packed one-model set (invalidated by training)
+    // lazily packed one-model sets, one per device (threads on different GPUs may score the same handle concurrently:
+    // each holds its device's lock only); invalidated by training
+    std::shared_ptr<SRModelSet> single[sr::MAX_DEVICES];
+    void drop_single() {
+        for (auto &s : single) s.reset();
+    }
     bool trained() const { return dim > 0 && (int)weights.size() == nr_mixtures; }
 };
 
@@ -63,6 +68,9 @@ struct PackedModels {
                                     // so that a feature space far from the origin costs no digits in x*s + m
     std::vector<ChunkDesc> chunks;  // all models, in model order
     std::vector<int> model_chunk_begin;  // [S+1]
+    // Width (nats) of the band above ln DBL_MIN in which the reference's flushes of PARTIAL products can change a
+    // frame's log-likelihood (lse.hpp): max_k sum_d max(0, -ln sigma_kd) + ln K + 17.5 over the set's models.
+    double flush_band = 0.0;
 };
 PackedModels pack_models(const std::vector<const GMM *> &models);
 
@@ -203,6 +211,7 @@ struct SRModelSet {
     // the two per-frame log-likelihoods are merged by a log-add-exp.  Empty unless the set needed it.
     std::vector<int> gcb_host;       // model-group table of the last scoring call (chunk / block index per group) ...
     sr::DevBuf<int> d_gcb;           // ... and its device copy
+    sr::DevBuf<int> d_flush_models;  // per model {first record, records} of the vector layout (gmm_flush.hip; built on first use)
     std::unique_ptr<SRModelSet> hy_good, hy_bad;
     int hy_bad_mixtures = 0;         // mixtures of the set's largest model that went to the vector engine
     int device = -1;

@@ -36,6 +36,7 @@ struct ScoreArgs {
     int dim;
     int n_models;
     int clamp;
+    float band_hi;             // below it a frame goes to the partial-product path (lse.hpp); -inf: never
 };
 
 
@@ -76,7 +77,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                       const ChunkDesc *__restrict__ chunks,
                       const int *__restrict__ group_chunk_begin, double *__restrict__ partial,
                       float *__restrict__ frame_ll, int64_t n_frames, int dim, int n_models,
-                      int clamp, int n_groups, int n_tiles) {
+                      int clamp, int n_groups, int n_tiles, float band_hi) {
     using L = Lanes<PK>;
     using XT = typename L::T;
     constexpr int W = L::W;
@@ -206,6 +207,7 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
         if (cd.model_done >= 0) {   // wave-uniform: close the model, start the next one
             const int s = cd.model_done;
             double mine = 0.0;
+            bool hot = false;              // a frame in the band of the reference's partial-product flushes (lse.hpp)
 #pragma unroll
             for (int f = 0; f < F; f++) {
                 // the reference's underflow behaviour (safe_log -> ln 1e-15, gmm.cc:34-38, :237-244): lse.hpp
@@ -213,11 +215,13 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
                 if (valid[f]) {
                     mine += (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[f]] = ll;
+                    hot |= ll < band_hi;
                 }
                 m[f] = NEG_BIG;
                 ssum[f] = 0.0f;
             }
             mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
+            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
         dma_publish_barrier();
@@ -231,9 +235,11 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
 
 // Per utterance: add the tile/wave partials in a fixed order (deterministic), then the
 // reference's argmax -- first maximum wins (gmmset.py:62-64, `max(enumerate(scores), key=...)`).
+// A (tile, model) whose partial is SR_FLUSH_POISON holds a frame in the band where the reference's flushes of partial
+// products decide (lse.hpp): it is left out of the sum and noted for gmm_flush.hip, which adds the tile's sum later.
 __global__ __launch_bounds__(256)
 void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n_models,
-                         int per_tile, double *sums, int *argmax) {
+                         int per_tile, double *sums, int *argmax, int2 *flush_list, int *flush_count, int flush_cap) {
     const int u = blockIdx.x;
     const int tb = utt_tile_begin[u], te = utt_tile_begin[u + 1];
     double best = -INFINITY;
@@ -243,7 +249,18 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
         for (int t = tb; t < te; t++) {
             // per_tile = 4: one double per wave of the tile's workgroup; 1: already combined
             const double *p = partial + ((int64_t)t * n_models + s) * per_tile;
-            for (int i = 0; i < per_tile; i++) acc += p[i];
+            double tile_sum = 0.0;
+            bool poisoned = false;
+            for (int i = 0; i < per_tile; i++) {
+                poisoned |= flush_poisoned(p[i]);
+                tile_sum += p[i];
+            }
+            if (__builtin_expect(poisoned && flush_count != nullptr, 0)) {
+                const int idx = atomicAdd(flush_count, 1);
+                if (idx < flush_cap) flush_list[idx] = make_int2(t, s);
+                continue;
+            }
+            acc += tile_sum;
         }
         sums[(int64_t)u * n_models + s] = acc;
         if (acc > best) {
@@ -276,7 +293,8 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
 // sum of the surviving terms.
 __global__ __launch_bounds__(256)
 void gmm_merge_kernel(const float *__restrict__ A, const float *__restrict__ B, const TileDesc *__restrict__ tiles,
-                      int n_models, int64_t n_frames, int clamp, double *__restrict__ partial, float *__restrict__ out) {
+                      int n_models, int64_t n_frames, int clamp, double *__restrict__ partial, float *__restrict__ out,
+                      float band_hi) {
     __shared__ double part[4];
     const TileDesc tile = tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,6 +302,7 @@ void gmm_merge_kernel(const float *__restrict__ A, const float *__restrict__ B, 
     const int64_t row = tile.start + (valid ? tid : 0);
     for (int s = 0; s < n_models; s++) {
         double mine = 0.0;
+        bool hot = false;                             // a frame in the band of the reference's partial-product flushes (lse.hpp)
         if (valid) {
             const float a = A[(int64_t)s * n_frames + row], b = B[(int64_t)s * n_frames + row];
             float ll;
@@ -296,8 +315,10 @@ void gmm_merge_kernel(const float *__restrict__ A, const float *__restrict__ B, 
             }
             if (out) out[(int64_t)s * n_frames + row] = ll;
             mine = (double)ll;
+            hot = ll < band_hi;
         }
         mine = wave_sum_f64(mine);
+        if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;     // (inf + anything finite stays inf below)
         __syncthreads();                              // the previous model's reader is done with part[]
         if (lane == 0) part[wave] = mine;
         __syncthreads();
@@ -328,15 +349,43 @@ struct ScoreWorkspace {
     DevBuf<double> ref_partial;
     DevBuf<int> exc_list, exc_count;     // ... and its (tile, block) exception list
     DevBuf<float> hy_a, hy_b;            // hybrid sets: per-frame LL of the two sub-sets
+    DevBuf<int2> flush_list;             // (tile, model) pairs in the partial-product band (lse.hpp, gmm_flush.hip)
+    DevBuf<int> flush_count;
+    size_t flush_min_cap = 0;            // set after an overflow: the next pass gets a list of that length
 };
 static ScoreWorkspace &ws() { return per_device<ScoreWorkspace>(); }   // one per device, leaked on purpose
+
+// What a scoring pass needs for the partial-product band (lse.hpp): the threshold its engine compares per-frame values
+// with, and the list gmm_finalize_kernel notes poisoned (tile, model) pairs in.  Nothing when the reference's clamp is off.
+struct FlushPass {
+    float band_hi = -INFINITY;
+    int2 *list = nullptr;
+    int *count = nullptr;
+    int cap = 0;
+};
+static FlushPass prepare_flush(const SRModelSet &set, int n_tiles, int flags) {
+    FlushPass fp;
+    if (!(flags & 1) || (flags & SCORE_NO_FLUSH)) return fp;
+    auto &w = ws();
+    const size_t pairs = (size_t)std::max(1, n_tiles) * (size_t)set.host.n_models;
+    size_t cap = std::min<size_t>(pairs, (size_t)1 << 20);
+    cap = std::min<size_t>(std::max(cap, w.flush_min_cap), 0x7fffffff);
+    w.flush_list.ensure(cap);
+    w.flush_count.ensure(1);
+    SR_HIP(hipMemsetAsync(w.flush_count.p, 0, sizeof(int), ctx().stream));
+    fp.list = w.flush_list.p;
+    fp.count = w.flush_count.p;
+    fp.cap = (int)std::min<size_t>(w.flush_list.n, 0x7fffffff);
+    fp.band_hi = (float)(-708.396418532264 + set.host.flush_band);
+    return fp;
+}
 
 template <int DP, int F, bool PK>
 static void launch_score(const ScoreArgs &a, int n_tiles, int n_groups) {
     dim3 grid((unsigned)((int64_t)n_groups * ((n_tiles + 7) / 8) * 8));   // 1-D, XCD-aware order
     hipLaunchKernelGGL((gmm_score_kernel<DP, F, PK>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        a.params, a.center, a.chunks, a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames,
-                       a.dim, a.n_models, a.clamp, n_groups, n_tiles);
+                       a.dim, a.n_models, a.clamp, n_groups, n_tiles, a.band_hi);
 }
 
 template <int DP>
@@ -690,6 +739,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 
     auto &w = ws();
     bool used_oor = false;
+    const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
     if (frame_ll_dst) want_frame_ll = true;
     w.sums.ensure((size_t)std::max(1, U) * S);
     w.argmax.ensure((size_t)std::max(1, U));
@@ -796,6 +846,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.force_exc = opt.h2s_force_exc;
             a.tiles_per_launch = opt.h2s_tiles_per_launch;
             a.shape = h2s_shape;
+            a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_h2s_kernel<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
                      "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf,
@@ -822,6 +873,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.clamp = (flags & 1) ? 1 : 0;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
+            a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "gmm_score_bx3_shared_kernel<%d,%d> (shared sigma: quadratic half once per %d models; split-bf16 MFMA)",
                      set.shared.kq, set.shared.kl, SHARED_SB);
@@ -853,6 +905,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.clamp = (flags & 1) ? 1 : 0;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
+            a.band_hi = fp.band_hi;
             ScopedKernelTimer t(T_SCORE);
             if (use_h2) {
                 snprintf(g_last_kernel, sizeof(LastKernel::name),
@@ -880,6 +933,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.dim = feat.dim;
             a.n_models = S;
             a.clamp = (flags & 1) ? 1 : 0;
+            a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
                      (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");
             ScopedKernelTimer t(T_SCORE);
@@ -891,7 +945,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums.p, w.argmax.p);
+                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums.p, w.argmax.p,
+                           fp.list, fp.count, fp.cap);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;
@@ -899,6 +954,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     r.d_argmax = w.argmax.p;
     r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? (frame_ll_dst ? frame_ll_dst : w.frame_ll.p) : nullptr;
     r.d_oor = used_oor ? w.oor.p : nullptr;
+    r.d_flush_count = fp.count;
+    r.d_flush_list = fp.list;
+    r.flush_cap = fp.cap;
+    r.tiles = &tt;
     return r;
 }
 
@@ -912,11 +971,13 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
     w.hy_b.ensure(n);
     // the ill-conditioned mixtures first (vector engine: the only layout that sub-set carries), then the rest -- so
     // that the fp16 engines' saturation flag of the second call is the one left in the workspace
-    score_device(*set.hy_bad, feat, true, flags, w.hy_b.p);
-    const ScoreResult good = score_device(*set.hy_good, feat, true, flags, w.hy_a.p);
+    // (the partial-product band is the merge's business: the merged value, against the WHOLE model's parameters)
+    score_device(*set.hy_bad, feat, true, flags | SCORE_NO_FLUSH, w.hy_b.p);
+    const ScoreResult good = score_device(*set.hy_good, feat, true, flags | SCORE_NO_FLUSH, w.hy_a.p);
     char good_name[sizeof(LastKernel::name)];
     snprintf(good_name, sizeof(good_name), "%s", g_last_kernel);
     TileTable &tt = feat.tiles_for(256);
+    const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
     w.sums.ensure((size_t)std::max(1, U) * S);
     w.argmax.ensure((size_t)std::max(1, U));
     float *out = nullptr;
@@ -928,13 +989,13 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
         w.partial.ensure((size_t)tt.n_tiles * S);
         ScopedKernelTimer t(T_SCORE);
         hipLaunchKernelGGL(gmm_merge_kernel, dim3((unsigned)tt.n_tiles), dim3(256), 0, ctx().stream, w.hy_a.p, w.hy_b.p,
-                           tt.d_tiles.p, S, feat.n_rows, (flags & 1) ? 1 : 0, w.partial.p, out);
+                           tt.d_tiles.p, S, feat.n_rows, (flags & 1) ? 1 : 0, w.partial.p, out, fp.band_hi);
         SR_HIP(hipGetLastError());
     }
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream, w.partial.p,
-                           tt.d_utt_tile_begin.p, S, 1, w.sums.p, w.argmax.p);
+                           tt.d_utt_tile_begin.p, S, 1, w.sums.p, w.argmax.p, fp.list, fp.count, fp.cap);
         SR_HIP(hipGetLastError());
     }
     snprintf(g_last_kernel, sizeof(LastKernel::name), "hybrid: %d ill-conditioned mixtures on the vector ALU + %.150s", set.hy_bad_mixtures, good_name);
@@ -943,6 +1004,10 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
     r.d_argmax = w.argmax.p;
     r.d_frame_ll = (out && tt.n_tiles > 0) ? out : nullptr;
     r.d_oor = good.d_oor;
+    r.d_flush_count = fp.count;
+    r.d_flush_list = fp.list;
+    r.flush_cap = fp.cap;
+    r.tiles = &tt;
     return r;
 }
 
@@ -954,34 +1019,56 @@ struct ResultStaging {
 };
 static ResultStaging &staging() { return per_device<ResultStaging>(); }   // leaked on purpose (no hipHostFree at exit)
 
-// Copies the last scoring call's results to host memory through pinned staging.
-bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
-                   int *argmax_out, float *frame_ll_out) {
+// Copies the last scoring call's results to host memory through pinned staging.  With the reference's clamp on, the
+// (tile, model) pairs gmm_finalize_kernel left out because a frame of theirs sits in the partial-product band (lse.hpp)
+// are resolved first (gmm_flush.hip patches the device results; nothing to do, and nothing extra copied but one int,
+// when there are none -- the case of real data).
+bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult &r_in, double *sums_out, int *argmax_out,
+                   float *frame_ll_out) {
     auto &st = staging();
-    if (r.d_oor) {
-        st.oor.ensure(1);
-        SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-    }
+    ScoreResult r = r_in;
+    const size_t U = (size_t)feat.n_utt, S = (size_t)set.host.n_models, n_frames = (size_t)feat.n_rows;
+    st.oor.ensure(2);
     const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
     const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
-    if (sums_out && U) {
-        st.sums.ensure(U * S);
-        SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
-    }
-    if (argmax_out && U) {
-        st.argmax.ensure(U);
-        SR_HIP(hipMemcpyAsync(st.argmax.p, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-    }
-    if (fll_n) {
-        if (stage_fll) {
-            st.frame_ll.ensure(fll_n);
-            SR_HIP(hipMemcpyAsync(st.frame_ll.p, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
-        } else {
-            SR_HIP(hipMemcpyAsync(frame_ll_out, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+    for (;;) {
+        st.oor.p[0] = st.oor.p[1] = 0;
+        if (r.d_oor) SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        if (r.d_flush_count) SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        if (sums_out && U) {
+            st.sums.ensure(U * S);
+            SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
         }
+        if (argmax_out && U) {
+            st.argmax.ensure(U);
+            SR_HIP(hipMemcpyAsync(st.argmax.p, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        }
+        if (fll_n) {
+            if (stage_fll) {
+                st.frame_ll.ensure(fll_n);
+                SR_HIP(hipMemcpyAsync(st.frame_ll.p, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+            } else {
+                SR_HIP(hipMemcpyAsync(frame_ll_out, r.d_frame_ll, fll_n * sizeof(float), hipMemcpyDeviceToHost, ctx().stream));
+            }
+        }
+        sync_stream();
+        if (r.d_oor && st.oor.p[0] != 0) return false;
+        int n_flush = st.oor.p[1];
+        if (n_flush == 0) break;
+        if (n_flush > r.flush_cap) {
+            // more pairs than the list holds (the counter kept counting): the pass again with a list of that length
+            ws().flush_min_cap = (size_t)n_flush;
+            const bool own = r.d_frame_ll && r.d_frame_ll != ws().frame_ll.p;
+            r = score_device(set, feat, r.d_frame_ll != nullptr, flags, own ? const_cast<float *>(r.d_frame_ll) : nullptr);
+            SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            sync_stream();
+            n_flush = st.oor.p[1];
+            if (n_flush > r.flush_cap) fail("partial-product band: %d (tile, model) pairs noted, list of %d", n_flush, r.flush_cap);
+        }
+        flush_resolve(set, feat, *r.tiles, r.d_flush_list, n_flush, const_cast<double *>(r.d_sums),
+                      const_cast<int *>(r.d_argmax), const_cast<float *>(r.d_frame_ll));
+        r.d_flush_count = nullptr;          // resolved: copy the patched results out
     }
-    sync_stream();
-    if (r.d_oor && st.oor.p[0] != 0) return false;
     if (sums_out && U) std::memcpy(sums_out, st.sums.p, U * S * sizeof(double));
     if (argmax_out && U) std::memcpy(argmax_out, st.argmax.p, U * sizeof(int));
     if (stage_fll) std::memcpy(frame_ll_out, st.frame_ll.p, fll_n * sizeof(float));
@@ -991,13 +1078,10 @@ bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, do
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags) {
     const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags);
-    if (fetch_results(r, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
-                      frame_ll_out))
-        return;
+    if (fetch_results(set, feat, flags, r, sums_out, argmax_out, frame_ll_out)) return;
     // a frame left the fp16 engine's range: the whole batch again on the fp32-grade engines
     const ScoreResult r2 = score_device(set, feat, frame_ll_out != nullptr, flags | SCORE_PRECISE);
-    fetch_results(r2, (size_t)feat.n_utt, (size_t)set.host.n_models, (size_t)feat.n_rows, sums_out, argmax_out,
-                  frame_ll_out);
+    fetch_results(set, feat, flags | SCORE_PRECISE, r2, sums_out, argmax_out, frame_ll_out);
 }
 
 }  // namespace sr
@@ -1021,6 +1105,7 @@ sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {
     }
     begin[n_utt] = (int)tiles.size();
     tt->n_tiles = (int)tiles.size();
+    tt->h_tiles = tiles;
     tt->d_tiles.upload(tiles.data(), tiles.size());
     tt->d_utt_tile_begin.upload(begin.data(), begin.size());
     sr::sync_stream();

@@ -86,7 +86,7 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
                                  const int *__restrict__ group_block_begin, const float *__restrict__ center,
                                  double *__restrict__ partial, float *__restrict__ frame_ll,
                                  int64_t n_frames, int dim, int n_models, int n_mix_tiles, int clamp,
-                                 int n_groups, int n_tiles) {
+                                 int n_groups, int n_tiles, float band_hi) {
     constexpr int SB = SHARED_SB;
     constexpr int Q_U4 = KQ * 3 * 64, L_U4 = KL * 3 * 64;
     constexpr int BUF_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;
@@ -211,7 +211,10 @@ void gmm_score_bx3_shared_kernel(const float *__restrict__ X, const TileDesc *__
                 mine = (double)ll;
                 if (frame_ll) frame_ll[(int64_t)(sb.first_model + si) * n_frames + row] = ll;
             }
+            // a frame in the band of the reference's partial-product flushes (lse.hpp) poisons the tile's partial
+            const bool hot = valid && hh == 0 && si < sb.n_models && ll < band_hi;
             mine = wave_sum_f64(mine);
+            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0) close_slot[si][wave] = mine;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -229,7 +232,7 @@ static void launch_shared(const SharedLaunch &a) {
     hipLaunchKernelGGL((gmm_score_bx3_shared_kernel<KQ, KL>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        reinterpret_cast<const uint4 *>(a.params), a.blocks, a.group_block_begin, a.center,
                        a.partial, a.frame_ll, a.n_frames, a.dim, a.n_models, a.n_mix_tiles, a.clamp,
-                       a.n_groups, a.n_tiles);
+                       a.n_groups, a.n_tiles, a.band_hi);
 }
 
 void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL) {

@@ -114,6 +114,7 @@ struct H2sArgs {
     int tile_base;                // first frame tile of this launch (long grids are cut into several launches)
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
+    float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
 
 // Workgroup shapes: waves per workgroup x 32-frame column tiles per wave x images per LDS stage.
@@ -212,7 +213,8 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     }
     if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);           // saturated: the host re-scores on the fp32-grade engines
     // the largest term is >= LL - log2 K; below this the online pass decides
-    const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
+    // (and everything below the band in which the reference's partial-product flushes can decide, lse.hpp)
+    const float safe_ll2 = a.clamp ? fmaxf(LSE_MINLOG2 + LSE_NEAR + a.log2_k, a.band_hi * H2S_LOG2E + 1.0f) : -3.0e38f;
 
     const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 zero16[COLS];
@@ -436,7 +438,9 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
                 mine = (double)ll;
                 if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll;
             }
+            const bool hot = valid && hh == 0 && si < sb.n_models && ll < a.band_hi;
             mine = wave_sum_f64(mine);
+            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0 && si < sb.n_models)
                 a.partial[(int64_t)e.x * a.n_models + sb.first_model + si] = mine;
             __builtin_amdgcn_sched_barrier(0);
@@ -472,6 +476,7 @@ static int launch_h2s(const H2sLaunch &l) {
     a.n_tiles = l.n_tiles;
     a.log2_k = l.log2_k;
     a.force_exc = l.force_exc;
+    a.band_hi = l.band_hi;
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
     constexpr int TILES_WG = WAVES * COLS;
     const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES));

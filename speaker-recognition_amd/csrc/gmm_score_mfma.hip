@@ -40,7 +40,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
                            const int *__restrict__ group_chunk_begin,
                            const float *__restrict__ center, double *__restrict__ partial,
                            float *__restrict__ frame_ll, int64_t n_frames, int dim, int n_models,
-                           int clamp, int n_groups, int n_tiles) {
+                           int clamp, int n_groups, int n_tiles, float band_hi) {
     constexpr int KKP = (DP + 1 + 3) & ~3;     // contraction steps (2 k-indices each), padded to 4
     constexpr int KQ = KKP / 4;
     constexpr int TILE_F4 = KQ * 64;           // float4 per 32-mixture tile
@@ -165,6 +165,7 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
         if (cd.model_done >= 0) {
             const int s = cd.model_done;
             double mine = 0.0;
+            bool hot = false;              // a frame in the band of the reference's partial-product flushes (lse.hpp)
 #pragma unroll
             for (int ft = 0; ft < FT; ft++) {
                 // merge the two half-waves (the other 16 mixture rows of the same frame)
@@ -172,11 +173,13 @@ void gmm_score_mfma_kernel(const float *__restrict__ X, const TileDesc *__restri
                 if (valid[ft] && hh == 0) {
                     mine += (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;
+                    hot |= ll < band_hi;
                 }
                 m[ft] = NEG_BIG;
                 ssum[ft] = 0.0f;
             }
             mine = wave_sum_f64(mine);     // DPP + readlane: no LDS round trips in the per-model close
+            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
         }
         dma_publish_barrier();
@@ -193,7 +196,7 @@ static void launch_mfma(const MfmaLaunch &a) {
     dim3 grid((unsigned)((int64_t)a.n_groups * ((a.n_tiles + 7) / 8) * 8));
     hipLaunchKernelGGL((gmm_score_mfma_kernel<DP, FT>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        a.params, a.chunks, a.group_chunk_begin, a.center, a.partial, a.frame_ll,
-                       a.n_frames, a.dim, a.n_models, a.clamp, a.n_groups, a.n_tiles);
+                       a.n_frames, a.dim, a.n_models, a.clamp, a.n_groups, a.n_tiles, a.band_hi);
 }
 
 template <int DP>

@@ -90,7 +90,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
                             const float *__restrict__ center, const float *__restrict__ scale,
                             double *__restrict__ partial, float *__restrict__ frame_ll,
                             int *__restrict__ oor_flag, int64_t n_frames, int dim, int n_models,
-                            int clamp, int n_groups, int n_tiles) {
+                            int clamp, int n_groups, int n_tiles, float band_hi) {
     constexpr int P = SC::PARTS;
     constexpr int TILE_U4 = KS * P * 64;       // 16-byte fragments-per-lane of one 32-mixture tile
     constexpr int PF = (TILE_U4 + 255) / 256;
@@ -246,6 +246,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         if (model_done >= 0) {
             const int s = model_done;
             double mine = 0.0;
+            bool hot = false;              // a frame in the band of the reference's partial-product flushes (lse.hpp)
 #pragma unroll
             for (int ft = 0; ft < FT; ft++) {
                 // merge the two half-waves (the other 16 mixture rows of the same frame); the
@@ -254,11 +255,13 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
                 if (valid[ft] && hh == 0) {
                     mine += (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;
+                    hot |= ll < band_hi;
                 }
                 m[ft] = NEG_BIG;
                 ssum[ft] = 0.0f;
             }
             mine = wave_sum_f64(mine);
+            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0) close_slot[gen][wave] = mine;
             pending_model = s;
             pending_gen = gen;
@@ -280,7 +283,7 @@ static void launch_split(const MfmaLaunch &a) {
     hipLaunchKernelGGL((gmm_score_split_kernel<SC, KS, FT>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        reinterpret_cast<const uint4 *>(a.params), a.chunks, a.group_chunk_begin, a.center,
                        a.scale, a.partial, a.frame_ll, a.oor_flag, a.n_frames, a.dim, a.n_models, a.clamp,
-                       a.n_groups, a.n_tiles);
+                       a.n_groups, a.n_tiles, a.band_hi);
 }
 
 template <typename SC, int KS>

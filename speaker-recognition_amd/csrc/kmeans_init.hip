@@ -433,7 +433,7 @@ void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Para
         }
     }
     g.weights.assign(K, 1.0 / K);                             // gmm.cc:356-360
-    g.single.reset();
+    g.drop_single();
 }
 
 }  // namespace sr

@@ -12,9 +12,22 @@
 // kernels do it only while some lane's running maximum is within NEAR log2 units above the
 // boundary (a wave-uniform branch never taken on real data: it needs a frame ~37 sigma from every
 // mixture); a term more than NEAR below the running maximum is < 2^-40 of the sum either way.
-// What no log-domain form reproduces, and is documented as such: the reference's
-// flush of PARTIAL products in dimension order (sigma < 0.399 makes a factor > 1) and its
-// per-dimension exponent floor (fastexp.cc:104-131).
+//
+// PARTIAL products (round 3).  A mixture's density is a product of D per-dimension factors
+// (gmm.cc:192-195) and every intermediate of it flushes too: a partial product below DBL_MIN is 0 for
+// good even when later factors > 1 (sigma < 0.399) would have lifted the full product back, and a single
+// dimension whose exponent reaches fastexp.cc's floor (-708.396, :104-105,128-131) zeroes its mixture.
+// Those decisions depend on the ORDER of the factors; they are taken by a separate, rare path
+// (gmm_flush.hip: the reference's linear-domain arithmetic restated in float64, explicit flushes) on
+// exactly the frames that can be affected: a killed term has a full product below exp(-708.396 + R),
+// R = sum_d max(0, -ln sigma_d), so a (frame, model) pair whose log-likelihood is at least
+// `band_hi` = -708.396 + max R + ln K + 17.5 cannot change by more than 3e-8.  At its per-model close
+// every engine compares the frame's value with band_hi (one v_cmp per frame and model; the clamped value
+// ln 1e-15 = -34.5 is above any band_hi, and below the boundary the full-product rule and the reference
+// agree: everything is 0) and, when a frame of its tile is below, writes FLUSH_POISON instead of the
+// tile's partial sum for that model: no list, no atomics, no registers in the hot kernels.
+// gmm_finalize_kernel, which reads every partial anyway, leaves such a (tile, model) out of the
+// utterance's sum and notes it; gmm_flush.hip re-evaluates the tile's frames for that model.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,6 +39,10 @@ constexpr float LSE_MINLOG2 = -708.396418532264f * 1.4426950408889634f;   // log
 constexpr float LSE_LN_1E_15 = -34.538776394910684f;                      // safe_log floor, gmm.cc:34-38
 constexpr float LSE_NEAR = 40.0f;
 constexpr float LSE_NEG_BIG = -1.0e30f;
+// written in place of a (tile, model) partial sum when a frame of the tile sits in the band where the reference's
+// flushes of partial products can decide (never a legitimate sum: log-likelihoods are finite or -inf)
+#define SR_FLUSH_POISON (__builtin_inf())
+__device__ __forceinline__ bool flush_poisoned(double v) { return v == SR_FLUSH_POISON; }
 
 typedef float lse_f32x16 __attribute__((ext_vector_type(16)));
 

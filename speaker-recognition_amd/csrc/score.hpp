@@ -39,6 +39,8 @@ constexpr double F16_MAX_SIGMA_RATIO = 256.0;
 constexpr double F16_MAX_COEF = 30000.0;
 // internal scoring flag (beside SR_CLAMP_COMPAT): keep to the fp32-grade engines (EM, serving stream)
 constexpr int SCORE_PRECISE = 0x200;
+// internal: leave the partial-product band alone (the two halves of a hybrid set: their merge looks at the merged value)
+constexpr int SCORE_NO_FLUSH = 0x400;
 
 struct MfmaLaunch {
     const float *X;
@@ -53,6 +55,7 @@ struct MfmaLaunch {
     int *oor_flag = nullptr;        // fp16 scheme: set when a frame saturated (|scaled x'| >= 255)
     int64_t n_frames;
     int dim, n_models, clamp, n_groups, n_tiles;
+    float band_hi = -__builtin_inff();   // below it a frame goes to the partial-product path (lse.hpp); -inf: never
 };
 void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
 struct SharedLaunch {
@@ -66,6 +69,7 @@ struct SharedLaunch {
     float *frame_ll;
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
+    float band_hi = -__builtin_inff();
 };
 void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL);
 struct H2sLaunch {
@@ -89,6 +93,7 @@ struct H2sLaunch {
     int force_exc;
     int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
     int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles)
+    float band_hi = -__builtin_inff();
 };
 int launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU
@@ -108,6 +113,13 @@ struct ScoreResult {
     const int *d_argmax = nullptr;     // [U]
     const float *d_frame_ll = nullptr; // [S][n_frames] when requested
     const int *d_oor = nullptr;        // fp16 engines: nonzero when a frame saturated -> results must be redone
+    // reference clamp on: (tile, model) pairs with a frame whose value the reference's flushes of partial products may
+    // change (lse.hpp), left out of `d_sums` by gmm_finalize_kernel -- `*d_flush_count` of them (it counts past
+    // `flush_cap`), to be resolved by flush_resolve before the results are used (fetch_results does)
+    const int *d_flush_count = nullptr;
+    const int2 *d_flush_list = nullptr;
+    int flush_cap = 0;
+    const TileTable *tiles = nullptr;  // the tile table the pass ran on
 };
 
 // Scores every utterance of `feat` against every model of `set`; leaves results on the device.
@@ -119,8 +131,14 @@ void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argm
 // Results of the last scoring call -> host memory, through pinned staging buffers.
 // Returns false when the fp16 engine reported saturated frames (nothing was copied out: score again
 // with SCORE_PRECISE).
-bool fetch_results(const ScoreResult &r, size_t U, size_t S, size_t n_frames, double *sums_out,
+bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult &r, double *sums_out,
                    int *argmax_out, float *frame_ll_out);
+// gmm_flush.hip: the frames of the noted (tile, model) pairs again with the reference's own linear-domain arithmetic;
+// adds the tiles' sums to `d_sums`, redoes the argmax of the utterances touched, overwrites the per-frame values
+void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *d_sums,
+                   int *d_argmax, float *d_frame_ll);
+int &flush_order_option();     // 2 = partial products as the reference DSO's compiler forms them (default), 1 = source order
+void flush_stats(long *calls, long *pairs, long *frames);
 // PCM batch -> MFCC -> CMVN/deltas -> all models -> sums + argmax on the host (abi.cpp; pipelined over
 // chunks of utterances for large batches).
 }  // namespace sr

@@ -65,8 +65,10 @@ void stream_destroy(SRStream *s) {
 void enqueue_tick(SRStream *s, SRStream::Slot &sl) {
     mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);
     const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags & 0xff);
-    sl.h_oor[0] = 0;
+    sl.h_oor[0] = sl.h_oor[1] = 0;
     if (r.d_oor) SR_HIP(hipMemcpyAsync(sl.h_oor, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+    // (tile, model) pairs in the band where the reference's partial-product flushes decide (lse.hpp): resolved at collect
+    if (r.d_flush_count) SR_HIP(hipMemcpyAsync(sl.h_oor + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
     SR_HIP(hipMemcpyAsync(sl.h_sums, r.d_sums, (size_t)s->n_windows * s->n_models * sizeof(double),
                           hipMemcpyDeviceToHost, ctx().stream));
     SR_HIP(hipMemcpyAsync(sl.h_argmax, r.d_argmax, (size_t)s->n_windows * sizeof(int),
@@ -133,8 +135,8 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_pcm), n_samp * sizeof(int16_t), hipHostMallocDefault));
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_sums), (size_t)n_windows * s->n_models * sizeof(double), hipHostMallocDefault));
             SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_argmax), (size_t)n_windows * sizeof(int), hipHostMallocDefault));
-            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_oor), sizeof(int), hipHostMallocDefault));
-            sl.h_oor[0] = 0;
+            SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_oor), 2 * sizeof(int), hipHostMallocDefault));
+            sl.h_oor[0] = sl.h_oor[1] = 0;
             SR_HIP(hipEventCreate(&sl.h2d_done));
             SR_HIP(hipEventCreate(&sl.done));
             SR_HIP(hipEventCreate(&sl.t_submit));
@@ -223,12 +225,17 @@ int sr_stream_collect(SRStream *s, double *sums_out, int *argmax_out, double *de
         s->in_flight.pop_front();
         auto &sl = s->slot[k];
         SR_HIP(hipEventSynchronize(sl.done));
-        if (sl.h_oor[0] != 0) {
-            // a frame of this tick left the fp16 engine's range: its features are still in the slot --
-            // score them again, synchronously, on the fp32-grade engines
-            const ScoreResult r = score_device(*s->set, sl.feat, false, (s->flags & 0xff) | SCORE_PRECISE);
-            fetch_results(r, (size_t)s->n_windows, (size_t)s->n_models, (size_t)sl.feat.n_rows, sl.h_sums, sl.h_argmax, nullptr);
-            sl.h_oor[0] = 0;
+        if (sl.h_oor[0] != 0 || sl.h_oor[1] != 0) {
+            // a frame of this tick left the fp16 engine's range (-> the fp32-grade engines), or sits in the band where the
+            // reference's partial-product flushes decide (-> resolved by fetch_results): its features are still in the
+            // slot -- score them again, synchronously
+            const int fl = (s->flags & 0xff) | (sl.h_oor[0] != 0 ? SCORE_PRECISE : 0);
+            ScoreResult r = score_device(*s->set, sl.feat, false, fl);
+            if (!fetch_results(*s->set, sl.feat, fl, r, sl.h_sums, sl.h_argmax, nullptr)) {
+                r = score_device(*s->set, sl.feat, false, fl | SCORE_PRECISE);
+                fetch_results(*s->set, sl.feat, fl | SCORE_PRECISE, r, sl.h_sums, sl.h_argmax, nullptr);
+            }
+            sl.h_oor[0] = sl.h_oor[1] = 0;
         }
         if (sums_out) std::memcpy(sums_out, sl.h_sums, (size_t)s->n_windows * s->n_models * sizeof(double));
         if (argmax_out) std::memcpy(argmax_out, sl.h_argmax, (size_t)s->n_windows * sizeof(int));

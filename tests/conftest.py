@@ -25,6 +25,21 @@ def clamp_golden():
 
 
 @pytest.fixture(scope="session")
+def flush_golden():
+    """Reference-DSO answers where its flush-to-zero arithmetic decides on PARTIAL products
+    (tests/golden/make_flush_golden.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "flush_golden.npz"))
+
+
+def flush_models(g, c):
+    """the case's model(s) as (weights, mean, sigma): the UBM first, then the speakers that share its sigma / weights"""
+    out = [(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"])]
+    if c + "_spk_mean" in g.files:
+        out += [(g[c + "_w"], m, g[c + "_sigma"]) for m in g[c + "_spk_mean"]]
+    return out
+
+
+@pytest.fixture(scope="session")
 def mfcc_golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "mfcc_golden.npz"))
 

@@ -27,6 +27,7 @@ def _reset_options(built_lib):
     for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic",
               "score_h2s_force_exc", "score_h2s_shape"):
         _lib.set_option(k, 0)
+    _lib.set_option("flush_order", 2)
 
 
 def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
@@ -515,6 +516,91 @@ def test_clamp_band_matches_reference_all_engines(built_lib, clamp_golden):
             assert np.array_equal(ll == floor32, clamped), (c, eng, _lib.last_score_kernel())
             assert ll_close(ll[~clamped], ref[~clamped]) < TOL, (c, eng)
             assert abs(m.score_all(X) - float(np.sum(ref))) < TOL * abs(float(np.sum(ref)))
+
+
+def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_built, flush_golden):
+    """SURVEY 8a-12, closed in round 3: the reference's FTZ arithmetic zeroes a mixture when ANY intermediate of its
+    density product dips below DBL_MIN (gmm.cc:192-195) or one dimension reaches fastexp.cc's exponent floor
+    (:104-131), also when the full product is representable -- frames ~37 sigma out whose offset sits in a few
+    dimensions while sigma < 0.399 elsewhere.  Goldens from the reference DSO (tests/golden/make_flush_golden.py; the
+    full-product rule of round 2 is wrong on a sixth of them, by up to ~650 nats).  Every engine returns the reference's
+    value: exactly ln(1e-15) where the reference clamps, the survivors' log-sum elsewhere; per frame, per utterance sum,
+    argmax; also through the legacy one-model path, the shared-sigma engines' exception pass and a hybrid set."""
+    from conftest import flush_models
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go, g = oracle_built, flush_golden
+    floor32 = np.float32(np.log(1e-15))
+    conditioned = {"d39_flat32", "d20_k64", "d39_flat256", "d39_k32c", "d39_ubm64"}     # fit the matrix-core engines' range
+    calls0, pairs0, frames0 = _lib.flush_stats()
+    n_wrong_before = 0
+    for c in g["cases"]:
+        X, ref = g[c + "_X"], g[c + "_ll"]
+        models = flush_models(g, c)
+        clamped = ref == np.log(1e-15)
+        n_wrong_before += int(np.sum(np.abs(g[c + "_full_rule_ll"] - ref) > 1e-3))
+        # ---- the legacy one-model path (score / score_all of every engine that fits the model)
+        m = GMM.from_arrays(*models[0])
+        for eng in ((1, 2, 3, 5, 0) if c in conditioned else (1, 0)):
+            _lib.set_option("score_engine", eng)
+            ll = m.score(X)
+            assert np.array_equal(ll == floor32, clamped[0]), (c, eng, _lib.last_score_kernel())
+            assert ll_close(ll[~clamped[0]], ref[0][~clamped[0]]) < TOL, (c, eng)
+            assert abs(m.score_all(X) - float(np.sum(ref[0]))) < TOL * abs(float(np.sum(ref[0]))), (c, eng)
+        # ---- a set, ragged utterances (tile boundaries inside and between them), sums + argmax with and without per-frame output
+        cuts = [0, 1, 34, 35, 99, len(X)]
+        utts = [X[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        ms = ModelSet([GMM.from_arrays(*mm) for mm in models])
+        want_sums = np.array([[ref[s][a:b].sum() for s in range(len(models))] for a, b in zip(cuts[:-1], cuts[1:])])
+        engines = [(1, 0, 0), (0, 0, 0)]
+        if c in conditioned:
+            engines += [(3, 0, 0), (5, 0, 0)]
+        if len(models) >= 12:
+            engines += [(4, 0, 0), (6, 1, 0), (6, 2, 0), (6, 1, 1)]
+        for eng, shape, force in engines:
+            _lib.set_option("score_engine", eng)
+            _lib.set_option("score_h2s_shape", shape)
+            _lib.set_option("score_h2s_force_exc", force)
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            assert np.array_equal(fll == floor32, clamped), (c, eng, shape, force, _lib.last_score_kernel())
+            assert ll_close(fll[~clamped], ref[~clamped]) < TOL, (c, eng)
+            assert np.max(np.abs(sums - want_sums) / np.maximum(1.0, np.abs(want_sums))) < TOL, (c, eng, shape, force)
+            sums2, arg2 = ms.score(Batch.from_features(utts))
+            assert np.array_equal(sums2, sums) and np.array_equal(arg2, arg), (c, eng)       # same with sums only; deterministic
+            _lib.set_option("score_h2s_force_exc", 0)
+        _lib.set_option("score_engine", 0)
+        _lib.set_option("score_h2s_shape", 0)
+        # ---- the source's order of the partial products instead of the compiler's (a DSO built without reassociation)
+        _lib.set_option("flush_order", 1)
+        ll = m.score(X)
+        _lib.set_option("flush_order", 2)
+        src = g[c + "_src_order_ll"][0]
+        keep = np.abs(src - ref[0]) > 1e-3          # (frames were drawn with a margin on the compiled order's decisions only)
+        cl = src == np.log(1e-15)
+        assert np.array_equal((ll == floor32)[keep], cl[keep]), c
+        assert ll_close(ll[keep & ~cl], src[keep & ~cl]) < TOL, c
+    calls1, pairs1, frames1 = _lib.flush_stats()
+    assert n_wrong_before >= 150 and calls1 > calls0 and pairs1 > pairs0 and frames1 > frames0
+    # ---- a hybrid set (two collapsed mixtures far from the centre go to the vector engine, the rest to the matrix cores;
+    #      the band is judged on the merged value against the whole model): the oracle's mode 0 -- equal to the DSO on
+    #      every golden above -- is the reference here
+    c = "d39_k32c"
+    w, mu, sg = flush_models(g, c)[0]
+    r6 = np.vectorize(lambda v: float("%g" % v))
+    rng = np.random.default_rng(5)
+    mu2 = np.concatenate([mu, r6(40.0 + rng.standard_normal((2, mu.shape[1])))])
+    sg2 = np.concatenate([sg, np.full((2, mu.shape[1]), 0.05)])
+    w2 = r6(np.concatenate([w * 0.98, [0.01, 0.01]]))
+    hy = ModelSet([GMM.from_arrays(w2, mu2, sg2)])
+    X = g[c + "_X"]
+    want = go.score_batch(go.GMMParams(w2, mu2, sg2), X, go.MODE_FASTEXP)
+    sums, arg, fll = hy.score(Batch.from_features([X]), frame_ll=True)
+    assert "hybrid" in _lib.last_score_kernel(), _lib.last_score_kernel()
+    cl = want == np.log(1e-15)
+    assert np.array_equal(fll[0] == floor32, cl)
+    assert ll_close(fll[0][~cl], want[~cl]) < TOL
+    assert abs(sums[0, 0] - want.sum()) < TOL * abs(want.sum())
 
 
 def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):

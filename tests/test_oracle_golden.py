@@ -65,6 +65,40 @@ def test_gmm_oracle_clamp_band_matches_reference(oracle_built, clamp_golden):
     assert in_band >= 40          # the band the sum-rule would have got wrong is populated
 
 
+def test_gmm_oracle_partial_product_flushes_match_reference(oracle_built, flush_golden):
+    """SURVEY 8a-12, the part round 2 left open: the reference's FTZ arithmetic zeroes a mixture as soon as ANY
+    intermediate of its density product dips below DBL_MIN (gmm.cc:192-195) or one dimension's exponent reaches the
+    floor of fastexp.cc:104-131 -- also when the full product would be representable.  Goldens from the reference
+    DSO (tests/golden/make_flush_golden.py).  Mode 0 of the oracle (the as-compiled order of the partial products)
+    equals the DSO; the full-product rule (mode 2, what the engines compute) does not on a sixth of the values; every
+    value on which it differs lies inside the band the engines hand to the exact path (csrc/lse.hpp, gmm_flush.hip)."""
+    from conftest import flush_models
+    go, g = oracle_built, flush_golden
+    T = go.MINLOG
+    n_diff = n_src = n_all = 0
+    for c in g["cases"]:
+        X, ref = g[c + "_X"], g[c + "_ll"]
+        models = [go.GMMParams(*m) for m in flush_models(g, c)]
+        band = max(float(np.max(np.sum(np.maximum(0.0, -np.log(p.sigma)), axis=1))) for p in models) + np.log(models[0].K) + 17.5
+        for i, p in enumerate(models):
+            assert np.max(np.abs(go.score_batch(p, X, go.MODE_FASTEXP) - ref[i])) < 1e-9, c
+            full = go.score_batch(p, X, go.MODE_LOGSUMEXP, clamp_compat=True)
+            assert np.max(np.abs(full - g[c + "_full_rule_ll"][i])) < 1e-6, c
+            differs = np.abs(full - ref[i]) > 1e-3
+            # where the engines' rule is wrong its value sits in [ln DBL_MIN, band_hi): noted, re-evaluated exactly
+            assert np.all(full[differs] >= T) and np.all(full[differs] < T + band - 1.0), c
+            n_diff += int(differs.sum())
+            n_all += differs.size
+            go.set_flush_order(1)
+            try:
+                src = go.score_batch(p, X, go.MODE_FASTEXP)
+            finally:
+                go.set_flush_order(2)
+            assert np.max(np.abs(src - g[c + "_src_order_ll"][i])) < 3e-4, c      # (numpy rule vs remez5 arithmetic)
+            n_src += int(np.sum(np.abs(src - ref[i]) > 1e-3))
+    assert n_diff >= 150 and n_src >= 150, (n_diff, n_src, n_all)
+
+
 def test_model_text_roundtrip(oracle_built, gmm_golden):
     go, g = oracle_built, gmm_golden
     p = _params(go, g, "syn16x13")
