@@ -589,9 +589,9 @@ def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_b
     w, mu, sg = flush_models(g, c)[0]
     r6 = np.vectorize(lambda v: float("%g" % v))
     rng = np.random.default_rng(5)
-    mu2 = np.concatenate([mu, r6(40.0 + rng.standard_normal((2, mu.shape[1])))])
-    sg2 = np.concatenate([sg, np.full((2, mu.shape[1]), 0.05)])
-    w2 = r6(np.concatenate([w * 0.98, [0.01, 0.01]]))
+    mu2 = np.concatenate([mu[:-2], r6(1.5 + 0.1 * rng.standard_normal((2, mu.shape[1])))])   # (32 mixtures: no tile padding)
+    sg2 = np.concatenate([sg[:-2], np.full((2, mu.shape[1]), 0.01)])
+    w2 = r6(np.concatenate([w[:-2], [0.01, 0.01]]))
     hy = ModelSet([GMM.from_arrays(w2, mu2, sg2)])
     X = g[c + "_X"]
     want = go.score_batch(go.GMMParams(w2, mu2, sg2), X, go.MODE_FASTEXP)
