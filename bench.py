@@ -159,19 +159,23 @@ def score_roofline(kname, n_frames, S, K, D, avg_s, hbm_measured):
     ach = flops / avg_s / 1e12 if avg_s > 0 else 0.0
     ratio = executed_over_algorithmic(kname, S, K, D)
     if ratio:
-        peak = MFMA16_PEAK_TFLOPS / ratio
-        note = ("compute-bound (%.0f flop/B vs machine balance ~20).  achieved = algorithmic S*K*(4D+6) flops per frame / "
-                "HIP-event launch time.  The kernel evaluates each fp32 product as exact 16-bit part products on the "
-                "matrix cores (fp32 accumulate) and executes %.2fx the algorithmic flops; peak = dense 16-bit MFMA "
-                "%.0f TFLOP/s / %.2f.  fp32 MFMA / vector peak for scale: %.1f TFLOP/s." % (flops / byts, ratio, MFMA16_PEAK_TFLOPS, ratio, FP32_PEAK_TFLOPS))
+        peak = MFMA16_PEAK_TFLOPS
+        note = ("compute-bound (%.0f flop/B vs machine balance ~20).  achieved = ALGORITHMIC flops, S*K*(4D+6) per frame "
+                "(SURVEY.md 8d), / HIP-event launch time; peak = the dense 16-bit MFMA peak the work runs on; frac = "
+                "frac_algorithmic = achieved / peak.  The kernel evaluates each fp32 product as exact 16-bit part products on "
+                "the matrix cores (fp32 accumulate) and executes %.2fx the algorithmic flops: frac_executed_mfma = that "
+                "rate / peak = how busy the matrix pipe is.  fp32 MFMA / vector peak for scale: %.1f TFLOP/s."
+                % (flops / byts, ratio, FP32_PEAK_TFLOPS))
     else:
         peak, note = FP32_PEAK_TFLOPS, "compute-bound; fp32 engine: peak = fp32 MFMA = fp32 vector peak"
     r = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0.0,
+         "frac_algorithmic": ach / peak if peak else 0.0, "frac_executed_mfma": (ach * ratio / peak) if ratio else None,
          "note": note, "avg_launch_ms": 1e3 * avg_s,
          # long grids of the shared-sigma kernel are cut into several launches per pass (DESIGN.md 2.1 point 4): rocprofv3's
          # per-call average is avg_launch_ms / launches_per_pass
          "launches_per_pass": int(kname.split("[")[1].split()[0]) if "launches per pass" in kname else 1,
-         "traffic": None, "traffic_note": "PMC passes are separate runs: see profiles/ (FETCH_SIZE x2 + WRITE_SIZE per launch)",
+         "traffic": None, "traffic_note": "not collected for this block (the headline's is: rocprofv3 --pmc passes of this script, separate runs)",
+         "algorithmic_bytes": byts,
          "achieved_over_fp32_peak": ach / FP32_PEAK_TFLOPS,
          "hbm": {"achieved_GBps": byts / avg_s / 1e9 if avg_s > 0 else 0.0, "peak_GBps": HBM_PEAK_GBS,
                  "frac": byts / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
@@ -194,6 +198,53 @@ def mfcc_roofline(n_raw_frames, avg_s, hbm_measured):
                     "measured_copy_ceiling_GBps": hbm_measured},
             "note": "1- and 2-flop butterflies on the vector ALU: issue-bound well below the FMA peak; see DESIGN.md 2.2 "
                     "and profiles/ for the instruction-mix evidence"}
+
+
+# ------------------------------------------------------------------ HBM traffic of the dominant kernel (PMC)
+def measure_traffic(kernel_substr, extra_args):
+    """HBM-side bytes per scoring pass of the dominant kernel from the L2's fabric counters, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes
+    (they do not fit one), kernel trace only beside them; both are in KiB; on gfx950 FETCH_SIZE tallies a wide coalesced
+    read at half its bytes -> x2; WRITE_SIZE is uncalibrated and taken as is.  Each pass is a run of THIS script
+    (1 warm-up + 1 step, headline only) outside any timed region.  -> (bytes per pass or None, detail dict)"""
+    import csv
+    import glob
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    detail = {}
+    total = 0.0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+               "--no-config-blocks", "--no-traffic"] + extra_args
+        try:
+            run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+        except Exception as e:
+            return None, {"error": "%s pass: %s: %s" % (counter, type(e).__name__, e)}
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if run.returncode != 0 or not files:
+            return None, {"error": "%s pass failed (rc %d): %s" % (counter, run.returncode, (run.stderr or run.stdout)[-300:])}
+        kib, n = 0.0, 0
+        with open(files[0]) as fh:
+            for row in csv.DictReader(fh):
+                if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    kib += float(row["Counter_Value"])
+                    n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if n == 0:
+            return None, {"error": "no dispatch of %s in the %s pass" % (kernel_substr, counter)}
+        passes = 2.0                                       # 1 warm-up + 1 step, each one scoring pass
+        b = kib * 1024.0 / passes * (2.0 if counter == "FETCH_SIZE" else 1.0)
+        detail[counter + "_bytes_per_pass"] = b
+        detail[counter + "_dispatches"] = n
+        total += b
+    detail["method"] = ("rocprofv3 --kernel-trace --pmc <counter> of `bench.py --steps 1 --warmup 1` (headline only), one run per "
+                        "counter; KiB x 1024, FETCH_SIZE x 2 (gfx950 tallies wide reads at half), WRITE_SIZE as reported; per "
+                        "scoring pass (all launches of the kernel in it)")
+    return total, detail
+
 
 
 def kernel_times(_lib, steps):
@@ -303,63 +354,157 @@ def block_legacy(_lib):
             "max_rel_sum_diff_legacy_vs_fused": float(np.max(np.abs(got - sums) / np.maximum(1.0, np.abs(sums))))}
 
 
-def block_cfg3(_lib, hbm, preq):
-    """One rank's shard of configs[3], sub-sampled: the full 2048-mixture UBM + 1000 MAP speakers, 250 k of
-    the shard's 12.5 M frames (features drawn from the models)."""
+CFG3_S, CFG3_K, CFG3_TOTAL_FRAMES, CFG3_DISTINCT_UTTS = 1000, 2048, 100_000_000, 1250
+
+
+def cfg3_models():
+    from speaker_recognition_amd import synth
+    ubm = synth.synth_gmm(CFG3_K, DIM, 99)
+    w, mean, sigma = ubm
+    alpha = ((w * 40.0 * CFG3_K) / (w * 40.0 * CFG3_K + 16.0))[:, None]
+    spk = []
+    for s in range(CFG3_S):
+        rng = np.random.default_rng(500 + s)
+        spk.append((w, mean + alpha * 0.3 * rng.standard_normal(mean.shape), sigma))
+    return ubm, spk
+
+
+def block_cfg3(_lib, hbm, preq, world=1, rank=0, barrier=None, total_frames=CFG3_TOTAL_FRAMES):
+    """BASELINE.json configs[3] -- 2048-mixture UBM + 1000 MAP speakers, 100 M frames sharded by utterance over the GPUs of a
+    node -- as ONE rank sees it: the whole model set and its share of the frames.  At world = 1 the rank takes the shard of
+    an 8-GPU job (12.5 M frames, in full); at world = N > 1 the N ranks split the 100 M frames (strong scaling: the caller
+    takes the max over ranks).  Features are drawn from the models (SURVEY.md 8d, 0.1 % outlier frames at +60):
+    CFG3_DISTINCT_UTTS distinct utterances, repeated to the shard's size on the host (the kernels' time does not depend on
+    the values; 2 GB per 12.5 M frames do not fit any cache)."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.core import Batch, ModelSet
     from speaker_recognition_amd.pygmm import GMM
-    S, K, U, T = 1000, 2048, 250, 1000
-    ubm = synth.synth_gmm(K, DIM, 99)
-    w, mean, sigma = ubm
-    alpha = ((w * 40.0 * K) / (w * 40.0 * K + 16.0))[:, None]
-    spk = []
-    for s in range(S):
-        rng = np.random.default_rng(500 + s)
-        spk.append((w, mean + alpha * 0.3 * rng.standard_normal(mean.shape), sigma))
+    S, K, T = CFG3_S, CFG3_K, FRAMES_PER_UTT
+    n_ranks = world if world > 1 else 8
+    U = total_frames // T // n_ranks
+    ubm, spk = cfg3_models()
     t0 = time.perf_counter()
     ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + spk])
     t_pack = time.perf_counter() - t0
-    utts = [synth.draw_frames(spk[u % S], T, 9000 + u) for u in range(U)]
-    feats = Batch.from_features(utts)
+    distinct = min(U, CFG3_DISTINCT_UTTS)
+    first = rank * U                                     # this rank's utterances of the job: speaker = utterance % S
+    base = np.concatenate([synth.draw_frames(spk[(first + u) % S], T, 9000 + first + u, outlier_frac=0.001) for u in range(distinct)])
+    reps = (U + distinct - 1) // distinct
+    X = np.tile(base, (reps, 1))[:U * T]
+    feats = Batch.from_features(X, np.arange(U + 1, dtype=np.int64) * T)
+    del X
     step = lambda: ms.score(feats)
     step()
     _lib.profile_reset()
-    el, (sums, arg) = timed(step, 0, 2, _lib.synchronize)
+    el, (sums, arg) = timed(step, 0, 1, barrier or _lib.synchronize)
     ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
     ms_r, _ = _lib.profile_get(_lib.T_SCORE_REF)
     kname = _lib.last_score_kernel()
     n = U * T
-    sub = [0, 1, 2, 500, 1000]
-    allm = [ubm] + spk
-    preq["configs[3]_rank_shard_subsample"] = {"models": [allm[i] for i in sub], "X": utts[0].astype(np.float64),
-                                                "offsets": [0, T], "device_sums": sums[:1, sub]}
-    return {"workload": "BASELINE.json configs[3], one of 8 ranks, SUB-SAMPLED: 2048-mixture UBM + 1000 MAP speakers (all of them), "
-                        "%d of the rank's 12.5 M frames; full-shard time = this x %.0f (linear in frames)" % (n, 12.5e6 / n),
-            "frames_per_s": n * 2 / el, "s_per_pass": el / 2, "extrapolated_full_shard_s": el / 2 * 12.5e6 / n,
-            "model_pack_upload_s": t_pack,
-            "roofline": score_roofline(kname, n, S + 1, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm),
-            "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), np.arange(U) % S))}}
+    out = {"workload": "BASELINE.json configs[3]: 2048-mixture UBM + 1000 MAP speakers (all 1001 models), rank %d of %d: %d utterances x %d "
+                       "frames = %d of the job's 100 M frames, IN FULL (features drawn from the models, 0.1 %% outliers; %d distinct "
+                       "utterances repeated to the shard's size)" % (rank, n_ranks, U, T, n, distinct),
+           "frames": n, "frames_per_s": n / el, "s_per_pass": el, "model_pack_upload_s": t_pack,
+           "roofline": score_roofline(kname, n, S + 1, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm),
+           "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), (first + np.arange(U)) % S))}}
+    if preq is not None:
+        # parity sample for the pool of host cores: 20 utterances x ALL 1001 models, per frame (their own small batch) and
+        # per utterance (the sums of the full shard's pass)
+        n20 = 20
+        sub = Batch.from_features(base[:n20 * T], np.arange(n20 + 1, dtype=np.int64) * T)
+        s20, a20, f20 = ms.score(sub, frame_ll=True)
+        preq["configs[3]_rank_shard"] = {"models_recipe": {"kind": "cfg3", "K": K, "dim": DIM, "S": S, "ubm_seed": 99, "spk_seed": 500},
+                                         "X": base[:n20 * T], "offsets": np.arange(n20 + 1) * T, "device_sums": sums[:n20],
+                                         "device_frame_ll": f20}
+        out["parity"]["small_batch_sums_equal_full_pass"] = float(np.max(np.abs(s20 - sums[:n20]) / np.maximum(1.0, np.abs(s20))))
+    return out
+
+
+def block_published_em(_lib):
+    """The reference's only PUBLISHED benchmark (doc/Final-Report-Complete/result.tex:41-49, img/time-comp.pdf): EM training,
+    10 iterations, 256 mixtures, 13-dim MFCC, 512 k frames -- reference C++ ~475 s at 1 thread, ~125 s at 8, ~70 s at 16
+    (hardware unstated); here through the same entry point (train_model: random-frame start, threshold off so that all 10
+    iterations run), frames drawn from a 256-mixture model."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.pygmm import GMM
+    n, K, D, iters = 512000, 256, 13, 10
+    true = synth.synth_gmm(K, D, 5)
+    X = synth.draw_frames(true, n, 11)
+    GMM(K, nr_iteration=2, threshold=-1.0, seed=3).fit(X[:4000])          # warm-up
+    _lib.profile_reset()
+    g = GMM(K, nr_iteration=iters, threshold=-1.0, seed=3)
+    t0 = time.perf_counter()
+    it = g.fit(X)
+    dt = time.perf_counter() - t0
+    ms_e, n_e = _lib.profile_get(_lib.T_ESTEP)
+    ms_s, n_s = _lib.profile_get(_lib.T_SCORE)
+    gk = GMM(K, nr_iteration=iters, threshold=-1.0, seed=3, init_with_kmeans=1)
+    t0 = time.perf_counter()
+    gk.fit(X)
+    dt_k = time.perf_counter() - t0
+    ll = g.score_all(X[:50000]) / 50000
+    flops = 4.0 * K * n * D * it                          # the statistics pass alone: 2 FMAs per (frame, mixture, dim)
+    return {"workload": "reference_published_em: %d EM iterations, %d mixtures, %d dims, %d frames (result.tex:41-49)" % (it, K, D, n),
+            "seconds": dt, "seconds_per_iteration": dt / it, "seconds_with_kmeans_ii_start": dt_k,
+            "estep_stats_kernel_ms_total": ms_e, "score_kernel_ms_total": ms_s,
+            "estep_stats_tflops": flops / (ms_e * 1e-3) / 1e12 if ms_e > 0 else None,
+            "mean_ll_after": ll, "mean_ll_generating_model": GMM.from_arrays(*true).score_all(X[:50000]) / 50000,
+            "reference_published_seconds": {"c++ 1 thread": 475, "c++ 8 threads": 125, "c++ 16 threads": 70, "scikit-learn": 2400},
+            "vs_reference_16_threads": 70.0 / dt, "published_hardware": "unstated (2013 laptop/desktop class): not a like-for-like number"}
+
+
+def block_multi_slot(_lib, ex, base):
+    """The one-process multi-GPU path (sr_multi_predict_pcm: a host thread + model replica per slot, PCM from HOST memory
+    in every call) on the configs[1] workload with 2 slots on this one GPU, beside the resident-PCM step of the same work."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet, MultiPredictor
+    from speaker_recognition_amd.pygmm import GMM
+    raw = [synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s) for s in range(CFG1_MODELS)]
+    gm = [GMM.from_arrays(*m) for m in raw]
+    cat, off = make_pcm(base[:CFG1_MODELS], CFG1_UTTS, 0)
+    ms = ModelSet(gm)
+    pcm = Batch.from_pcm((cat, off))
+    step = lambda: ex.predict_batch(ms, pcm, nd=ND)
+    step(); step()
+    el_res, (sums, arg) = timed(step, 0, 10, _lib.synchronize)
+    out = {"workload": "configs[1] (%d utterances x %d frames, 100 x 64 mixtures): sr_multi_predict_pcm from host PCM "
+                       "(%.0f MB per call) vs the resident-PCM step" % (CFG1_UTTS, FRAMES_PER_UTT, cat.nbytes / 1e6),
+           "resident_pcm_ms_per_step": 1e3 * el_res / 10}
+    for slots in (1, 2):
+        mp_ = MultiPredictor(gm, FS, n_slots=slots, **MFCC_KW)
+        f = lambda: mp_.predict_concat(cat, off, nd=ND)
+        f(); f()
+        el, (s2, a2) = timed(f, 0, 10)
+        out["slots_%d" % slots] = {"ms_per_call": 1e3 * el / 10, "over_resident": (el / 10) / (el_res / 10),
+                                   "argmax_equal": bool(np.array_equal(a2, arg)),
+                                   "sums_bit_identical": bool(np.array_equal(s2, sums)), "slot_seconds": [float(v) for v in mp_.slot_seconds]}
+        del mp_
+    return out
 
 
 def block_point256(_lib, hbm, preq):
-    """north_star's '256 mixtures x 39-dim' point: ONE 256-mixture model, 2 M frames."""
+    """north_star's '256 mixtures x 39-dim' point: ONE 256-mixture model, 2 M frames (100 distinct utterances drawn from the
+    model with 0.1 % outlier frames, SURVEY.md 8d, each 20 times in the batch)."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.core import Batch, ModelSet
     from speaker_recognition_amd.pygmm import GMM
     m = synth.synth_gmm(256, DIM, 77)
     ms = ModelSet([GMM.from_arrays(*m)])
-    utts = [synth.draw_frames(m, 1000, 100 + u) for u in range(100)]
+    utts = [synth.draw_frames(m, 1000, 100 + u, outlier_frac=0.001) for u in range(100)]
     feats = Batch.from_features([utts[u % 100] for u in range(2000)])
     step = lambda: ms.score(feats)
     step()
     _lib.profile_reset()
     el, (sums, arg) = timed(step, 0, 5, _lib.synchronize)
     ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
-    preq["north_star_256x39"] = {"models": [m], "X": utts[3].astype(np.float64), "offsets": [0, 1000], "device_sums": sums[3:4, :1]}
+    kname = _lib.last_score_kernel()
+    # parity: the WHOLE block (its 100 distinct utterances), per frame and per utterance
+    s100, a100, f100 = ms.score(Batch.from_features(utts), frame_ll=True)
+    preq["north_star_256x39"] = {"models": [m], "X": np.concatenate(utts), "offsets": np.arange(101) * 1000, "device_sums": sums[:100, :1],
+                                 "device_frame_ll": f100}
     return {"workload": "north_star point: 1 model x 256 mixtures x 39 dims, 2 M frames resident",
             "frames_per_s": 2e6 * 5 / el,
-            "roofline": score_roofline(_lib.last_score_kernel(), 2000000, 1, 256, DIM, ms_k / max(1, n_k) * 1e-3, hbm),
+            "roofline": score_roofline(kname, 2000000, 1, 256, DIM, ms_k / max(1, n_k) * 1e-3, hbm),
             "parity": None}
 
 
@@ -456,6 +601,9 @@ def main():
     ap.add_argument("--utts", type=int, default=CFG2_UTTS, help="utterances per GPU (default: the configs[2] size, 10 M frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config-blocks", action="store_true", help="headline only (PMC / rocprof passes)")
+    ap.add_argument("--cfg3-total-frames", type=int, default=CFG3_TOTAL_FRAMES,
+                    help="testing only: total frames of the configs[3] job the ranks split (default: its stated 100 M)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc sub-runs that fill roofline.traffic")
     ap.add_argument("--cpu-sample-utts", type=int, default=4)
     ap.add_argument("--device-override", type=int, default=-1,
                     help="testing only: put every rank on this device (N>1 code path on a 1-GPU box)")
@@ -534,19 +682,34 @@ def main():
         dist.all_gather_object(rates, rank_rate)
     else:
         rates = [rank_rate]
+    kt = kernel_times(_lib, args.steps)
+    kname = _lib.last_score_kernel()
+    # ---- N > 1: north_star's configs[3] split -- the N ranks share the 100 M frames (strong scaling), every rank with
+    #      the whole 2048-mixture UBM + 1000 speakers; wall time = the slowest rank's
+    strong = None
+    if dist is not None and not args.no_config_blocks:
+        del pcm
+        mine = block_cfg3(_lib, None, None, world, rank, barrier, args.cfg3_total_frames)
+        t = torch.tensor([mine["s_per_pass"]], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"frames": mine["frames"], "s_per_pass": mine["s_per_pass"], "own_speaker_wins": mine["parity"]["own_speaker_wins"]})
+        strong = {"workload": "BASELINE.json configs[3] at its stated size: 2048-mixture UBM + 1000 MAP speakers, 100 M frames split by utterance "
+                              "over %d ranks (strong scaling; models replicated; no collective on the data path)" % world,
+                  "frames_total": sum(p["frames"] for p in per_rank), "stated_frames": CFG3_TOTAL_FRAMES, "n_gpus": world, "wall_s": float(t[0]),
+                  "frames_per_s": sum(p["frames"] for p in per_rank) / float(t[0]), "per_rank": per_rank,
+                  "roofline_rank0": mine["roofline"], "scaling": "strong"}
     if rank != 0:
         if dist is not None:
             dist.barrier()
         return
 
-    kt = kernel_times(_lib, args.steps)
-    kname = _lib.last_score_kernel()
     hbm = _lib.hbm_copy_gbps(1 << 30, 10)
     # the same step WITH the feature/scoring pipelining (8 chunks of utterances, feature kernels of chunk i+1.. on a
     # second stream under the scoring of chunk i): an option, off by default because it measures slower
     kt1 = kt
     el8, kt8 = None, None
-    if not args.no_config_blocks:
+    if not args.no_config_blocks and world == 1:
         _lib.set_option("predict_chunks", 8)
         step()
         _lib.profile_reset()
@@ -570,8 +733,9 @@ def main():
                  "MFCC in fp32, CMVN statistics in f64)",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]: 16 kHz synthetic PCM -> 13 MFCC (25/10 ms, FFT 2048, 50 filters) + CMVN + "
-                               "delta + delta-delta = 39 dims; 512-mixture diagonal UBM (EM on the device) + %d MAP-adapted speaker "
-                               "GMMs = %d models x 512 mixtures per frame; %d utterances x %d frames per GPU"
+                               "delta + delta-delta = 39 dims; 512-mixture diagonal UBM + %d speaker GMMs MAP-style adapted from it (SURVEY.md 8d's "
+                               "synthetic models: sigma and weights shared, means moved) = %d models x 512 mixtures per frame; "
+                               "%d utterances x %d frames per GPU"
                                % (CFG2_SPEAKERS, S, args.utts, FRAMES_PER_UTT),
                    "frames_per_gpu": n_frames, "models": S, "mixtures": CFG2_MIX, "dim": DIM,
                    "sharding": "utterances/%d ranks, models replicated, no collective" % world},
@@ -592,6 +756,14 @@ def main():
         "parity": {"all_sums_finite": bool(np.all(np.isfinite(sums))),
                    "last_two_steps_bit_identical": bool(np.array_equal(prev, sums)) if prev is not None else None},
     }
+    if strong is not None:
+        result["configs[3]_strong_scaling"] = strong
+    if world == 1 and not args.no_traffic:
+        tb, td = measure_traffic(kname.split("<")[0].split()[0], ["--utts", str(args.utts)])
+        result["roofline"]["traffic"] = tb
+        result["roofline"]["traffic_unit"] = "bytes per scoring pass (HBM side of L2)"
+        result["roofline"]["traffic_over_algorithmic"] = (tb / result["roofline"]["algorithmic_bytes"]) if tb else None
+        result["roofline"]["traffic_note"] = td
     if world == 1 and not args.no_cpu_baseline:
         tmp = tempfile.mkdtemp()
         sample_models = [0] + list(range(1, 12))           # the UBM + 11 speakers: bounded CPU work
@@ -627,11 +799,26 @@ def main():
                 "cpu_sample": "%d utterances x %d models vs the reference's C++ scorer on the float64 numpy MFCC" % (spec["n_utt"], len(files))})
     if world == 1 and not args.no_config_blocks:
         blocks, preq = {}, {}
+        # headline parity for the pool of host cores: the first 200 utterances x ALL 201 models -- per frame on their own
+        # batch (features = the device's own MFCC output) and per utterance against the sums of the timed 10 M-frame pass
+        try:
+            n200 = min(200, args.utts)
+            fb = ex.extract_batch(Batch.from_pcm((cat[:off[n200]], off[:n200 + 1])), nd=ND)
+            s200, a200, f200 = ms.score(fb, frame_ll=True)
+            preq["configs[2]_headline"] = {"models_recipe": {"kind": "cfg2", "K": CFG2_MIX, "dim": DIM, "S": CFG2_SPEAKERS, "ubm_seed": 99, "spk_seed": 500},
+                                           "X": fb.download(), "offsets": fb.offsets(), "device_sums": sums[:n200], "device_frame_ll": f200}
+            result["parity"]["small_batch_sums_vs_timed_pass_max_rel"] = float(np.max(np.abs(s200 - sums[:n200]) / np.maximum(1.0, np.abs(s200))))
+            del fb, f200
+        except Exception as e:
+            result["parity"]["headline_sample_error"] = "%s: %s" % (type(e).__name__, e)
+        del pcm
         for name, fn in (("configs[1]", lambda: block_cfg1(_lib, ex, base, hbm, preq)),
-                         ("configs[3]_rank_shard_subsample", lambda: block_cfg3(_lib, hbm, preq)),
+                         ("configs[3]_rank_shard", lambda: block_cfg3(_lib, hbm, preq, total_frames=args.cfg3_total_frames)),
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
                          ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
+                         ("reference_published_em", lambda: block_published_em(_lib)),
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
+                         ("sr_multi_predict_pcm_2_slots", lambda: block_multi_slot(_lib, ex, base)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
             try:
                 blocks[name] = fn()
@@ -648,6 +835,10 @@ def main():
             for name, v in par.items():
                 if isinstance(blocks.get(name), dict):
                     blocks[name]["parity"] = dict(blocks[name].get("parity") or {}, **v)
+                elif name == "configs[2]_headline":
+                    result["parity"]["headline_200_utterances_x_all_models"] = v
+                elif name == "_checker":
+                    result["parity"]["checker"] = v
         except Exception as e:
             blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
         result["configs"] = blocks

@@ -170,9 +170,81 @@ static double gaussian_logprob(const double *x, const double *mean, const double
  *   mode 2: float64 log-sum-exp over per-mixture log densities (gmm.cc:78-99 for the
  *           density) -- the formulation the HIP kernel uses; `clamp_compat` applies the
  *           reference's underflow behaviour (terms < DBL_MIN are 0; none left -> ln(1e-15)).
+ *   mode 3: mode 0's result at a fraction of its cost (see score_batch_fast).
  * Layout: weights[K], mean[K*D], sigma[K*D] (sigma = standard deviations, gmm.hh:24-46),
  * X[n*D] row-major, out[n].
  */
+/*
+ * mode 3 -- the reference's result (mode 0) at a fraction of its cost, for the bulk parity checks of bench.py
+ * (oracle/parity_check.py: hundreds of utterances x every model on the host cores).  Per-mixture constants
+ * c_k = ln w_k - sum ln(sqrt(2 pi) s) and 1/(2 s^2) are formed once; a frame's value is the float64 log-sum-exp
+ * of c_k - sum_d (x - mu)^2 / (2 s^2) under the full-product underflow rule of mode 2 -- and every frame whose
+ * value falls in the band in which the reference's flushes of PARTIAL products can decide (gmm.cc:192-195;
+ * [ln DBL_MIN, ln DBL_MIN + max_k sum_d max(0, -ln s_kd) + ln K + 17.5), the same band the HIP engines use,
+ * csrc/lse.hpp) is evaluated again by mode 0 itself.  Differs from mode 0 by remez5's polynomial error only
+ * (<= 1.2e-6 absolute); tests/test_oracle_golden.py holds it to mode 0 on every golden.
+ */
+static void score_batch_fast(const double *weights, const double *mean, const double *sigma, int K, int D,
+                             const double *X, long n, double *out, int ftz, int clamp_compat)
+{
+    const double minlog = -7.08396418532264106224e2;
+    double *c = (double *)malloc(sizeof(double) * (size_t)K);
+    double *h = (double *)malloc(sizeof(double) * (size_t)K * (size_t)D);
+    double *v = (double *)malloc(sizeof(double) * (size_t)K);
+    double lift = 0;
+    for (int k = 0; k < K; k++) {
+        double ck = weights[k] > 0 ? log(weights[k]) : -INFINITY, up = 0;
+        for (int d = 0; d < D; d++) {
+            double s = sigma[(long)k * D + d];
+            ck -= log(SQRT_2_PI * s);
+            h[(long)k * D + d] = 1.0 / (2 * s * s);
+            if (-log(s) > 0) up += -log(s);
+        }
+        c[k] = ck;
+        if (up > lift) lift = up;
+    }
+    const double band_hi = minlog + lift + log((double)K) + 17.5;
+    for (long t = 0; t < n; t++) {
+        const double *x = X + t * (long)D;
+        double m = -INFINITY;
+        for (int k = 0; k < K; k++) {
+            const double *mu = mean + (long)k * D, *hk = h + (long)k * D;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            int d = 0;
+            for (; d + 4 <= D; d += 4) {
+                double e0 = x[d] - mu[d], e1 = x[d + 1] - mu[d + 1], e2 = x[d + 2] - mu[d + 2], e3 = x[d + 3] - mu[d + 3];
+                a0 += e0 * e0 * hk[d];
+                a1 += e1 * e1 * hk[d + 1];
+                a2 += e2 * e2 * hk[d + 2];
+                a3 += e3 * e3 * hk[d + 3];
+            }
+            for (; d < D; d++) {
+                double e0 = x[d] - mu[d];
+                a0 += e0 * e0 * hk[d];
+            }
+            v[k] = c[k] - ((a0 + a1) + (a2 + a3));
+            if (v[k] > m) m = v[k];
+        }
+        double s = 0;
+        for (int k = 0; k < K; k++)
+            if ((!clamp_compat || v[k] >= minlog) && v[k] > -INFINITY)
+                s += exp(v[k] - m);
+        double ll = (m > -INFINITY) ? m + log(s) : -INFINITY;
+        if (clamp_compat && m < minlog)
+            ll = log(1e-15);
+        else if (clamp_compat && ll < band_hi) {        /* the partial products decide: the reference's own arithmetic */
+            double prob = 0;
+            for (int k = 0; k < K; k++)
+                prob += flush(weights[k] * gaussian_prob_fastexp(x, mean + (long)k * D, sigma + (long)k * D, D, ftz, 2), ftz);
+            ll = safe_log(prob);
+        }
+        out[t] = ll;
+    }
+    free(c);
+    free(h);
+    free(v);
+}
+
 static int g_flush_order = 2;
 /* 1 = source order, 2 = as compiled (see gaussian_prob_fastexp); the default is what the DSO does */
 void oracle_set_flush_order(int order) { g_flush_order = order == 1 ? 1 : 2; }
@@ -181,6 +253,10 @@ void oracle_gmm_score_batch(const double *weights, const double *mean, const dou
                             int K, int D, const double *X, long n, double *out,
                             int mode, int ftz, int clamp_compat)
 {
+    if (mode == 3) {
+        score_batch_fast(weights, mean, sigma, K, D, X, n, out, ftz, clamp_compat);
+        return;
+    }
     for (long t = 0; t < n; t++) {
         const double *x = X + t * (long)D;
         if (mode == 0 || mode == 1) {

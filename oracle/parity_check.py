@@ -1,19 +1,76 @@
 """oracle/parity_check.py -- TEST / MEASUREMENT INFRASTRUCTURE ONLY.
 
-Checker leg of bench.py: reads a pickle {name: {"models": [(w, mean, sigma), ...], "X": float64[n, D],
-"offsets": int[U + 1], "device_sums": float64[U, S]}}, scores every utterance under every model
-with the C restatement of the reference's arithmetic (oracle/gmm_oracle.c, mode 0 = what its C ABI
-computes), and prints one JSON line {name: {"max_rel_sum_diff_vs_oracle": ..., ...}}.  Runs as a
-subprocess: the benchmark process itself never imports oracle/."""
+Checker leg of bench.py.  Reads a pickle {name: spec} with
+
+    "models"            [(w, mean, sigma), ...]            or
+    "models_recipe"     {"kind": "cfg3", ...} / {"kind": "cfg2", ...}   (regenerated here with the product's own
+                        speaker_recognition_amd.synth, seed for seed -- 1001 x 2048 x 39 doubles do not travel well)
+    "X"                 float[n, D]  the frames the DEVICE scored (its own MFCC output, or drawn features)
+    "offsets"           int[U + 1]
+    "device_sums"       float64[U, S]   (optional)   "device_frame_ll"  float32[S, n]  (optional)
+
+scores every frame under every model with the C restatement of the reference's arithmetic (oracle/gmm_oracle.c mode 3 =
+mode 0, what the reference's C ABI computes, to remez5's 1.2e-6: score_batch_fast) on ALL host cores --
+multiprocessing.Pool over (model, frame range) tasks, the shape of the reference's own test driver
+(src/test/test-gmm.py:128-133) -- and prints one JSON line {name: {...}}: worst per-frame and per-utterance relative
+differences, frames whose clamp decision differs, argmax mismatches.  Runs as a subprocess: the benchmark process itself
+never imports oracle/."""
 import json
+import multiprocessing as mp
 import os
 import pickle
 import sys
+import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+_REQ = {}          # name -> spec with "models" materialised; inherited by the forked workers
+FRAME_CHUNK = 20000
+
+
+def _models_from_recipe(rc):
+    from speaker_recognition_amd import synth
+    if rc["kind"] == "cfg3":       # bench.py block_cfg3
+        ubm = synth.synth_gmm(rc["K"], rc["dim"], rc["ubm_seed"])
+        w, mean, sigma = ubm
+        alpha = ((w * 40.0 * rc["K"]) / (w * 40.0 * rc["K"] + 16.0))[:, None]
+        out = [ubm]
+        for s in range(rc["S"]):
+            rng = np.random.default_rng(rc["spk_seed"] + s)
+            out.append((w, mean + alpha * 0.3 * rng.standard_normal(mean.shape), sigma))
+        return out
+    if rc["kind"] == "cfg2":       # bench.py headline: synth.synth_map_speaker
+        ubm = synth.synth_gmm(rc["K"], rc["dim"], rc["ubm_seed"])
+        return [ubm] + [synth.synth_map_speaker(ubm, rc["spk_seed"] + s) for s in range(rc["S"])]
+    raise ValueError(rc["kind"])
+
+
+def _task(t):
+    """(name, model, frame range) -> worst per-frame relative difference, clamp mismatches, per-utterance partial sums"""
+    from oracle import gmm_oracle as go
+    name, s, f0, f1 = t
+    r = _REQ[name]
+    p = go.GMMParams(*[np.asarray(a, dtype=np.float64) for a in r["models"][s]])
+    ll = go.score_batch(p, r["X"][f0:f1], go.MODE_FAST)
+    worst, clamp_bad = 0.0, 0
+    dev = r.get("device_frame_ll")
+    if dev is not None:
+        d = dev[s, f0:f1].astype(np.float64)
+        worst = float(np.max(np.abs(d - ll) / np.maximum(1.0, np.abs(ll)))) if len(ll) else 0.0
+        clamp_bad = int(np.sum((dev[s, f0:f1] == np.float32(go.LN_1E_15)) != (ll == go.LN_1E_15)))
+    off = r["offsets"]
+    u0 = int(np.searchsorted(off, f0, side="right") - 1)
+    parts = []
+    u = u0
+    while u < len(off) - 1 and off[u] < f1:
+        a, b = max(off[u], f0), min(off[u + 1], f1)
+        if b > a:
+            parts.append((u, float(ll[a - f0:b - f0].sum())))
+        u += 1
+    return name, s, worst, clamp_bad, parts
 
 
 def main():
@@ -21,22 +78,53 @@ def main():
     if not os.path.exists(go.ORACLE_SO):
         go.build(ref=False)
     req = pickle.load(open(sys.argv[1], "rb"))
+    tasks = []
+    for name, r in req.items():
+        if "models" not in r:
+            r["models"] = _models_from_recipe(r["models_recipe"])
+        r["X"] = np.ascontiguousarray(r["X"], dtype=np.float64)
+        r["offsets"] = np.asarray(r["offsets"], dtype=np.int64)
+        if r.get("device_frame_ll") is not None:
+            r["device_frame_ll"] = np.asarray(r["device_frame_ll"], dtype=np.float32)
+        n = len(r["X"])
+        for s in range(len(r["models"])):
+            for f0 in range(0, n, FRAME_CHUNK):
+                tasks.append((name, s, f0, min(n, f0 + FRAME_CHUNK)))
+        _REQ[name] = r
+    cores = os.cpu_count() or 1
+    procs = max(1, min(cores, len(tasks)))
+    t0 = time.perf_counter()
+    if procs > 1:
+        with mp.get_context("fork").Pool(procs) as pool:
+            results = pool.map(_task, tasks, chunksize=max(1, len(tasks) // (8 * procs)))
+    else:
+        results = [_task(t) for t in tasks]
+    elapsed = time.perf_counter() - t0
     out = {}
     for name, r in req.items():
-        X = np.ascontiguousarray(r["X"], dtype=np.float64)
-        off = np.asarray(r["offsets"])
-        dev = np.asarray(r["device_sums"], dtype=np.float64)
-        worst, am = 0.0, 0
-        want = np.zeros_like(dev)
-        for s, m in enumerate(r["models"]):
-            ll = go.score_batch(go.GMMParams(*[np.asarray(a, dtype=np.float64) for a in m]), X)
-            for u in range(len(off) - 1):
-                want[u, s] = ll[off[u]:off[u + 1]].sum()
-        worst = float(np.max(np.abs(dev - want) / np.maximum(1.0, np.abs(want))))
-        if dev.shape[1] > 1:
-            am = int(np.sum(np.argmax(dev, axis=1) != np.argmax(want, axis=1)))
-        out[name] = {"max_rel_sum_diff_vs_oracle": worst, "argmax_mismatches": am,
-                     "utterances": int(dev.shape[0]), "models": int(dev.shape[1]), "frames": int(len(X))}
+        U, S = len(r["offsets"]) - 1, len(r["models"])
+        want = np.zeros((U, S))
+        worst, clamp_bad = 0.0, 0
+        for nm, s, w, cb, parts in results:
+            if nm != name:
+                continue
+            worst = max(worst, w)
+            clamp_bad += cb
+            for u, v in parts:
+                want[u, s] += v
+        o = {"utterances": U, "models": S, "frames": int(len(r["X"])),
+             "mixture_evaluations": int(len(r["X"])) * int(sum(len(m[0]) for m in r["models"]))}
+        if r.get("device_frame_ll") is not None:
+            o["max_rel_frame_ll_diff_vs_oracle"] = worst
+            o["frames_with_different_clamp_decision"] = clamp_bad
+        if r.get("device_sums") is not None:
+            dev = np.asarray(r["device_sums"], dtype=np.float64)
+            o["max_rel_sum_diff_vs_oracle"] = float(np.max(np.abs(dev - want) / np.maximum(1.0, np.abs(want))))
+            if S > 1:
+                o["argmax_mismatches"] = int(np.sum(np.argmax(dev, axis=1) != np.argmax(want, axis=1)))
+        out[name] = o
+    out["_checker"] = {"processes": procs, "host_cores": cores, "seconds": elapsed, "tasks": len(tasks),
+                       "oracle": "oracle/gmm_oracle.c mode 3 (= the reference's C ABI arithmetic to remez5's 1.2e-6), float64"}
     print(json.dumps(out))
 
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256)
 void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict__ center,
                             const float *__restrict__ params, const FlushModel *__restrict__ models,
                             const TileDesc *__restrict__ tiles, const int2 *__restrict__ pairs, int dim, int dp,
-                            int frames_per_tile, int64_t n_frames, float *__restrict__ exact_out,
+                            int frames_per_tile, int64_t n_frames, float band_hi, float *__restrict__ exact_out,
                             float *__restrict__ frame_ll) {
     __shared__ double xs_all[4][MAX_DIM];
     const int lane = threadIdx.x & 63;
@@ -89,6 +89,49 @@ void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict
     for (int d = lane; d < dim; d += 64) xs[d] = (double)X[row * dim + d] - (double)center[d];
     wave_sync();
     const FlushModel fm = models[pr.y];
+    // ---- phase 1: the frame's value in the log domain (float64, full-product underflow rule of lse.hpp: what the
+    //      engines compute, 2 FMAs per mixture and dimension).  Most frames of a noted tile are ordinary ones that
+    //      merely share the tile with the frame that was in the band: their value stands.
+    const double MINLOG2 = -708.396418532264106224 * 1.4426950408889634073599;
+    double vmax = -INFINITY;
+    for (int k = lane; k < fm.n_records * KB; k += 64) {
+        const float *rec = params + ((size_t)fm.offset_f4 * 4 + (size_t)(k / KB) * rec_f);
+        const int jj = k % KB;
+        const float c = rec[(size_t)2 * dp * 4 + jj];
+        if (!(c > NEG_BIG)) continue;
+        double q = 0.0;
+        for (int d = 0; d < dim; d++) {
+            const double t = xs[d] * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
+            q += t * t;
+        }
+        vmax = fmax(vmax, (double)c - q);
+    }
+    for (int o = 32; o > 0; o >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, o));
+    double s1 = 0.0;
+    for (int k = lane; k < fm.n_records * KB; k += 64) {
+        const float *rec = params + ((size_t)fm.offset_f4 * 4 + (size_t)(k / KB) * rec_f);
+        const int jj = k % KB;
+        const float c = rec[(size_t)2 * dp * 4 + jj];
+        if (!(c > NEG_BIG)) continue;
+        double q = 0.0;
+        for (int d = 0; d < dim; d++) {
+            const double t = xs[d] * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
+            q += t * t;
+        }
+        const double v = (double)c - q;
+        if (v >= MINLOG2) s1 += exp2(v - vmax);
+    }
+    s1 = wave_sum_f64(s1);
+    const double ll1 = vmax < MINLOG2 ? (double)LSE_LN_1E_15 : LN2 * (vmax + log2(s1));
+    if (!(ll1 < (double)band_hi)) {                      // (also a NaN frame: it stays NaN)
+        if (lane == 0) {
+            const float ll = (float)ll1;
+            exact_out[(int64_t)blockIdx.x * frames_per_tile + j] = ll;
+            if (frame_ll) frame_ll[(int64_t)pr.y * n_frames + row] = ll;
+        }
+        return;
+    }
+    // ---- phase 2: the band.  The reference's own arithmetic.
     double sum = 0.0;
     for (int k = lane; k < fm.n_records * KB; k += 64) {
         const float *rec = params + ((size_t)fm.offset_f4 * 4 + (size_t)(k / KB) * rec_f);
@@ -249,7 +292,8 @@ void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const in
 #define SR_FLUSH_LAUNCH(ORDER)                                                                                            \
         hipLaunchKernelGGL(gmm_flush_exact_kernel<ORDER>, grid, dim3(256), 0, ctx().stream, feat.data.p, set.d_center0.p,  \
                            set.d_params.p, reinterpret_cast<const FlushModel *>(set.d_flush_models.p), tt.d_tiles.p,       \
-                           fw.sorted.p + base, feat.dim, set.host.dp, fpt, feat.n_rows, fw.exact.p, d_frame_ll)
+                           fw.sorted.p + base, feat.dim, set.host.dp, fpt, feat.n_rows,                        \
+                           (float)(-708.396418532264 + set.host.flush_band), fw.exact.p, d_frame_ll)
         if (flush_order_option() == 1) SR_FLUSH_LAUNCH(1); else SR_FLUSH_LAUNCH(2);
 #undef SR_FLUSH_LAUNCH
         hipLaunchKernelGGL(gmm_flush_tile_sum_kernel, dim3((unsigned)n), dim3(64), 0, ctx().stream, fw.exact.p, tt.d_tiles.p,
