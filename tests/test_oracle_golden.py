@@ -99,6 +99,27 @@ def test_gmm_oracle_partial_product_flushes_match_reference(oracle_built, flush_
     assert n_diff >= 150 and n_src >= 150, (n_diff, n_src, n_all)
 
 
+def test_gmm_oracle_fast_mode_equals_the_reference(oracle_built, gmm_golden, clamp_golden, flush_golden):
+    """Mode 3 (the bulk checker of bench.py: per-mixture constants, vectorised across mixtures, the reference's own
+    arithmetic only in the band where its partial-product flushes decide) against the reference DSO's goldens: remez5's
+    polynomial error (<= 1.2e-6 absolute) is all that separates them, clamp decisions are identical."""
+    from conftest import flush_models
+    go = oracle_built
+    for g in (gmm_golden, clamp_golden):
+        for c in g["cases"]:
+            ref = g[c + "_ll"]
+            got = go.score_batch(go.GMMParams(g[c + "_w"], g[c + "_mean"], g[c + "_sigma"]), g[c + "_X"], go.MODE_FAST)
+            assert np.array_equal(got == go.LN_1E_15, ref == go.LN_1E_15), c
+            assert np.max(np.abs(got - ref)) < 2e-6, c
+    g = flush_golden
+    for c in g["cases"]:
+        for i, m in enumerate(flush_models(g, c)):
+            ref = g[c + "_ll"][i]
+            got = go.score_batch(go.GMMParams(*m), g[c + "_X"], go.MODE_FAST)
+            assert np.array_equal(got == go.LN_1E_15, ref == go.LN_1E_15), c
+            assert np.max(np.abs(got - ref)) < 2e-6, c
+
+
 def test_model_text_roundtrip(oracle_built, gmm_golden):
     go, g = oracle_built, gmm_golden
     p = _params(go, g, "syn16x13")
