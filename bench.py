@@ -406,7 +406,7 @@ def block_cfg3(_lib, hbm, preq, world=1, rank=0, barrier=None, total_frames=CFG3
                        "utterances repeated to the shard's size)" % (rank, n_ranks, U, T, n, distinct),
            "frames": n, "frames_per_s": n / el, "s_per_pass": el, "model_pack_upload_s": t_pack,
            "roofline": score_roofline(kname, n, S + 1, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm),
-           "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), (first + np.arange(U)) % S))}}
+           "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), (first + np.arange(U) % distinct) % S))}}
     if preq is not None:
         # parity sample for the pool of host cores: 20 utterances x ALL 1001 models, per frame (their own small batch) and
         # per utterance (the sums of the full shard's pass)

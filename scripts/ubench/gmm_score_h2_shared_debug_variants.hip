@@ -1,3 +1,7 @@
+// FROZEN COPY (round 2, commit 16e5f76) of csrc/gmm_score_h2_shared.hip WITH its -DH2S_DEBUG_* / -DH2S_WIDE_G experiment
+// switches: every one of them produces WRONG RESULTS by construction (stall / energy experiments of
+// profiles/r02_h2s_stalls.txt, r02_h2s_energy.txt).  Not built, not shipped; the product source no longer carries them.
+
 // gmm_score_h2_shared.hip -- split-fp16 scoring of speaker sets that share sigma and weights: a UBM
 // and the speakers MAP-adapted from it (train_model_from_ubm moves the means only, gmmubm.cc:40-81;
 // BASELINE configs[2] and [3]).  Math of gmm.cc:176-202, :237-244, :533-569 in the form
@@ -114,7 +118,6 @@ struct H2sArgs {
     int tile_base;                // first frame tile of this launch (long grids are cut into several launches)
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
-    float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
 
 // Workgroup shapes: waves per workgroup x 32-frame column tiles per wave x images per LDS stage.
@@ -130,7 +133,11 @@ __host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, i
 __host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) {
     // 4-wave form: 2 images per stage (three workgroups per CU share the LDS); 12-wave form: 4 (measured on the
     // configs[2]-shaped 5 M-frame pass: 8 images 0.145 s, 4 images 0.137 s, 2 images 0.138 s)
+#ifdef H2S_WIDE_G                 /* experiment: images per stage of the wide form */
+    return waves == 4 ? 2 : H2S_WIDE_G;
+#else
     return waves == 4 ? 2 : 4;
+#endif
 }
 
 template <int KQF, int KLF, int COLS, int WAVES>
@@ -175,8 +182,10 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     // tile loop altogether (the stage-0 barrier had no wait: stale fragments for the second model of
     // a block whenever the parameters came from HBM rather than L2).  So: explicit.
     auto publish_barrier = [&]() {
+#ifndef H2S_DEBUG_NO_BARRIER      /* stall experiment only: wrong results */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     };
 
     const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
@@ -207,8 +216,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     }
     if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);           // saturated: the host re-scores on the fp32-grade engines
     // the largest term is >= LL - log2 K; below this the online pass decides
-    // (and everything below the band in which the reference's partial-product flushes can decide, lse.hpp)
-    const float safe_ll2 = a.clamp ? fmaxf(LSE_MINLOG2 + LSE_NEAR + a.log2_k, a.band_hi * H2S_LOG2E + 1.0f) : -3.0e38f;
+    const float safe_ll2 = a.clamp ? LSE_MINLOG2 + LSE_NEAR + a.log2_k : -3.0e38f;
 
     const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 zero16[COLS];
@@ -237,9 +245,15 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         constexpr int KM = KQF > KLF ? KQF : KLF;
         uint4 fr[KM];
         auto load_frags = [&](const uint4 *at, int kn) {
+#ifdef H2S_DEBUG_ONE_FRAG         /* energy experiment only: one LDS read per image, wrong results */
+            fr[0] = at[0];
+#pragma unroll
+            for (int ks = 1; ks < KM; ks++) fr[ks] = fr[0];
+#else
 #pragma unroll
             for (int ks = 0; ks < KM; ks++)
                 if (ks < kn) fr[ks] = at[ks * 64];
+#endif
         };
         const int n_stage_total = a.n_mix_tiles * N_STAGES;
         __syncthreads();                      // previous block's readers are done with both buffers
@@ -268,10 +282,15 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                         // every wave holds its fragments of this stage: `cur` may be refilled, and
                         // the stage after this one has landed (its DMA was issued a stage ago)
                         publish_barrier();
+#ifdef H2S_DEBUG_DMA_THIRD       /* stall experiment only: a third of the stream (wrong results) */
+                        if (st % 3 == 0)
+#endif
+#ifndef H2S_DEBUG_NO_DMA          /* stall experiment only: wrong results */
                         if (st + 2 < N_STAGES)
                             stage_load(cur, tsrc + (size_t)(st + 2) * G * IMG_U4);
                         else if (more_tiles)
                             stage_load(cur, tsrc + STRIDE_U4 + (size_t)(st + 2 - N_STAGES) * G * IMG_U4);
+#endif
                         if (st + 1 < N_STAGES || more_tiles)
                             load_frags(nxt + lane, (st + 1 < N_STAGES) ? KLF : KQF);
                     } else {
@@ -286,17 +305,16 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                     } else {
 #pragma unroll
                         for (int c = 0; c < COLS; c++) {
-                            // (Tried in round 3 and lost, profiles/r03_h2s_experiments.txt: skipping the 16 exponentials of a
-                            // model-tile whose 64 x 16 terms are all below 2^-36 of the frame's offset -- 8 v_max3 + a compare +
-                            // a wave-uniform branch.  7-9 % SLOWER on every workload: with 32 different frames per wave tile
-                            // almost every tile holds a term that matters for some lane; and unsafe as it stood, the offset
-                            // being the UBM's value, not the model's own.)
                             float e0 = 0.0f, e1 = 0.0f;
+#ifdef H2S_DEBUG_NO_EPILOGUE      /* energy experiment only: wrong results */
+                            e0 = acc[c][0]; e1 = acc[c][15];
+#else
 #pragma unroll
                             for (int r = 0; r < 16; r += 2) {
                                 e0 += __builtin_amdgcn_exp2f(acc[c][r]);
                                 e1 += __builtin_amdgcn_exp2f(acc[c][r + 1]);
                             }
+#endif
                             ssum[c][img - 1] += e0 + e1;
                             asm volatile("" : "+v"(ssum[c][img - 1]));
                         }
@@ -318,7 +336,11 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                 // the offset form is only trusted well inside fp32's exponent range and well above
                 // the reference's underflow boundary
                 const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
+#if defined(H2S_DEBUG_NO_EPILOGUE) || defined(H2S_DEBUG_ONE_FRAG) || defined(H2S_DEBUG_NO_DMA) || defined(H2S_DEBUG_NO_BARRIER) || defined(H2S_DEBUG_DMA_THIRD)
+                (void)ok;                                   // energy experiments: results are wrong by construction
+#else
                 bad |= (valid[c] && si < sb.n_models && !ok) || a.force_exc;
+#endif
             }
             if (__builtin_amdgcn_ballot_w64(bad) != 0) {      // wave-uniform
                 if (lane == 0 && has[c]) {
@@ -418,9 +440,7 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
                 mine = (double)ll;
                 if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll;
             }
-            const bool hot = valid && hh == 0 && si < sb.n_models && ll < a.band_hi;
             mine = wave_sum_f64(mine);
-            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
             if (lane == 0 && si < sb.n_models)
                 a.partial[(int64_t)e.x * a.n_models + sb.first_model + si] = mine;
             __builtin_amdgcn_sched_barrier(0);
@@ -456,7 +476,6 @@ static int launch_h2s(const H2sLaunch &l) {
     a.n_tiles = l.n_tiles;
     a.log2_k = l.log2_k;
     a.force_exc = l.force_exc;
-    a.band_hi = l.band_hi;
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
     constexpr int TILES_WG = WAVES * COLS;
     const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES));
