@@ -21,6 +21,7 @@ void burn_reference_rand(int count);     // kmeans_init.hip
 void reference_rand_sample(int *out, int count);
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed);
+void set_em_stats_engine(int v);
 }  // namespace sr
 
 using namespace sr;
@@ -775,6 +776,9 @@ int sr_set_option(const char *key, long value) {
             fail("flush_order must be 2 (partial products as the reference DSO's compiler forms them: even / odd dimensions) or "
                  "1 (the source's order, gmm.cc:192-195)");
         flush_order_option() = (int)value;
+    } else if (k == "em_stats_engine") {
+        if (value != 0 && value != 1) fail("em_stats_engine must be 0 (automatic: fp64 matrix cores for dims <= 40) or 1 (vector ALU)");
+        set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
     } else if (k == "mfcc_generic") {

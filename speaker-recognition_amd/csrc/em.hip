@@ -13,6 +13,7 @@
 // update does not cancel).  The M-step is O(K*D) and runs on the host in float64 with the
 // reference's formulas.
 #include "score.hpp"
+#include "wave_ops.hpp"
 
 #include "../../include/pygmm_hip.h"
 
@@ -124,6 +125,216 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The statistics on the fp64 matrix cores (round 3).  sum_i g_ik [x_i | x_i^2 | 1] is a product
+// Gamma^T [K x N] . Y [N x (2D+1)], and v_mfma_f64_16x16x4_f64 accumulates it in float64 from operands that are exact
+// in float64 (g: the fp32 responsibility; x, x^2: the fp32 feature and its exact square), so the sums can be taken
+// about the ORIGIN -- no per-mixture centring, which is what kept the old form off the matrix cores; the host's float64
+// M-step re-centres (E[x^2] - E[x]^2 costs (mu/sigma)^2 eps_64).  M = 16 mixtures, N = 16 statistic columns,
+// K = 4 frames per instruction: lane l supplies A[mixture l & 15][frame l >> 4] = g and B[frame l >> 4][column l & 15] = y
+// and receives D[mixture (l >> 4) + 4 r][column l & 15], r = 0..3 (the f64 layout, NOT the f32 one).
+//
+// A workgroup = 4 waves on ONE 64-frame tile at a time and 64 mixtures (16 per wave) for its whole life: the 16
+// parameter records sit in LDS from the start; the tile's raw rows arrive transposed ([d][frame], stride 68: conflict-free
+// for both access patterns below) by LDS-DMA one tile ahead.  Per tile a wave (lane = frame) evaluates its 16 mixtures'
+// responsibilities in the 2-FMA form of the scoring kernel (same arithmetic as before), passes them through LDS into
+// the A layout, and issues 16 frame groups x NCB column blocks of MFMAs into NCB x 4 float64 accumulators that live in
+// registers until the workgroup's frame range is done.  Columns: [x, 16 per block][x^2, 16 per block][the rest of x, of
+// x^2, the count] -- only the last block(s) mix kinds, so a B operand is one cvt (x) or cvt + mul (x^2).
+// Per-(frame chunk) slabs in float64, added in a fixed order by em_reduce64_kernel: deterministic.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int EMM_WAVES = 4, EMM_MB = 16, EMM_WG_MIX = EMM_WAVES * EMM_MB;
+constexpr int EMM_F = 2;                       // frames per lane in the responsibility phase: a parameter read serves both
+constexpr int EMM_FT = 64 * EMM_F;             // frames per tile
+constexpr int EMM_XS = EMM_FT + 4, EMM_GS = EMM_FT + 4;   // row strides = 4 mod 64: both access patterns conflict-free
+__host__ __device__ constexpr int emm_ncb(int dp) { return 2 * (dp / 16) + (2 * (dp % 16) + 1 + 15) / 16; }
+
+template <int DP>
+__global__ __launch_bounds__(EMM_WAVES * 64, 2)
+void em_stats_mfma_kernel(const float *__restrict__ X, int64_t n_frames, int dim, const float4 *__restrict__ params,
+                          const float *__restrict__ center, int n_records, const float *__restrict__ frame_ll,
+                          double *__restrict__ slabs /* [gridDim.y][gridDim.x * 64][NCB * 16] */, int n_tiles) {
+    constexpr int REC = 2 * DP + 1;
+    constexpr int NFULL = DP / 16, REM = DP % 16, NCB = emm_ncb(DP);
+    constexpr int RECS_WG = EMM_WG_MIX / KB;                       // 16 records per workgroup
+    extern __shared__ float4 em_lds[];
+    float4 *par = em_lds;                                          // [RECS_WG * REC]
+    float *xt = reinterpret_cast<float *>(par + RECS_WG * REC);    // raw rows of the tile, [d][frame], stride EMM_XS
+    float *gs_all = xt + DP * EMM_XS;                              // responsibilities, per wave [mixture][frame], stride EMM_GS
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rec0 = blockIdx.x * RECS_WG;                         // first record of this workgroup
+    // ---- this workgroup's parameter records -> LDS (dead records beyond the model: c = -1e30, everything else 0)
+    for (int i = tid; i < RECS_WG * REC; i += EMM_WAVES * 64) {
+        const int r = rec0 + i / REC;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n_records) v = params[(size_t)r * REC + (i % REC)];
+        else if (i % REC == 2 * DP) v = make_float4(NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG);
+        par[i] = v;
+    }
+    // frame range of this workgroup
+    const int tiles_per = (n_tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_begin = (int)blockIdx.y * tiles_per, t_end = min(n_tiles, t_begin + tiles_per);
+    // the tile's rows -> xt[d][frame]: one LDS-DMA wave-instruction per dimension and 64 frames (lane = frame supplies its
+    // own global address, LDS takes the lanes side by side), the four waves take every fourth dimension
+    auto fetch_tile = [&](int tile) {
+#pragma unroll
+        for (int h = 0; h < EMM_F; h++) {
+            int64_t f = (int64_t)tile * EMM_FT + 64 * h + lane;
+            if (f >= n_frames) f = n_frames - 1;                    // (a valid address; the lane's responsibilities are 0)
+            const float *src = X + f * dim;
+            for (int d = wave; d < DP; d += EMM_WAVES)
+                if (d < dim)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + d),
+                                                     (__attribute__((address_space(3))) void *)(&xt[d * EMM_XS + 64 * h]), 4, 0, 0);
+        }
+    };
+    if (DP != dim)                                                 // padded dimensions read as 0
+        for (int i = tid; i < DP * EMM_XS; i += EMM_WAVES * 64) xt[i] = 0.f;
+
+    // What column (16 cb + j) of this lane's B operand is.  Blocks 0 .. NFULL-1 are x_d and blocks NFULL .. 2 NFULL-1 x_d^2 of
+    // the SAME d = 16 cb + j: one LDS read and one conversion serve both.  The remaining block(s) mix kinds per lane:
+    // y = v (alpha + beta v) + gamma with (alpha, beta, gamma) = (1,0,0) for x, (0,1,0) for x^2, (0,0,1) for the count,
+    // (0,0,0) for padding -- two fp64 FMAs, no selects.
+    const int j = lane & 15, fl = lane >> 4;
+    constexpr int NMIX = NCB - 2 * NFULL;
+    int boff[NFULL > 0 ? NFULL : 1], moff[NMIX];
+    double al[NMIX], be[NMIX], ga[NMIX];
+#pragma unroll
+    for (int cb = 0; cb < NFULL; cb++) boff[cb] = (16 * cb + j) * EMM_XS + fl;
+#pragma unroll
+    for (int mb = 0; mb < NMIX; mb++) {
+        const int q = 16 * mb + j;
+        int d = 0;
+        al[mb] = be[mb] = ga[mb] = 0.0;
+        if (q < REM) { d = 16 * NFULL + q; al[mb] = 1.0; }
+        else if (q < 2 * REM) { d = 16 * NFULL + q - REM; be[mb] = 1.0; }
+        else if (q == 2 * REM) ga[mb] = 1.0;
+        moff[mb] = d * EMM_XS + fl;
+    }
+    f64x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    float *g = gs_all + (size_t)wave * EMM_MB * EMM_GS;
+    const float4 *mypar = par + (size_t)wave * (EMM_MB / KB) * REC;
+
+    for (int tile = t_begin; tile < t_end; tile++) {
+        __syncthreads();                       // every wave is done with the previous tile's rows (and `par` is filled)
+        fetch_tile(tile);
+        dma_publish_barrier();                 // this tile's rows have landed for every wave
+        // ---- responsibilities of this wave's 16 mixtures, lane = frames l and l + 64 (the 2-FMA form on x - centre, as
+        //      the scoring kernel; one parameter read from LDS serves both frames)
+        // underflowed frames (and the lanes beyond the data) carry no responsibility (gmm.cc:482-498): their "log-likelihood"
+        // is +1e30, so every 2^(c - q - lse2) below is 2^-1e30 = 0 without a select for the compiler to branch around
+        float lse2[EMM_F];
+        float x[EMM_F][DP];
+#pragma unroll
+        for (int h = 0; h < EMM_F; h++) {
+            const int64_t frame = (int64_t)tile * EMM_FT + 64 * h + lane;
+            lse2[h] = 1.0e30f;
+            if (frame < n_frames) {
+                const float ll = frame_ll[frame];
+                lse2[h] = ll >= EM_MINLOG ? ll * LOG2E_F : 1.0e30f;
+            }
+#pragma unroll
+            for (int d = 0; d < DP; d++) x[h][d] = xt[d * EMM_XS + 64 * h + lane] - center[d];
+        }
+        // (the records never change: without an offset the compiler cannot see through, it hoists every parameter read of all
+        // four records out of the TILE loop -- 1264 registers' worth -- and spills the frame)
+        int roff = 0;
+        asm volatile("" : "+s"(roff));
+#pragma unroll 1
+        for (int r = 0; r < EMM_MB / KB; r++) {
+            const float4 *rec = mypar + roff + r * REC;
+            float a4[EMM_F][KB];
+#pragma unroll
+            for (int h = 0; h < EMM_F; h++)
+#pragma unroll
+                for (int m = 0; m < KB; m++) a4[h][m] = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; d++) {
+                const float4 p0 = rec[2 * d];
+                const float4 p1 = rec[2 * d + 1];
+#pragma unroll
+                for (int h = 0; h < EMM_F; h++) {
+                    const float t0 = fmaf(x[h][d], p0.x, p0.y);
+                    const float t1 = fmaf(x[h][d], p0.z, p0.w);
+                    const float t2 = fmaf(x[h][d], p1.x, p1.y);
+                    const float t3 = fmaf(x[h][d], p1.z, p1.w);
+                    a4[h][0] = fmaf(t0, t0, a4[h][0]);
+                    a4[h][1] = fmaf(t1, t1, a4[h][1]);
+                    a4[h][2] = fmaf(t2, t2, a4[h][2]);
+                    a4[h][3] = fmaf(t3, t3, a4[h][3]);
+                }
+            }
+            const float4 cc = rec[2 * DP];
+#pragma unroll
+            for (int h = 0; h < EMM_F; h++) {
+                g[(r * KB + 0) * EMM_GS + 64 * h + lane] = __builtin_amdgcn_exp2f(cc.x - a4[h][0] - lse2[h]);
+                g[(r * KB + 1) * EMM_GS + 64 * h + lane] = __builtin_amdgcn_exp2f(cc.y - a4[h][1] - lse2[h]);
+                g[(r * KB + 2) * EMM_GS + 64 * h + lane] = __builtin_amdgcn_exp2f(cc.z - a4[h][2] - lse2[h]);
+                g[(r * KB + 3) * EMM_GS + 64 * h + lane] = __builtin_amdgcn_exp2f(cc.w - a4[h][3] - lse2[h]);
+            }
+        }
+        wave_sync();
+        // ---- EMM_FT / 4 frame groups x NCB column blocks on the fp64 matrix cores
+#pragma unroll 4
+        for (int fg = 0; fg < EMM_FT / 4; fg++) {
+            const double av = (double)g[j * EMM_GS + 4 * fg + fl];             // A[mixture j][frame 4 fg + fl]
+#pragma unroll
+            for (int cb = 0; cb < NFULL; cb++) {
+                const double v = (double)xt[boff[cb] + 4 * fg];
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v, acc[cb], 0, 0, 0);
+                acc[NFULL + cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v * v, acc[NFULL + cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < NMIX; mb++) {
+                const double v = (double)xt[moff[mb] + 4 * fg];
+                const double y = __builtin_fma(v, __builtin_fma(be[mb], v, al[mb]), ga[mb]);
+                acc[2 * NFULL + mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y, acc[2 * NFULL + mb], 0, 0, 0);
+            }
+        }
+        wave_sync();                           // (gs is rewritten by this wave's next tile)
+    }
+    // ---- this workgroup's sums -> its slab: D[mixture (l >> 4) + 4 r][column l & 15]
+    double *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EMM_WG_MIX * (NCB * 16);
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            slab[(size_t)(wave * EMM_MB + fl + 4 * r) * (NCB * 16) + 16 * cb + j] = acc[cb][r];
+}
+
+// dynamic LDS of em_stats_mfma_kernel<DP>: 16 parameter records, one transposed tile of rows, four waves' responsibilities
+static size_t emm_lds_bytes(int DP) {
+    return (size_t)(EMM_WG_MIX / KB) * (2 * DP + 1) * sizeof(float4) + (size_t)DP * EMM_XS * sizeof(float) +
+           (size_t)EMM_WAVES * EMM_MB * EMM_GS * sizeof(float);
+}
+
+// sums the frame chunks' slabs in chunk order and unpacks the column blocks: out[k][2 DP + 1] = sum g x_d | sum g x_d^2 | sum g
+template <int DP>
+__global__ __launch_bounds__(256)
+void em_reduce64_kernel(const double *__restrict__ slabs, int n_chunks, int n_ranges, int k_pad /* the old layout's */,
+                        double *__restrict__ out) {
+    constexpr int REC = 2 * DP + 1, NFULL = DP / 16, REM = DP % 16, NC = emm_ncb(DP) * 16;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= k_pad * REC) return;
+    const int k = e / REC, c = e - k * REC;
+    // statistic c of the old layout -> column of the blocked one
+    const int kind = c < DP ? 0 : c < 2 * DP ? 1 : 2, d = kind == 0 ? c : kind == 1 ? c - DP : 0;
+    int col;
+    if (kind == 2) col = 2 * NFULL * 16 + 2 * REM;
+    else if (d < 16 * NFULL) col = (kind == 0 ? 0 : NFULL * 16) + d;
+    else col = 2 * NFULL * 16 + (d - 16 * NFULL) + (kind == 0 ? 0 : REM);
+    const int range = k / EMM_WG_MIX, kk = k - range * EMM_WG_MIX;
+    double acc = 0.0;
+    if (range < n_ranges)
+        for (int ch = 0; ch < n_chunks; ch++)
+            acc += slabs[(((size_t)ch * n_ranges + range) * EMM_WG_MIX + kk) * NC + col];
+    out[e] = acc;
+}
+
 __global__ __launch_bounds__(256)
 void em_reduce_kernel(const float *__restrict__ slabs, int n_slabs, int n_elem,
                       double *__restrict__ out) {
@@ -155,14 +366,51 @@ static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const flo
 #undef SR_CASE
 }
 
+template <int DP>
+static void launch_stats_mfma(const float *X, int64_t n, int dim, const float4 *params, const float *center, int n_records,
+                              const float *frame_ll, double *slabs, int n_tiles64, int n_ranges, int n_chunks, int k_pad, double *out) {
+    static bool attr_set[MAX_DEVICES] = {};
+    if (!attr_set[ctx().device]) {
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&em_stats_mfma_kernel<DP>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)emm_lds_bytes(DP)));
+        attr_set[ctx().device] = true;
+    }
+    hipLaunchKernelGGL((em_stats_mfma_kernel<DP>), dim3(n_ranges, n_chunks), dim3(EMM_WAVES * 64), emm_lds_bytes(DP), ctx().stream, X,
+                       n, dim, params, center, n_records, frame_ll, slabs, n_tiles64);
+    const int n_elem = k_pad * (2 * DP + 1);
+    hipLaunchKernelGGL((em_reduce64_kernel<DP>), dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, ctx().stream, slabs, n_chunks,
+                       n_ranges, k_pad, out);
+}
+
+// the fp64 matrix-core form is instantiated for padded dims <= 40 (its LDS -- 16 parameter records, a transposed 128-frame
+// tile, the responsibilities: 75 KiB at DP = 39 -- lets two workgroups share a CU); wider rows keep em_stats_kernel
+static bool stats_mfma_available(int DP) { return DP <= 40; }
+static size_t stats_mfma_slab_doubles(int DP, int n_ranges, int n_chunks) {
+    return (size_t)n_chunks * n_ranges * EMM_WG_MIX * (size_t)(emm_ncb(DP) * 16);
+}
+static void dispatch_stats_mfma(int DP, const float *X, int64_t n, int dim, const float4 *params, const float *center, int n_records,
+                                const float *frame_ll, double *slabs, int n_tiles64, int n_ranges, int n_chunks, int k_pad, double *out) {
+#define SR_CASE(V) case V: launch_stats_mfma<V>(X, n, dim, params, center, n_records, frame_ll, slabs, n_tiles64, n_ranges, n_chunks, k_pad, out); break;
+    switch (DP) {
+        SR_CASE(8) SR_CASE(13) SR_CASE(16) SR_CASE(24) SR_CASE(26) SR_CASE(32) SR_CASE(34) SR_CASE(39) SR_CASE(40)
+        default: fail("no fp64 matrix-core EM kernel for padded dim %d", DP);
+    }
+#undef SR_CASE
+}
+
 // initialisation: kmeans_init.hip (the reference's own draws, decision for decision)
 void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Parameter &param, long seed);
 void burn_reference_rand(int count);
 
 struct EmWorkspace {
     DevBuf<float> slabs, mean_f32;
-    DevBuf<double> stats;
+    DevBuf<double> stats, slabs64;
 };
+static int &em_stats_engine_option() {
+    static int v = 0;       // 0 = automatic (fp64 matrix cores where instantiated), 1 = the vector-ALU form always
+    return v;
+}
+void set_em_stats_engine(int v) { em_stats_engine_option() = v; }
 static EmWorkspace &ews() { return per_device<EmWorkspace>(); }
 
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
@@ -230,26 +478,52 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         const ScoreResult sres = score_device(set, feat, true, SCORE_PRECISE);
         if (trace) sync_stream();
         const double t3 = now();
-        std::vector<float> mean_f32((size_t)K_pad * DP, 0.f);
-        for (int k = 0; k < K; k++)
-            for (int d = 0; d < dim; d++) mean_f32[(size_t)k * DP + d] = (float)gmm.mean[(size_t)k * dim + d];
-        w.mean_f32.upload(mean_f32.data(), mean_f32.size());
         const size_t n_elem = (size_t)K_pad * REC;
-        w.slabs.ensure((size_t)grid * n_elem);
         w.stats.ensure(n_elem);
-        SR_HIP(hipMemsetAsync(w.slabs.p, 0, (size_t)grid * n_elem * sizeof(float), ctx().stream));
-        {
+        const bool use_mfma = stats_mfma_available(DP) && em_stats_engine_option() == 0;
+        if (use_mfma) {
+            // sums about the origin on the fp64 matrix cores (em_stats_mfma_kernel); re-centred below
+            const int n_ranges = (n_records + EMM_WG_MIX / KB - 1) / (EMM_WG_MIX / KB);
+            const int n_tiles64 = (int)((n + EMM_FT - 1) / EMM_FT);
+            const int n_chunks = std::max(1, std::min(n_tiles64, (4 * ctx().n_cu + n_ranges - 1) / n_ranges));
+            w.slabs64.ensure(stats_mfma_slab_doubles(DP, n_ranges, n_chunks));
             ScopedKernelTimer t(T_ESTEP);
-            dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p,
-                           n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
+            dispatch_stats_mfma(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p, n_records,
+                                sres.d_frame_ll, w.slabs64.p, n_tiles64, n_ranges, n_chunks, K_pad, w.stats.p);
+        } else {
+            std::vector<float> mean_f32((size_t)K_pad * DP, 0.f);
+            for (int k = 0; k < K; k++)
+                for (int d = 0; d < dim; d++) mean_f32[(size_t)k * DP + d] = (float)gmm.mean[(size_t)k * dim + d];
+            w.mean_f32.upload(mean_f32.data(), mean_f32.size());
+            w.slabs.ensure((size_t)grid * n_elem);
+            SR_HIP(hipMemsetAsync(w.slabs.p, 0, (size_t)grid * n_elem * sizeof(float), ctx().stream));
+            {
+                ScopedKernelTimer t(T_ESTEP);
+                dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p,
+                               n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
+            }
+            SR_HIP(hipGetLastError());
+            hipLaunchKernelGGL(em_reduce_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0,
+                               ctx().stream, w.slabs.p, grid, (int)n_elem, w.stats.p);
         }
-        SR_HIP(hipGetLastError());
-        hipLaunchKernelGGL(em_reduce_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0,
-                           ctx().stream, w.slabs.p, grid, (int)n_elem, w.stats.p);
         SR_HIP(hipGetLastError());
         std::vector<double> stats(n_elem);
         w.stats.download(stats.data(), n_elem);
         sync_stream();
+        if (use_mfma) {
+            // T1 = sum g x, T2 = sum g x^2, N = sum g  ->  the centred sums the M-step below works on, about the fp32 mean
+            // the vector form centres on: sum g (x - m) = T1 - N m, sum g (x - m)^2 = T2 - 2 m T1 + N m^2 (float64)
+            for (int k = 0; k < K; k++) {
+                double *st = stats.data() + (size_t)k * REC;
+                const double N = st[2 * DP];
+                for (int d = 0; d < dim; d++) {
+                    const double m = (double)(float)gmm.mean[(size_t)k * dim + d];
+                    const double t1 = st[d], t2 = st[DP + d];
+                    st[d] = t1 - N * m;
+                    st[DP + d] = t2 - 2.0 * m * t1 + N * m * m;
+                }
+            }
+        }
         const double t4 = now();
 
         // Mixtures without support: a responsibility below fp32's range (~1e-38) is 0 on the device, while the
