@@ -14,15 +14,16 @@ from speaker_recognition_amd import synth  # noqa: E402
 from speaker_recognition_amd.pygmm import GMM  # noqa: E402
 
 out = []
-for n, K, D in ((512000, 256, 13), (2000000, 512, 39)):
+for n, K, D in ((512000, 256, 13), (2000000, 512, 39), (1000000, 2048, 39)):
     true = synth.synth_gmm(K, D, 5)
     X = synth.draw_frames(true, n, 11)
     GMM(8, nr_iteration=0, init_with_kmeans=1, seed=1, concurrency=8).fit(X[:4000])      # warm-up
     row = {"frames": n, "mixtures": K, "dims": D}
     for km in (0, 1):
-        g = GMM(K, nr_iteration=0, init_with_kmeans=km, seed=3, concurrency=int(os.environ.get("KM_CONC", 16)))
+        g = GMM(K, nr_iteration=0, init_with_kmeans=km, seed=3, concurrency=int(os.environ.get("KM_CONC", os.cpu_count() or 16)))
         t0 = time.perf_counter()
         g.fit(X)
         row["init_with_kmeans=%d_seconds" % km] = time.perf_counter() - t0
+    row["concurrency (worker blocks whose order the sums keep)"] = int(os.environ.get("KM_CONC", os.cpu_count() or 16))
     out.append(row)
 print(json.dumps(out))

@@ -17,14 +17,25 @@
 // ceil(n / concurrency) points, then over the blocks); sums that feed a decision are formed in that
 // order here as well.  The O(n K D) part -- nearest centre and squared distance of every point -- runs on
 // the device in float64, dimension by dimension with separate multiply and add as the reference's SSE2
-// build does (no FMA); the per-cluster sums of a Lloyd step are added on the host in the reference's
-// order (O(n D) per step, one host thread per worker block).
+// build does (no FMA).  The per-cluster sums of a Lloyd step on the full data are formed on the device too
+// (round 3), in the reference's order: a stable radix sort of the points by (worker block, cluster) puts every
+// (block, cluster)'s members side by side in point order; one thread per (cluster, dimension) then adds each
+// (block, cluster)'s members side by side in point order; one thread per (block, cluster, dimension) adds them one
+// after the other, one per (cluster, dimension) the blocks' sums in block order -- the additions calc_belonging and
+// Lloyds_iteration make (kmeans.cc:72-107, :189-212), bit for bit, at device bandwidth instead of 9 s of host
+// loops in front of a 2048-mixture UBM.
+// The full data keeps every coordinate (gmm.cc:288-294 dense2sparse; only the CANDIDATE centres of the weighted
+// k-means++ / weighted Lloyd stages go through Vector2Instance, which drops |x| < 1e-15, kmeans++.cc:42-51), so
+// the distance here is the dense one.
 #include "score.hpp"
 
 #include "../../include/pygmm_hip.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -92,60 +103,187 @@ struct RandStream {
     }
 };
 
-constexpr int KM_CH = 32;          // centres per LDS chunk
+constexpr int KM_CH = 16;          // centres per LDS chunk
+constexpr int KM_PP = 2;           // points per lane: a centre coordinate read from LDS serves both
 constexpr int KM_MAX_ITER = 200;   // kmeans.cc:172, :272
+typedef double km_d2 __attribute__((ext_vector_type(2)));
 
 // Nearest centre among centres [c_begin, c_end): dist[i] / belong[i] are updated when a centre is STRICTLY
 // closer (kmeansII.cc:59-72; with dist preset to DBL_MAX it is the full search of kmeans.cc:87-99).
-__global__ __launch_bounds__(256)
+// float64, dimension by dimension, subtract - multiply - add as the reference's SSE2 build (no FMA): the distances
+// and therefore every decision taken on them are the reference's, bit for bit.  A lane keeps two points in registers
+// (fp32, widened per use) and 2 x 16 running sums; a chunk of 16 centres sits in LDS transposed ([d][centre]), so one
+// 16-byte broadcast read feeds two centres x two points x three operations: the kernel is bound by the fp64 vector rate
+// (round 2's one point per lane and one 8-byte read per three operations was bound by LDS issue: 21 ms per pass of
+// 1 M points x 2048 centres x 39 dims).
+template <int DIM_MAX>
+__global__ __launch_bounds__(256, 2)
 void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const double *__restrict__ C,
                           int c_begin, int c_end, double *__restrict__ dist, int *__restrict__ belong, int reset) {
-    extern __shared__ double cs[];               // [KM_CH][dim]
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n;
-    const float *x = X + (valid ? i : 0) * dim;
-    double best = reset ? 1.7976931348623157e308 : valid ? dist[i] : 0.0;     // reset: a fresh search (DBL_MAX, no centre yet)
-    int best_j = reset ? -1 : valid ? belong[i] : 0;
+    __shared__ km_d2 cs[DIM_MAX * KM_CH / 2];    // [d][KM_CH]
+    double *csd = reinterpret_cast<double *>(cs);
+    constexpr bool XREG = DIM_MAX <= 40;         // wider rows are re-read (L1 / L2) instead of held: 2 x 128 registers would spill
+    float x[KM_PP][XREG ? DIM_MAX : 1];
+    const float *xsrc[KM_PP];
+    long idx[KM_PP];
+    bool valid[KM_PP];
+    double best[KM_PP];
+    int best_j[KM_PP];
+#pragma unroll
+    for (int p = 0; p < KM_PP; p++) {
+        idx[p] = ((long)blockIdx.x * KM_PP + p) * 256 + threadIdx.x;
+        valid[p] = idx[p] < n;
+        const float *src = X + (valid[p] ? idx[p] : 0) * dim;
+        xsrc[p] = src;
+        if constexpr (XREG) {
+#pragma unroll
+            for (int d = 0; d < DIM_MAX; d++) x[p][d] = d < dim ? src[d] : 0.f;
+        }
+        best[p] = reset ? 1.7976931348623157e308 : valid[p] ? dist[idx[p]] : 0.0;     // reset: a fresh search (DBL_MAX, no centre yet)
+        best_j[p] = reset ? -1 : valid[p] ? belong[idx[p]] : 0;
+    }
     for (int c0 = c_begin; c0 < c_end; c0 += KM_CH) {
         const int nc = min(KM_CH, c_end - c0);
         __syncthreads();
-        for (int e = threadIdx.x; e < nc * dim; e += 256) cs[e] = C[(size_t)c0 * dim + e];
+        for (int e = threadIdx.x; e < KM_CH * dim; e += 256) {
+            const int j = e / dim, d = e - j * dim;
+            csd[d * KM_CH + j] = j < nc ? C[(size_t)(c0 + j) * dim + d] : 0.0;
+        }
         __syncthreads();
-        double acc[KM_CH];
+        double acc[KM_PP][KM_CH];
 #pragma unroll
-        for (int j = 0; j < KM_CH; j++) acc[j] = 0.0;
-        for (int d = 0; d < dim; d++) {
-            const double xv = (double)x[d];
+        for (int p = 0; p < KM_PP; p++)
 #pragma unroll
-            for (int j = 0; j < KM_CH; j++) {
-                if (j < nc) {
-                    const double delta = __dsub_rn(xv, cs[j * dim + d]);
-                    acc[j] = __dadd_rn(acc[j], __dmul_rn(delta, delta));      // mul, then add: the reference has no FMA
+            for (int j = 0; j < KM_CH; j++) acc[p][j] = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM_MAX; d++) {
+            if (d < dim) {
+                double xv[KM_PP];
+#pragma unroll
+                for (int p = 0; p < KM_PP; p++) xv[p] = XREG ? (double)x[p][XREG ? d : 0] : (double)xsrc[p][d];
+#pragma unroll
+                for (int j2 = 0; j2 < KM_CH / 2; j2++) {
+                    const km_d2 c = cs[d * (KM_CH / 2) + j2];
+#pragma unroll
+                    for (int p = 0; p < KM_PP; p++) {
+                        const double d0 = __dsub_rn(xv[p], c.x), d1 = __dsub_rn(xv[p], c.y);
+                        acc[p][2 * j2] = __dadd_rn(acc[p][2 * j2], __dmul_rn(d0, d0));      // mul, then add: the reference has no FMA
+                        acc[p][2 * j2 + 1] = __dadd_rn(acc[p][2 * j2 + 1], __dmul_rn(d1, d1));
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);      // (keeps the next dimensions' LDS reads from being hoisted: registers)
             }
         }
 #pragma unroll
-        for (int j = 0; j < KM_CH; j++)
-            if (j < nc && acc[j] < best) {
-                best = acc[j];
-                best_j = c0 + j;
-            }
+        for (int p = 0; p < KM_PP; p++)
+#pragma unroll
+            for (int j = 0; j < KM_CH; j++)
+                if (j < nc && acc[p][j] < best[p]) {
+                    best[p] = acc[p][j];
+                    best_j[p] = c0 + j;
+                }
     }
-    if (valid) {
-        dist[i] = best;
-        belong[i] = best_j;
-    }
+#pragma unroll
+    for (int p = 0; p < KM_PP; p++)
+        if (valid[p]) {
+            dist[idx[p]] = best[p];
+            belong[idx[p]] = best_j[p];
+        }
 }
 
 struct KmWorkspace {
     DevBuf<float> X;
     DevBuf<double> C, dist;
     DevBuf<int> belong;
+    // Lloyd on the full data, cluster sums on the device
+    DevBuf<unsigned> key_in, key_out, idx_in, idx_out, seg;
+    DevBuf<char> sort_tmp;
+    DevBuf<double> csum, bsum, segsum;
+    DevBuf<int> csize;
 };
 KmWorkspace &kws() { return per_device<KmWorkspace>(); }
 
+// key = worker block * K + cluster (a point without a cluster -- NaN centres -- sorts behind everything); value = the point
+__global__ __launch_bounds__(256)
+void lloyd_keys_kernel(const int *__restrict__ belong, long n, long block, int K, unsigned n_keys, unsigned *__restrict__ key,
+                       unsigned *__restrict__ idx) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = belong[i];
+    key[i] = j >= 0 ? (unsigned)(i / block) * (unsigned)K + (unsigned)j : n_keys;
+    idx[i] = (unsigned)i;
+}
+
+// seg[k] = first position of key k in the sorted keys (k = 0 .. n_keys inclusive)
+__global__ __launch_bounds__(256)
+void lloyd_segments_kernel(const unsigned *__restrict__ sorted, long n, unsigned n_keys, unsigned *__restrict__ seg) {
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k > n_keys) return;
+    long lo = 0, hi = n;
+    while (lo < hi) {
+        const long mid = (lo + hi) >> 1;
+        if (sorted[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    seg[k] = (unsigned)lo;
+}
+
+// One thread per (block b, cluster j, dimension d): the members of (b, j) one after the other in point order into a sum
+// that starts at 0.0 (calc_belonging's new_centroids, kmeans.cc:78-103); consecutive threads take consecutive dimensions of
+// the same member rows.
+__global__ __launch_bounds__(256)
+void lloyd_segment_sum_kernel(const float *__restrict__ X, int dim, size_t n_seg_elems, const unsigned *__restrict__ seg,
+                              const unsigned *__restrict__ idx, double *__restrict__ buf) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_seg_elems) return;
+    const size_t k = e / dim;
+    const int d = (int)(e - k * dim);
+    const unsigned lo = seg[k], hi = seg[k + 1];
+    double s = 0.0;
+    for (unsigned p = lo; p < hi; p++) s = __dadd_rn(s, (double)X[(size_t)idx[p] * dim + d]);
+    buf[e] = s;
+}
+
+// One thread per (cluster j, dimension d): the blocks' sums in block order into a total that starts at 0.0 (Lloyds_iteration,
+// kmeans.cc:198-204) -- an empty (block, cluster) adds its 0.0 like the reference -- and the cluster's size.
+__global__ __launch_bounds__(256)
+void lloyd_centroid_kernel(int dim, int K, int n_blocks, const unsigned *__restrict__ seg, const double *__restrict__ buf,
+                           double *__restrict__ csum, int *__restrict__ csize) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= K * dim) return;
+    const int j = e / dim;
+    double total = 0.0;
+    int count = 0;
+    for (int b = 0; b < n_blocks; b++) {
+        total = __dadd_rn(total, buf[(size_t)b * K * dim + e]);
+        count += (int)(seg[(size_t)b * K + j + 1] - seg[(size_t)b * K + j]);
+    }
+    csum[e] = total;
+    if (e == j * dim) csize[j] = count;
+}
+
+// the sum of a worker block's distances in point order (calc_belonging's distsqr_sum, kmeans.cc:85-106): a workgroup per
+// block stages the distances through LDS with coalesced loads, one thread adds them one after the other (a lone thread
+// walking global memory pays a cache-miss latency per addend: 8 ms per Lloyd step at 4 k points per block)
+constexpr int KM_BS_CHUNK = 4096;
+__global__ __launch_bounds__(256)
+void lloyd_block_sum_kernel(const double *__restrict__ dist, long n, long block, int n_blocks, double *__restrict__ bsum) {
+    __shared__ double stage[KM_BS_CHUNK];
+    const int b = blockIdx.x;
+    const long lo = (long)b * block, hi = min(n, lo + block);
+    double s = 0.0;
+    for (long c0 = lo; c0 < hi; c0 += KM_BS_CHUNK) {
+        const int m = (int)min((long)KM_BS_CHUNK, hi - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 256) stage[i] = dist[c0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < m; i++) s = __dadd_rn(s, stage[i]);
+    }
+    if (threadIdx.x == 0) bsum[b] = s;
+}
+
 void device_assign(long n, int dim, const std::vector<double> &C, int c_begin, int c_end,
-                   std::vector<double> &dist, std::vector<int> &belong, bool reset) {
+                   std::vector<double> &dist, std::vector<int> &belong, bool reset, bool download = true) {
     auto &w = kws();
     w.C.upload(C.data(), (size_t)c_end * dim);
     if (reset) {
@@ -155,10 +293,17 @@ void device_assign(long n, int dim, const std::vector<double> &C, int c_begin, i
         w.dist.upload(dist.data(), (size_t)n);
         w.belong.upload(belong.data(), (size_t)n);
     }
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(kmeans_assign_kernel, dim3(grid), dim3(256), (size_t)KM_CH * dim * sizeof(double), ctx().stream,
-                       w.X.p, n, dim, w.C.p, c_begin, c_end, w.dist.p, w.belong.p, reset ? 1 : 0);
+    const unsigned grid = (unsigned)((n + 256 * KM_PP - 1) / (256 * KM_PP));
+#define SR_KM_LAUNCH(DM)                                                                                                    \
+    hipLaunchKernelGGL(kmeans_assign_kernel<DM>, dim3(grid), dim3(256), 0, ctx().stream, w.X.p, n, dim, w.C.p, c_begin, c_end, \
+                       w.dist.p, w.belong.p, reset ? 1 : 0)
+    if (dim <= 16) SR_KM_LAUNCH(16);
+    else if (dim <= 40) SR_KM_LAUNCH(40);
+    else if (dim <= 64) SR_KM_LAUNCH(64);
+    else SR_KM_LAUNCH(128);
+#undef SR_KM_LAUNCH
     SR_HIP(hipGetLastError());
+    if (!download) return;                    // (Lloyd on the full data goes on with them on the device)
     w.dist.download(dist.data(), (size_t)n);
     w.belong.download(belong.data(), (size_t)n);
     sync_stream();
@@ -180,48 +325,53 @@ double blocked_sum(const std::vector<double> &v, long n, int concurrency) {
 
 // Lloyd on the full data (kmeans.cc:150-246).  centroids: [K][dim] in/out.
 void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::vector<double> &centroids, int verbosity) {
-    std::vector<double> best_centroids, dist((size_t)n);
-    std::vector<int> belong((size_t)n);
+    (void)X;                                   // (resident on the device: kws().X)
+    auto &w = kws();
+    std::vector<double> best_centroids, dummy_d;
+    std::vector<int> dummy_i;
     double best = std::numeric_limits<double>::max(), last = std::numeric_limits<double>::max();
     const long block = (long)std::ceil((double)n / concurrency);
     const int n_blocks = (int)((n + block - 1) / block);
-    std::vector<std::vector<double>> buf((size_t)n_blocks, std::vector<double>((size_t)K * dim));
-    std::vector<std::vector<int>> cnt((size_t)n_blocks, std::vector<int>((size_t)K));
+    if ((double)n_blocks * K >= 4.0e9 || n >= ((long)1 << 32)) fail("k-means: %d worker blocks x %d clusters x %ld points do not fit 32-bit sort keys", n_blocks, K, n);
+    const unsigned n_keys = (unsigned)n_blocks * (unsigned)K;
+    int end_bit = 1;
+    while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)n_keys) end_bit++;      // keys 0 .. n_keys inclusive
+    w.key_in.ensure((size_t)n);
+    w.key_out.ensure((size_t)n);
+    w.idx_in.ensure((size_t)n);
+    w.idx_out.ensure((size_t)n);
+    w.seg.ensure((size_t)n_keys + 2);
+    w.csum.ensure((size_t)K * dim);
+    w.csize.ensure((size_t)K);
+    w.bsum.ensure((size_t)n_blocks);
+    w.segsum.ensure((size_t)n_keys * dim);
+    size_t tmp_bytes = 0;
+    SR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (int)n, 0, end_bit, ctx().stream));
+    w.sort_tmp.ensure(tmp_bytes);
+    std::vector<double> csum((size_t)K * dim), bsum((size_t)n_blocks);
+    std::vector<int> csize((size_t)K);
     for (int iter = 0; iter < KM_MAX_ITER; iter++) {
-        device_assign(n, dim, centroids, 0, K, dist, belong, true);
-        // per worker block: sum of the distances and of the members, in point order (calc_belonging, kmeans.cc:72-107)
-        std::vector<double> block_sum((size_t)n_blocks, 0.0);
-        auto work = [&](int b) {
-            std::fill(buf[b].begin(), buf[b].end(), 0.0);
-            std::fill(cnt[b].begin(), cnt[b].end(), 0);
-            double s = 0;
-            const long e = std::min(n, (long)(b + 1) * block);
-            for (long i = (long)b * block; i < e; i++) {
-                const int j = belong[i];
-                if (j >= 0) {                    // a point no centre is comparable to (NaN centres) has none; the reference indexes [-1] there
-                    cnt[b][j] += 1;
-                    double *c = buf[b].data() + (size_t)j * dim;
-                    const float *x = X + (size_t)i * dim;
-                    for (int d = 0; d < dim; d++) c[d] += (double)x[d];
-                }
-                s += dist[i];
-            }
-            block_sum[b] = s;
-        };
-        {
-            // the blocks are independent; a few host threads share them (the reference runs one task per block)
-            const int n_threads = std::max(1, std::min({n_blocks, (int)std::thread::hardware_concurrency(), 16}));
-            auto run = [&](int t) { for (int b = t; b < n_blocks; b += n_threads) work(b); };
-            std::vector<std::thread> th;
-            if (n > 20000)
-                for (int t = 1; t < n_threads; t++) th.emplace_back(run, t);
-            else
-                for (int t = 1; t < n_threads; t++) run(t);          // small inputs: not worth a thread
-            run(0);
-            for (auto &t : th) t.join();
-        }
+        device_assign(n, dim, centroids, 0, K, dummy_d, dummy_i, true, false);
+        const unsigned g256 = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(lloyd_block_sum_kernel, dim3((unsigned)n_blocks), dim3(256), 0, ctx().stream, w.dist.p, n, block, n_blocks,
+                           w.bsum.p);
+        hipLaunchKernelGGL(lloyd_keys_kernel, dim3(g256), dim3(256), 0, ctx().stream, w.belong.p, n, block, K, n_keys, w.key_in.p, w.idx_in.p);
+        size_t tb = w.sort_tmp.n;
+        SR_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp.p, tb, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (int)n, 0, end_bit,
+                                                  ctx().stream));                            // stable: point order inside a key
+        hipLaunchKernelGGL(lloyd_segments_kernel, dim3((n_keys + 1 + 255) / 256), dim3(256), 0, ctx().stream, w.key_out.p, n, n_keys, w.seg.p);
+        const size_t n_seg_elems = (size_t)n_keys * dim;
+        hipLaunchKernelGGL(lloyd_segment_sum_kernel, dim3((unsigned)((n_seg_elems + 255) / 256)), dim3(256), 0, ctx().stream, w.X.p, dim,
+                           n_seg_elems, w.seg.p, w.idx_out.p, w.segsum.p);
+        hipLaunchKernelGGL(lloyd_centroid_kernel, dim3((unsigned)((K * dim + 255) / 256)), dim3(256), 0, ctx().stream, dim, K, n_blocks,
+                           w.seg.p, w.segsum.p, w.csum.p, w.csize.p);
+        SR_HIP(hipGetLastError());
+        w.bsum.download(bsum.data(), bsum.size());
+        w.csum.download(csum.data(), csum.size());
+        w.csize.download(csize.data(), csize.size());
+        sync_stream();
         double sum = 0;
-        for (int b = 0; b < n_blocks; b++) sum += block_sum[b];
+        for (int b = 0; b < n_blocks; b++) sum += bsum[b];
         if (sum < best) {
             best = sum;
             best_centroids = centroids;
@@ -229,14 +379,9 @@ void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::ve
         if (verbosity >= 2) printf("k-means iteration %3d: %f\n", iter, sum);
         if (std::fabs(last - sum) < 1e-6) break;
         if (sum > best * 1.5) break;                          // terminate_cost_factor
-        std::vector<double> size((size_t)K, 0.0);
-        for (int b = 0; b < n_blocks; b++)
-            for (int k = 0; k < K; k++) size[k] += cnt[b][k];
-        std::fill(centroids.begin(), centroids.end(), 0.0);
-        for (int b = 0; b < n_blocks; b++)
-            for (size_t e = 0; e < (size_t)K * dim; e++) centroids[e] += buf[b][e];
         for (int k = 0; k < K; k++)
-            for (int d = 0; d < dim; d++) centroids[(size_t)k * dim + d] /= size[k];      // an empty cluster divides by 0, as the reference
+            for (int d = 0; d < dim; d++)
+                centroids[(size_t)k * dim + d] = csum[(size_t)k * dim + d] / (double)csize[k];    // an empty cluster divides by 0, as the reference
         last = sum;
     }
     centroids = best_centroids;
@@ -289,7 +434,7 @@ void lloyd_weighted(const std::vector<double> &P, const std::vector<double> &wei
             block_sum[b] = s;
         };
         {
-            const int n_threads = std::max(1, std::min({n_blocks, (int)std::thread::hardware_concurrency(), 16}));
+            const int n_threads = std::max(1, std::min({n_blocks, (int)std::thread::hardware_concurrency(), 64}));
             auto run = [&](int t) { for (int b = t; b < n_blocks; b += n_threads) work(b); };
             std::vector<std::thread> th;
             if ((size_t)np * K * dim > ((size_t)1 << 22))
@@ -322,6 +467,8 @@ void lloyd_weighted(const std::vector<double> &P, const std::vector<double> &wei
 // KMeansIISolver::cluster (kmeansII.cc:82-171) with its defaults oversampling_factor = size_factor = 2.
 std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K, int concurrency, RandStream &rs, int verbosity) {
     const double oversampling_factor = 2.0, size_factor = 2.0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     RefRandom solver_random(rs());                            // KMeansIISolver::random (kmeansII.hh:41)
     std::vector<double> cand;                                 // candidate centres, [count][dim]
     auto push_point = [&](long i) {
@@ -347,6 +494,7 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
     }
     while ((double)(cand.size() / dim) <= size_factor * K) push_point(solver_random.rand_int((int)n));
     const int np = (int)(cand.size() / dim);
+    const double t_rounds = now();
     std::vector<double> weight((size_t)np, 0.0);
     for (long i = 0; i < n; i++) weight[belong[i]] += 1.0;
 
@@ -361,10 +509,24 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
     };
     copy_sparse(pp_random.rand_int() % np, 0);
     std::vector<double> pdist((size_t)np, std::numeric_limits<double>::max());
+    // the candidates' distance updates are independent of one another (only the blocked sum below has an order): a few host
+    // threads share them when the candidate set is large (2 K+ candidates x K centres x dim: 0.24 s on one thread at K = 2048)
+    const int pp_threads = (size_t)np * dim > ((size_t)1 << 16) ? std::max(1, std::min((int)std::thread::hardware_concurrency(), 16)) : 1;
     for (int k = 1; k < K; k++) {
         const double *c = centroids.data() + (size_t)(k - 1) * dim;
-        for (int i = 0; i < np; i++)
-            pdist[i] = std::min(pdist[i], sparse_distsqr(cand.data() + (size_t)i * dim, c, dim) * weight[i]);
+        auto upd = [&](int t) {
+            const int lo = (int)((long)np * t / pp_threads), hi = (int)((long)np * (t + 1) / pp_threads);
+            for (int i = lo; i < hi; i++)
+                pdist[i] = std::min(pdist[i], sparse_distsqr(cand.data() + (size_t)i * dim, c, dim) * weight[i]);
+        };
+        if (pp_threads > 1) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < pp_threads; t++) th.emplace_back(upd, t);
+            upd(0);
+            for (auto &t : th) t.join();
+        } else {
+            upd(0);
+        }
         const double distsqr_sum = blocked_sum(pdist, np, concurrency);
         double random_weight = pp_random.rand_int() / (double)RAND_MAX * distsqr_sum;
         for (int i = 0; i < np; i++) {
@@ -375,8 +537,13 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
             }
         }
     }
+    const double t_pp = now();
     lloyd_weighted(cand, weight, np, dim, K, concurrency, centroids);
+    const double t_lw = now();
     lloyd_full(X, n, dim, K, concurrency, centroids, verbosity);
+    if (verbosity >= 2)
+        printf("k-means|| phases: oversampling rounds %.3f s (%d candidates), weighted k-means++ %.3f s, weighted Lloyd %.3f s, "
+               "Lloyd on the full data %.3f s\n", t_rounds - t_start, np, t_pp - t_rounds, t_lw - t_pp, now() - t_lw);
     return centroids;
 }
 
