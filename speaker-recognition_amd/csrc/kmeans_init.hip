@@ -34,6 +34,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <climits>
@@ -509,24 +510,30 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
     };
     copy_sparse(pp_random.rand_int() % np, 0);
     std::vector<double> pdist((size_t)np, std::numeric_limits<double>::max());
-    // the candidates' distance updates are independent of one another (only the blocked sum below has an order): a few host
-    // threads share them when the candidate set is large (2 K+ candidates x K centres x dim: 0.24 s on one thread at K = 2048)
+    // The candidates' distance updates are independent of one another (only the blocked sum below has an order): when the
+    // candidate set is large (2 K+ candidates x K centres x dim: 0.24 s on one thread at K = 2048) a few host threads,
+    // started once and stepped through the K rounds by a pair of counters, share them.
     const int pp_threads = (size_t)np * dim > ((size_t)1 << 16) ? std::max(1, std::min((int)std::thread::hardware_concurrency(), 16)) : 1;
-    for (int k = 1; k < K; k++) {
+    std::atomic<int> round_go{0}, round_done{0};
+    auto upd = [&](int t, int k) {
         const double *c = centroids.data() + (size_t)(k - 1) * dim;
-        auto upd = [&](int t) {
-            const int lo = (int)((long)np * t / pp_threads), hi = (int)((long)np * (t + 1) / pp_threads);
-            for (int i = lo; i < hi; i++)
-                pdist[i] = std::min(pdist[i], sparse_distsqr(cand.data() + (size_t)i * dim, c, dim) * weight[i]);
-        };
-        if (pp_threads > 1) {
-            std::vector<std::thread> th;
-            for (int t = 1; t < pp_threads; t++) th.emplace_back(upd, t);
-            upd(0);
-            for (auto &t : th) t.join();
-        } else {
-            upd(0);
-        }
+        const int lo = (int)((long)np * t / pp_threads), hi = (int)((long)np * (t + 1) / pp_threads);
+        for (int i = lo; i < hi; i++)
+            pdist[i] = std::min(pdist[i], sparse_distsqr(cand.data() + (size_t)i * dim, c, dim) * weight[i]);
+    };
+    std::vector<std::thread> pp_workers;
+    for (int t = 1; t < pp_threads; t++)
+        pp_workers.emplace_back([&, t] {
+            for (int k = 1; k < K; k++) {
+                while (round_go.load(std::memory_order_acquire) < k) std::this_thread::yield();
+                upd(t, k);
+                round_done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    for (int k = 1; k < K; k++) {
+        round_go.store(k, std::memory_order_release);              // centroid k - 1 is in place
+        upd(0, k);
+        while (round_done.load(std::memory_order_acquire) < (pp_threads - 1) * k) std::this_thread::yield();
         const double distsqr_sum = blocked_sum(pdist, np, concurrency);
         double random_weight = pp_random.rand_int() / (double)RAND_MAX * distsqr_sum;
         for (int i = 0; i < np; i++) {
@@ -537,6 +544,7 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
             }
         }
     }
+    for (auto &t : pp_workers) t.join();
     const double t_pp = now();
     lloyd_weighted(cand, weight, np, dim, K, concurrency, centroids);
     const double t_lw = now();
