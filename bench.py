@@ -470,15 +470,23 @@ def block_multi_slot(_lib, ex, base):
     out = {"workload": "configs[1] (%d utterances x %d frames, 100 x 64 mixtures): sr_multi_predict_pcm from host PCM "
                        "(%.0f MB per call) vs the resident-PCM step" % (CFG1_UTTS, FRAMES_PER_UTT, cat.nbytes / 1e6),
            "resident_pcm_ms_per_step": 1e3 * el_res / 10}
-    for slots in (1, 2):
-        mp_ = MultiPredictor(gm, FS, n_slots=slots, **MFCC_KW)
-        f = lambda: mp_.predict_concat(cat, off, nd=ND)
-        f(); f()
-        el, (s2, a2) = timed(f, 0, 10)
-        out["slots_%d" % slots] = {"ms_per_call": 1e3 * el / 10, "over_resident": (el / 10) / (el_res / 10),
-                                   "argmax_equal": bool(np.array_equal(a2, arg)),
-                                   "sums_bit_identical": bool(np.array_equal(s2, sums)), "slot_seconds": [float(v) for v in mp_.slot_seconds]}
-        del mp_
+    for pinned in (False, True):
+        if pinned:
+            _lib.host_register(cat)            # what a serving loop does once with its PCM ring: the copy engines read it in place
+        for slots in (1, 2, 4):
+            mp_ = MultiPredictor(gm, FS, n_slots=slots, **MFCC_KW)
+            f = lambda: mp_.predict_concat(cat, off, nd=ND)
+            f(); f()
+            el, (s2, a2) = timed(f, 0, 10)
+            out["slots_%d_%s" % (slots, "caller_memory_page_locked" if pinned else "pageable_caller_memory")] = {
+                "ms_per_call": 1e3 * el / 10, "over_resident": (el / 10) / (el_res / 10), "argmax_equal": bool(np.array_equal(a2, arg)),
+                "sums_bit_identical": bool(np.array_equal(s2, sums)), "slot_seconds": [float(v) for v in mp_.slot_seconds]}
+            del mp_
+        if pinned:
+            _lib.host_unregister(cat)
+    out["pcie_floor_ms"] = cat.nbytes / 55e9 * 1e3
+    out["note"] = ("every call moves the PCM host -> device; a slot uploads and scores its utterances in 4 pieces, the copy of a piece "
+                   "under the scoring of the pieces before it; pcie_floor_ms = the PCM at 55 GB/s")
     return out
 
 
@@ -820,6 +828,8 @@ def main():
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
                          ("sr_multi_predict_pcm_2_slots", lambda: block_multi_slot(_lib, ex, base)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
+            if os.environ.get("SR_BENCH_BLOCKS") and name not in os.environ["SR_BENCH_BLOCKS"].split(","):
+                continue                                    # (experiments: a chosen subset of the blocks)
             try:
                 blocks[name] = fn()
             except Exception as e:                          # a secondary block must not take the headline down

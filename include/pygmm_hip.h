@@ -187,6 +187,10 @@ SRMulti *sr_multi_create(GMM *const *models, int n_models, double fs, double win
                          double win_shift_ms, int fft_size, int n_filters, int n_ceps,
                          double pre_emphasis, int n_slots);
 void sr_multi_free(SRMulti *m);
+/* Page-lock caller memory (hipHostRegister) -- a serving loop's PCM ring, say -- so that sr_multi_predict_pcm's copy
+ * engines read it in place instead of going through a staging buffer; sr_host_unregister before it is freed. */
+int sr_host_register(void *p, size_t bytes);
+int sr_host_unregister(void *p);
 int sr_multi_slots(SRMulti *m);
 int sr_multi_slot_device(SRMulti *m, int slot);
 int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_offsets, int n_utt,

@@ -30,7 +30,7 @@ EXT_SYMBOLS = [
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
     "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
-    "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats",
+    "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats", "sr_host_register", "sr_host_unregister",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -124,6 +124,8 @@ def lib():
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
         "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
+        "sr_host_register": (i32, [vp, C.c_size_t]),
+        "sr_host_unregister": (i32, [vp]),
         "sr_reference_rand_sample": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
         "sr_ltsd_num_windows": (i64, [i64, i32]),
         "sr_ltsd_noise_spectrum": (i32, [vp, i32, fp]),
@@ -215,6 +217,15 @@ def synchronize() -> None:
 
 def set_option(key: str, value: int) -> None:
     check(lib().sr_set_option(key.encode(), int(value)), "sr_set_option")
+
+
+def host_register(a) -> None:
+    """Page-lock a numpy array's memory so that the copy engines read it in place (sr_multi_predict_pcm)."""
+    check(lib().sr_host_register(C.c_void_p(a.ctypes.data), a.nbytes), "sr_host_register")
+
+
+def host_unregister(a) -> None:
+    check(lib().sr_host_unregister(C.c_void_p(a.ctypes.data)), "sr_host_unregister")
 
 
 def flush_stats():

@@ -88,6 +88,7 @@ void ensure_device() {
     g_ctx[d].n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].main, hipStreamNonBlocking));
     SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].aux, hipStreamNonBlocking));
+    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].copy, hipStreamNonBlocking));
     g_ctx[d].stream = g_ctx[d].main;
     g_ready[d] = true;
 }

@@ -56,6 +56,8 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // where launches go (normally `main`; StreamScope redirects)
     hipStream_t main = nullptr, aux = nullptr;
+    hipStream_t copy = nullptr;        // host -> device transfers that run under compute (multi.cpp): one per device, so that
+                                       // the transfers of the slots sharing a GPU are served in the order they were queued
     bool profiling = false;
     int n_cu = 256;
 };

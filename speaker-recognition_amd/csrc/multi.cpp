@@ -22,18 +22,27 @@
 #include "score.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <deque>
 #include <numeric>
 #include <thread>
 
 using namespace sr;
 
+constexpr int MULTI_CHUNKS = 4;         // a slot's utterances are uploaded and scored in this many pieces
+
 struct SRMulti {
+    struct Chunk {
+        std::unique_ptr<SRBatch> pcm;
+        PinnedBuf<int16_t> staging;         // only used when the caller's PCM is not page-locked
+        hipEvent_t uploaded = nullptr;
+        int u0 = 0, u1 = 0;                 // range of the slot's utterances
+    };
     struct Slot {
         int device = 0;
         std::unique_ptr<SRModelSet> set;
-        std::unique_ptr<SRBatch> pcm, feat;
-        std::vector<int16_t> host_pcm;      // this slot's utterances, concatenated
+        Chunk chunk[MULTI_CHUNKS];
         std::vector<int64_t> offsets;
         std::vector<int> utts;              // global utterance indices, in slot order
         std::vector<double> sums;
@@ -42,19 +51,35 @@ struct SRMulti {
         double seconds = 0.0;               // wall time of the slot's last pass
     };
     std::unique_ptr<SRMfcc> mfcc;           // host tables shared; device tables per GPU inside
-    std::vector<Slot> slots;
+    std::deque<Slot> slots;                // (a slot owns page-locked buffers and events: not movable)
     int n_models = 0;
 };
 
 namespace {
 
-// Longest-first greedy assignment by sample count (what shard.partition_utterances does in Python).
-void partition(const int64_t *off, int n_utt, std::vector<SRMulti::Slot> &slots) {
+// Utterances -> slots.  Many utterances that are small against a slot's share: contiguous ranges of about equal sample
+// counts, in the caller's order -- a slot's PCM is then ONE run of the caller's buffer and travels as a few large copies (dealt
+// round-robin, 1000 equal utterances over 2 slots were 1000 copies of 320 KB: 15 ms of copy calls for 6 ms of PCIe time).
+// Few or very uneven utterances: longest-first greedy by sample count (what shard.partition_utterances does in Python).
+void partition(const int64_t *off, int n_utt, std::deque<SRMulti::Slot> &slots) {
+    for (auto &s : slots) s.utts.clear();
+    if (n_utt == 0) return;
+    const int64_t total = off[n_utt];
+    int64_t longest = 0;
+    for (int u = 0; u < n_utt; u++) longest = std::max(longest, off[u + 1] - off[u]);
+    const size_t ns = slots.size();
+    if (longest * 8 * (int64_t)ns <= total) {
+        int u = 0;
+        for (size_t k = 0; k < ns; k++) {
+            const int64_t hi = total * (int64_t)(k + 1) / (int64_t)ns;
+            while (u < n_utt && (k + 1 == ns || off[u + 1] <= hi)) slots[k].utts.push_back(u++);
+        }
+        return;
+    }
     std::vector<int> order(n_utt);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return off[a + 1] - off[a] > off[b + 1] - off[b]; });
-    std::vector<int64_t> load(slots.size(), 0);
-    for (auto &s : slots) s.utts.clear();
+    std::vector<int64_t> load(ns, 0);
     for (int u : order) {
         const size_t k = std::min_element(load.begin(), load.end()) - load.begin();
         slots[k].utts.push_back(u);
@@ -63,37 +88,104 @@ void partition(const int64_t *off, int n_utt, std::vector<SRMulti::Slot> &slots)
     for (auto &s : slots) std::sort(s.utts.begin(), s.utts.end());
 }
 
-void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *off, int nd, int flags) {
+// true when [p, p + bytes) is page-locked host memory the copy engines can read directly (hipHostMalloc / hipHostRegister
+// / sr_host_register): then the slots DMA straight out of the caller's buffer
+bool host_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();           // (an ordinary malloc pointer is "invalid value" to the runtime: not an error here)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// One slot: its utterances cut into MULTI_CHUNKS pieces of whole utterances; every piece goes host -> device on the
+// device's copy stream (queued in order: piece 0 first, and behind the pieces of the slots that queued earlier) while the
+// pieces before it are being scored on the main stream -- PCM from pageable caller memory passes through a page-locked
+// staging buffer filled by this thread, one piece ahead of the copy engine; page-locked caller memory is read in place.
+// Scoring takes the device's lock piece by piece, so slots that share a GPU interleave.  (Round 2 copied the whole
+// slot into a std::vector, uploaded it from pageable memory and synchronised before the first kernel: 4.8x the
+// resident-PCM step on the configs[1] workload.)
+void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *off, int nd, int flags, bool pinned) {
     try {
         set_thread_device(s.device);
-        std::lock_guard<std::recursive_mutex> lock(api_mutex());
         ensure_device();
         const auto t0 = std::chrono::steady_clock::now();
         const int U = (int)s.utts.size();
         s.offsets.assign(U + 1, 0);
         for (int i = 0; i < U; i++) s.offsets[i + 1] = s.offsets[i] + (off[s.utts[i] + 1] - off[s.utts[i]]);
-        s.host_pcm.resize((size_t)s.offsets[U]);
-        for (int i = 0; i < U; i++)
-            std::memcpy(s.host_pcm.data() + s.offsets[i], pcm + off[s.utts[i]],
-                        sizeof(int16_t) * (size_t)(s.offsets[i + 1] - s.offsets[i]));
-        if (!s.pcm) s.pcm = std::make_unique<SRBatch>();
-        if (!s.feat) s.feat = std::make_unique<SRBatch>();
-        SRBatch &b = *s.pcm;
-        b.bind_device();
-        b.kind = SRBatch::PCM16;
-        b.n_utt = U;
-        b.offsets = s.offsets;
-        b.n_rows = s.offsets[U];
-        b.tile_tables.clear();
-        b.pcm16.upload(s.host_pcm.data(), s.host_pcm.size());
-        b.d_offsets.upload(b.offsets.data(), b.offsets.size());
-        sync_stream();
         s.sums.assign((size_t)U * m->n_models, 0.0);
         s.argmax.assign((size_t)U, -1);
-        if (U > 0) predict_pcm(m->mfcc.get(), s.set.get(), &b, nd, s.sums.data(), s.argmax.data(), flags);
+        // piece boundaries: whole utterances, about equal sample counts
+        const int n_chunks = std::max(1, std::min(MULTI_CHUNKS, U));
+        for (int c = 0; c < MULTI_CHUNKS; c++) {
+            auto &ch = s.chunk[c];
+            ch.u0 = ch.u1 = 0;
+            if (c >= n_chunks) continue;
+            const int64_t lo = s.offsets[U] * c / n_chunks, hi = s.offsets[U] * (c + 1) / n_chunks;
+            ch.u0 = c == 0 ? 0 : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), lo) - s.offsets.begin());
+            ch.u1 = c == n_chunks - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
+            ch.u0 = std::min(ch.u0, U);
+            ch.u1 = std::max(ch.u0, std::min(ch.u1, U));
+        }
+        for (int c = 1; c < n_chunks; c++) s.chunk[c].u0 = s.chunk[c - 1].u1;      // contiguous cover
+        // ---- upload: every piece queued on the copy stream, an event behind it
+        for (int c = 0; c < n_chunks; c++) {
+            auto &ch = s.chunk[c];
+            if (!ch.pcm) ch.pcm = std::make_unique<SRBatch>();
+            if (!ch.uploaded) SR_HIP(hipEventCreateWithFlags(&ch.uploaded, hipEventDisableTiming));
+            SRBatch &b = *ch.pcm;
+            const int nu = ch.u1 - ch.u0;
+            const int64_t base = s.offsets[ch.u0], n_samp = s.offsets[ch.u1] - base;
+            {
+                std::lock_guard<std::recursive_mutex> lock(api_mutex());   // (the batch's buffers may be reallocated: not under a kernel)
+                b.bind_device();
+                std::vector<int64_t> po((size_t)nu + 1, 0);
+                for (int i = 0; i <= nu; i++) po[i] = s.offsets[ch.u0 + i] - base;
+                if (b.kind != SRBatch::PCM16 || b.offsets != po || !b.d_offsets.p) {   // a serving loop repeats its shape: nothing to redo
+                    b.kind = SRBatch::PCM16;
+                    b.n_utt = nu;
+                    b.offsets = po;
+                    b.n_rows = n_samp;
+                    b.tile_tables.clear();
+                    b.pcm16.ensure((size_t)std::max<int64_t>(1, n_samp));
+                    b.d_offsets.upload(b.offsets.data(), b.offsets.size());
+                    sync_stream();
+                }
+            }
+            if (!pinned) ch.staging.ensure((size_t)std::max<int64_t>(1, n_samp));
+            // runs of utterances that are neighbours in the caller's buffer travel as one copy
+            int i = ch.u0;
+            while (i < ch.u1) {
+                int j = i;
+                while (j + 1 < ch.u1 && s.utts[j + 1] == s.utts[j] + 1) j++;
+                const int64_t src0 = off[s.utts[i]], n = off[s.utts[j] + 1] - src0, dst0 = s.offsets[i] - base;
+                if (n > 0) {
+                    const int16_t *src = pcm + src0;
+                    if (!pinned) {
+                        std::memcpy(ch.staging.p + dst0, src, sizeof(int16_t) * (size_t)n);
+                        src = ch.staging.p + dst0;
+                    }
+                    SR_HIP(hipMemcpyAsync(b.pcm16.p + dst0, src, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice, ctx().copy));
+                }
+                i = j + 1;
+            }
+            SR_HIP(hipEventRecord(ch.uploaded, ctx().copy));
+        }
+        // ---- score: piece by piece, each as soon as it has arrived
+        for (int c = 0; c < n_chunks; c++) {
+            auto &ch = s.chunk[c];
+            const int nu = ch.u1 - ch.u0;
+            if (nu == 0) continue;
+            std::lock_guard<std::recursive_mutex> lock(api_mutex());
+            SR_HIP(hipStreamWaitEvent(ctx().stream, ch.uploaded, 0));
+            predict_pcm(m->mfcc.get(), s.set.get(), ch.pcm.get(), nd, s.sums.data() + (size_t)ch.u0 * m->n_models,
+                        s.argmax.data() + ch.u0, flags);
+        }
         s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } catch (const std::exception &e) {
         s.error = e.what();
+        (void)hipStreamSynchronize(ctx().copy);        // nothing of this call may still be reading the caller's buffer
     } catch (...) {
         s.error = "unknown C++ exception";
     }
@@ -158,13 +250,39 @@ void sr_multi_free(SRMulti *m) {
             std::lock_guard<std::recursive_mutex> lock(api_mutex());
             (void)hipSetDevice(s.device);
             s.set.reset();
-            s.pcm.reset();
-            s.feat.reset();
+            for (auto &ch : s.chunk) {
+                ch.pcm.reset();
+                if (ch.uploaded) (void)hipEventDestroy(ch.uploaded);
+                ch.uploaded = nullptr;
+            }
         } catch (...) {
         }
     }
     try { set_thread_device(prev); } catch (...) {}
     delete m;
+}
+
+// Page-locks caller memory (a serving loop's PCM ring, say) so that sr_multi_predict_pcm's copy engines read it in place.
+int sr_host_register(void *p, size_t bytes) {
+    try {
+        ensure_device();
+        if (!p || bytes == 0) fail("bad arguments to sr_host_register");
+        SR_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+        return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+int sr_host_unregister(void *p) {
+    try {
+        ensure_device();
+        SR_HIP(hipHostUnregister(p));
+        return 0;
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
 }
 
 int sr_multi_slots(SRMulti *m) { return m ? (int)m->slots.size() : 0; }
@@ -181,10 +299,12 @@ int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_o
             if (sample_offsets[u + 1] < sample_offsets[u]) fail("sample_offsets must be non-decreasing");
         if (sample_offsets[n_utt] > 0 && !pcm) fail("null PCM pointer");
         partition(sample_offsets, n_utt, m->slots);
+        const bool pinned = sample_offsets[n_utt] > 0 && host_pinned(pcm) &&
+                            host_pinned(pcm + sample_offsets[n_utt] - 1);
         std::vector<std::thread> th;
         for (auto &s : m->slots) {
             s.error.clear();
-            th.emplace_back(run_slot, m, std::ref(s), pcm, sample_offsets, nd, flags);
+            th.emplace_back(run_slot, m, std::ref(s), pcm, sample_offsets, nd, flags, pinned);
         }
         for (auto &t : th) t.join();
         for (auto &s : m->slots)
