@@ -133,11 +133,18 @@ __host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) 
     return waves == 4 ? 2 : 4;
 }
 
+// BQ_LDS (round 3): the wave's quadratic-half B fragments -- used once per 15 models, 8 x 16 bytes per lane at D = 39 -- live in
+// LDS (dynamic, WAVES x KQF KiB) instead of the registers they never fitted: in round 2 the compiler kept them in scratch
+// (344 bytes per lane with the prologue's temporaries: 7 GB of scratch writes per configs[2] pass, profiles/r02b_pmc.txt).
+// Taken for the 12-wave shape (one workgroup per CU: the LDS is there); the 4-wave shape shares a CU's LDS three ways.
+// Same speed as the scratch form to 0.5 % (profiles/r03_scoring_experiments.txt), bit-identical results, 142 VGPRs, no scratch.
 template <int KQF, int KLF, int COLS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, h2s_waves_per_eu(KQF, KLF, COLS, WAVES))
 void gmm_score_h2s_kernel(const H2sArgs a) {
     constexpr int SB = SHARED_SB;
-    constexpr int G = h2s_stage_images(KQF, KLF, WAVES);
+    constexpr bool BQ_LDS = WAVES > 4;
+    constexpr int G = BQ_LDS ? 2 : h2s_stage_images(KQF, KLF, WAVES);      // (2 images per stage measured the same as 4)
+    extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64] when BQ_LDS
     constexpr int TILES_WG = WAVES * COLS;                     // 32-frame tiles per workgroup
     constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
     constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;          // every image padded to the larger of the two
@@ -202,6 +209,11 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         valid[c] = has[c] && col < tile.count;
         row[c] = tile.start + (valid[c] ? col : 0);
         h2s_build_b<KQF>(bq[c], a.X + row[c] * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
+        if constexpr (BQ_LDS) {
+            static_assert(COLS == 1, "one column tile per wave");
+#pragma unroll
+            for (int ks = 0; ks < KQF; ks++) h2s_bq_lds[(wave * KQF + ks) * 64 + lane] = __builtin_bit_cast(uint4, bq[c][ks]);
+        }
         h2s_build_b<KLF>(bl[c], a.X + row[c] * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
         off[c] = a.ref_ll[row[c]] * H2S_LOG2E;
     }
@@ -259,9 +271,17 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                 for (int gi = 0; gi < G; gi++) {
                     const int img = st * G + gi;
                     f32x16 acc[COLS];
-                    if (img == 0)
-                        h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bq);
-                    else
+                    if (img == 0) {
+                        if constexpr (BQ_LDS) {
+                            f16x8 bqt[COLS][KQF];                 // this wave's own slab: written once in the prologue (same lanes)
+#pragma unroll
+                            for (int ks = 0; ks < KQF; ks++)
+                                bqt[0][ks] = __builtin_bit_cast(f16x8, h2s_bq_lds[(wave * KQF + ks) * 64 + lane]);
+                            h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bqt);
+                        } else {
+                            h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bq);
+                        }
+                    } else
                         h2s_chain_regs<KLF, KM, COLS>(acc, qacc, fr, bl);
                     __builtin_amdgcn_sched_barrier(0);
                     if (gi == G - 1) {
@@ -430,6 +450,7 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 
 template <int KQF, int KLF, int COLS, int WAVES>
 static int launch_h2s(const H2sLaunch &l) {
+    constexpr bool BQ_LDS = WAVES > 4;
     H2sArgs a;
     a.X = l.X;
     a.tiles = l.tiles;
@@ -472,7 +493,16 @@ static int launch_h2s(const H2sLaunch &l) {
         a.tile_base = base * TILES_WG;
         const int n = std::min(wg_per_launch, n_wg - base);
         dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
-        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
+        constexpr size_t dyn = BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0;
+        if constexpr (BQ_LDS) {
+            static bool attr_set[MAX_DEVICES] = {};
+            if (!attr_set[ctx().device]) {
+                SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                attr_set[ctx().device] = true;
+            }
+        }
+        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
     }
     a.tile_base = 0;
     // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
