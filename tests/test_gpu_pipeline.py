@@ -234,6 +234,58 @@ def test_train_from_scratch_vs_reference_trainer_golden(built_lib, tmp_path):
         assert np.max(np.abs(got.sigma - g[name + "_sigma"]) / g[name + "_sigma"]) < 1e-3, name
 
 
+def test_kmeans_initialiser_on_the_device_equals_its_restatement(built_lib):
+    """k-means|| + weighted k-means++ + Lloyd with the nearest-centre pass and (round 3) the cluster sums of every Lloyd
+    step on the device: a stable sort of the points by (worker block, cluster), sequential segment sums, block-ordered
+    totals -- the additions the reference makes (kmeans.cc:72-107, :189-212).  Against the independent numpy
+    restatement of the same initialiser and random streams (oracle/init_oracle.py, pinned on the reference trainer's
+    goldens) with MANY worker blocks of odd sizes and clusters that are empty in most of them; float64 on both sides,
+    same order: the centres agree to rounding."""
+    from oracle import init_oracle as io
+    from speaker_recognition_amd.pygmm import GMM
+    rng = np.random.default_rng(3)
+    for n, K, D, conc, seed in ((30011, 96, 13, 37, 11), (9001, 40, 39, 64, 5), (5000, 8, 20, 3, 2)):
+        cent = rng.normal(0, 3, (K, D))
+        X = (cent[rng.integers(0, K, n)] + rng.normal(0, 1, (n, D))).astype(np.float32)
+        g = GMM(nr_mixture=K, nr_iteration=0, init_with_kmeans=1, seed=seed, concurrency=conc)
+        g.fit(X)
+        w, mu, sg = g.params()
+        w0, mu0, sg0 = io.init_gaussians(X.astype(np.float64), K, 1, conc, io.GlibcRand(seed + 1))
+        assert np.max(np.abs(mu - mu0)) < 1e-9 * max(1.0, np.max(np.abs(mu0))), (n, K, D, np.max(np.abs(mu - mu0)))
+        assert np.max(np.abs(sg - sg0) / sg0) < 1e-12 and np.allclose(w, w0, atol=0)
+
+
+def test_em_statistics_engines_vs_oracle(built_lib, oracle_built):
+    """One EM iteration from identical starting parameters through both statistics engines -- the fp64 matrix cores
+    (em_stats_mfma_kernel: sums about the origin from fp32-exact operands, re-centred in the float64 M-step; dims <= 40)
+    and the vector ALU (em_stats_kernel: per-mixture centring, fp32 slabs; every dim) -- against the float64 oracle, on
+    data FAR FROM THE ORIGIN (where sums about the origin cancel the most): both inside the gate, the float64 accumulation
+    at least as close as the fp32 one."""
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(8)
+    try:
+        for n, K, D in ((20000, 40, 13), (12000, 70, 39), (6000, 17, 26)):
+            cent = 30.0 + rng.normal(0, 2, (K, D))
+            X = (cent[rng.integers(0, K, n)] + rng.normal(0, 0.7, (n, D))).astype(np.float32)
+            r6 = np.vectorize(lambda v: float("%g" % v))
+            start = go.GMMParams(np.full(K, 1.0 / K), r6(cent + 0.2 * rng.standard_normal(cent.shape)), np.full((K, D), 0.9))
+            want = go.em_iteration(start, X.astype(np.float64))
+            err = {}
+            for eng in (1, 0):
+                _lib.set_option("em_stats_engine", eng)
+                g = GMM.from_arrays(start.weights, start.mean, start.sigma)
+                g.nr_iteration, g.init_with_kmeans = 1, -1            # -1: warm start (extension)
+                assert g.fit(X) == 1
+                w, mu, sg = g.params()
+                err[eng] = (np.max(np.abs(w - want.weights)), np.max(np.abs(mu - want.mean)), np.max(np.abs(sg - want.sigma) / want.sigma))
+                assert err[eng][0] < 1e-5 and err[eng][1] < 1e-4 and err[eng][2] < 1e-3, (n, K, D, eng, err[eng])
+            assert err[0][2] <= err[1][2] + 1e-6 and err[0][1] <= err[1][1] + 1e-6, (n, K, D, err)
+    finally:
+        _lib.set_option("em_stats_engine", 0)
+
+
 def test_serving_stream_double_buffered_equals_synchronous(built_lib):
     """sr_stream_*: ticks submitted two deep (H2D of tick i+1 on its own HIP stream while tick i
     computes) return exactly what the synchronous fused step returns for the same windows, with
