@@ -306,9 +306,10 @@ void gmm_merge_kernel(const float *__restrict__ A, const float *__restrict__ B, 
         if (valid) {
             const float a = A[(int64_t)s * n_frames + row], b = B[(int64_t)s * n_frames + row];
             float ll;
-            const bool sa = clamp && a == LSE_LN_1E_15, sb = clamp && b == LSE_LN_1E_15;
+            // with the clamp on, a half whose terms all underflowed reports -inf (lse.hpp, clamp 2): out of band
+            const bool sa = clamp && a == -INFINITY, sb = clamp && b == -INFINITY;
             if (sa || sb) {
-                ll = sa ? b : a;                      // (both: ln 1e-15)
+                ll = sa ? (sb ? LSE_LN_1E_15 : b) : a;        // (both: the reference's ln 1e-15)
             } else {
                 const float hi = fmaxf(a, b), lo = fminf(a, b);
                 ll = hi + LSE_LN2 * log2f(1.0f + __builtin_amdgcn_exp2f((lo - hi) * 1.4426950408889634f));
@@ -740,6 +741,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     auto &w = ws();
     bool used_oor = false;
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
+    // 0 off, 1 the reference's clamp, 2 the same with "all terms underflowed" reported as -inf (a half of a hybrid set)
+    const int clamp_mode = (flags & 1) ? ((flags & SCORE_NO_FLUSH) ? 2 : 1) : 0;
     if (frame_ll_dst) want_frame_ll = true;
     w.sums.ensure((size_t)std::max(1, U) * S);
     w.argmax.ensure((size_t)std::max(1, U));
@@ -839,7 +842,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.dim = feat.dim;
             a.n_models = S;
             a.n_mix_tiles = h.n_tiles;
-            a.clamp = (flags & 1) ? 1 : 0;
+            a.clamp = clamp_mode;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
             a.log2_k = (float)std::log2((double)h.n_tiles * MT);
@@ -870,7 +873,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.dim = feat.dim;
             a.n_models = S;
             a.n_mix_tiles = set.shared.n_tiles;
-            a.clamp = (flags & 1) ? 1 : 0;
+            a.clamp = clamp_mode;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
             a.band_hi = fp.band_hi;
@@ -902,7 +905,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;
-            a.clamp = (flags & 1) ? 1 : 0;
+            a.clamp = clamp_mode;
             a.n_groups = G;
             a.n_tiles = tt.n_tiles;
             a.band_hi = fp.band_hi;
@@ -932,7 +935,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;
-            a.clamp = (flags & 1) ? 1 : 0;
+            a.clamp = clamp_mode;
             a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
                      (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");

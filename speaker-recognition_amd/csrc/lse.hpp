@@ -84,13 +84,15 @@ __device__ __forceinline__ float lse_close2(float m, float ssum, float om, float
         b = om >= LSE_MINLOG2 ? b : 0.0f;
     }
     float ll = LSE_LN2 * (mn + log2f(a + b));
-    if (clamp && mn < LSE_MINLOG2) ll = LSE_LN_1E_15;
+    // clamp 2 (the two halves of a hybrid set, merged afterwards): "every term underflowed" is reported out of band, as
+    // -inf -- a genuine value that happens to round to ln 1e-15 must not be mistaken for it
+    if (clamp && mn < LSE_MINLOG2) ll = clamp == 2 ? -__builtin_inff() : LSE_LN_1E_15;
     return ll;
 }
 
 __device__ __forceinline__ float lse_close1(float m, float ssum, int clamp) {
     float ll = LSE_LN2 * (m + log2f(ssum));
-    if (clamp && m < LSE_MINLOG2) ll = LSE_LN_1E_15;
+    if (clamp && m < LSE_MINLOG2) ll = clamp == 2 ? -__builtin_inff() : LSE_LN_1E_15;
     return ll;
 }
 

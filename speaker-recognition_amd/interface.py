@@ -100,7 +100,14 @@ class ModelInterface(object):
                 all(np.asarray(sig).dtype == np.int16 and np.asarray(sig).ndim == 1 for _, sig in items):
             from .core import MultiPredictor
             kw = dict(self.feature_kwargs)
-            mp = MultiPredictor(self.gmmset.gmms, rates.pop(), n_slots=int(gpus), **kw)
+            fs = rates.pop()
+            # the per-GPU model replicas are packed and uploaded once and kept until the model set changes (re-training
+            # replaces the GMM objects), not rebuilt on every call
+            key = (tuple(id(g) for g in self.gmmset.gmms), fs, int(gpus), tuple(sorted(kw.items())))
+            cached = getattr(self, "_multi", None)
+            if cached is None or cached[0] != key:
+                cached = self._multi = (key, MultiPredictor(self.gmmset.gmms, fs, n_slots=int(gpus), **kw))
+            mp = cached[1]
             _, winners = mp.predict([sig for _, sig in items], nd=self.nd if self.diff else 0)
             return [None if w < 0 else self.gmmset.y[w] for w in winners]
         feats = [self._features(fs, sig) for fs, sig in items]
@@ -109,9 +116,13 @@ class ModelInterface(object):
     def dump(self, fname):
         """ dump all models to file"""
         self.gmmset.before_pickle()
-        with open(fname, "wb") as f:
-            pickle.dump(self, f, -1)
-        self.gmmset.after_pickle()
+        multi, self._multi = getattr(self, "_multi", None), None        # (device handles do not pickle)
+        try:
+            with open(fname, "wb") as f:
+                pickle.dump(self, f, -1)
+        finally:
+            self._multi = multi
+            self.gmmset.after_pickle()
 
     @staticmethod
     def load(fname):
