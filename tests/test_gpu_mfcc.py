@@ -26,7 +26,10 @@ def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden, generic):
         assert np.max(np.abs(raw - ref_raw)) < 2e-4 * max(1.0, np.abs(ref_raw).max()), (c, np.max(np.abs(raw - ref_raw)))
         feat = MFCC.extract(fs, pcm, **kw)
         assert np.max(np.abs(feat - m[c + "_feat"])) < 1e-3, (c, np.max(np.abs(feat - m[c + "_feat"])))
-        assert np.mean(np.abs(feat - m[c + "_feat"])) < 1e-5 * 10, c
+        # SURVEY.md 8d's gate on the mean: 1e-5.  Measured (scripts/debug/mfcc_error.py, round 3): 5.8e-6 .. 9.3e-6 over the five
+        # golden cases and both FFT kernels (max 1.2e-4); with both deltas appended (39 dims, the bench audio) 1.1e-5 .. 1.4e-5 --
+        # a second difference carries up to four times the error of its three terms
+        assert np.mean(np.abs(feat - m[c + "_feat"])) < 1e-5, (c, np.mean(np.abs(feat - m[c + "_feat"])))
         d1 = MFCC.extract((fs, pcm), diff=True, **kw)                 # tuple form, MFCC.py:125-127
         d2 = MFCC.extract(fs, pcm, diff=True, nd=2, **kw)
         assert d1.shape == m[c + "_d1"].shape and d2.shape == m[c + "_d2"].shape
