@@ -672,6 +672,7 @@ def main():
     for _ in range(args.warmup):
         step()
     _lib.profile_reset()           # timed region starts with zeroed timers
+    fl0 = _lib.flush_stats()
     barrier()
     t0 = time.perf_counter()
     prev = None
@@ -692,6 +693,7 @@ def main():
         rates = [rank_rate]
     kt = kernel_times(_lib, args.steps)
     kname = _lib.last_score_kernel()
+    fl1 = _lib.flush_stats()
     # ---- N > 1: north_star's configs[3] split -- the N ranks share the 100 M frames (strong scaling), every rank with
     #      the whole 2048-mixture UBM + 1000 speakers; wall time = the slowest rank's
     strong = None
@@ -759,6 +761,10 @@ def main():
                                      "predict_chunks): built for overlap, measures slower than one pass (the feature kernels starve next to "
                                      "the scoring kernel), so it is off by default"},
         "hbm_copy_ceiling_GBps": hbm,
+        # frames whose log-likelihood sits where the reference's flushes of PARTIAL products decide: noted by the
+        # engine per (32-frame tile, model), re-evaluated with the reference's own arithmetic inside the timed step (csrc/gmm_flush.hip)
+        "partial_product_path_per_step": {"tile_model_pairs": (fl1[1] - fl0[1]) / max(1, args.steps),
+                                          "frames_re_evaluated": (fl1[2] - fl0[2]) / max(1, args.steps)},
         "device": _lib.device_name(),
         "model_set": ms.info(),
         "parity": {"all_sums_finite": bool(np.all(np.isfinite(sums))),

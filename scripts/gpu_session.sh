@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 TAG=$1; shift
 T=${STAGE_TIMEOUT:-600}
-DEF_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-config-blocks"
+DEF_ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-config-blocks --no-traffic"
 for st in "$@"; do
   name=${st%%=*}; arg=""; [ "$st" != "$name" ] && arg=${st#*=}
   echo "=== [$TAG] $name $arg"

@@ -135,7 +135,7 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
 // and receives D[mixture (l >> 4) + 4 r][column l & 15], r = 0..3 (the f64 layout, NOT the f32 one).
 //
 // A workgroup = 4 waves on ONE 64-frame tile at a time and 64 mixtures (16 per wave) for its whole life: the 16
-// parameter records sit in LDS from the start; the tile's raw rows arrive transposed ([d][frame], stride 68: conflict-free
+// parameter records sit in LDS from the start; the tile's raw rows arrive transposed ([d][frame], stride 130: conflict-free
 // for both access patterns below) by LDS-DMA one tile ahead.  Per tile a wave (lane = frame) evaluates its 16 mixtures'
 // responsibilities in the 2-FMA form of the scoring kernel (same arithmetic as before), passes them through LDS into
 // the A layout, and issues 16 frame groups x NCB column blocks of MFMAs into NCB x 4 float64 accumulators that live in
@@ -146,7 +146,10 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int EMM_WAVES = 4, EMM_MB = 16, EMM_WG_MIX = EMM_WAVES * EMM_MB;
 constexpr int EMM_F = 2;                       // frames per lane in the responsibility phase: a parameter read serves both
 constexpr int EMM_FT = 64 * EMM_F;             // frames per tile
-constexpr int EMM_XS = EMM_FT + 4, EMM_GS = EMM_FT + 4;   // row strides = 4 mod 64: both access patterns conflict-free
+// Row strides = 2 mod 32.  The operand reads are ds_read_b32: two 32-lane groups, bank = dword address mod 32; a group holds
+// (mixture or column j = 0..15) x (frame fl = 0..1 or 2..3) at j * stride + fl + const, i.e. banks 2 j + fl: all different.
+// (Stride 4 mod 64 -- the ds_read_b64 / b128 bank map -- made j and j + 8 collide: SQ_LDS_BANK_CONFLICT 55 % of the LDS cycles.)
+constexpr int EMM_XS = EMM_FT + 2, EMM_GS = EMM_FT + 2;
 __host__ __device__ constexpr int emm_ncb(int dp) { return 2 * (dp / 16) + (2 * (dp % 16) + 1 + 15) / 16; }
 
 template <int DP>
