@@ -766,6 +766,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_h2s_shape") {
         if (value < 0 || value > 2) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups) or 2 (12-wave workgroups)");
         score_options().h2s_shape = (int)value;
+    } else if (k == "flush_list_cap") {
+        if (value < 0) fail("flush_list_cap must be >= 0");
+        score_options().flush_list_cap = (int)value;
     } else if (k == "score_h2s_force_exc") {
         score_options().h2s_force_exc = value != 0;
     } else if (k == "score_mfma_ft") {

@@ -370,13 +370,14 @@ static FlushPass prepare_flush(const SRModelSet &set, int n_tiles, int flags) {
     auto &w = ws();
     const size_t pairs = (size_t)std::max(1, n_tiles) * (size_t)set.host.n_models;
     size_t cap = std::min<size_t>(pairs, (size_t)1 << 20);
+    if (score_options().flush_list_cap > 0) cap = (size_t)score_options().flush_list_cap;     // (testing the overflow path)
     cap = std::min<size_t>(std::max(cap, w.flush_min_cap), 0x7fffffff);
     w.flush_list.ensure(cap);
     w.flush_count.ensure(1);
     SR_HIP(hipMemsetAsync(w.flush_count.p, 0, sizeof(int), ctx().stream));
     fp.list = w.flush_list.p;
     fp.count = w.flush_count.p;
-    fp.cap = (int)std::min<size_t>(w.flush_list.n, 0x7fffffff);
+    fp.cap = (int)std::min<size_t>(score_options().flush_list_cap > 0 ? cap : w.flush_list.n, 0x7fffffff);
     fp.band_hi = (float)(-708.396418532264 + set.host.flush_band);
     return fp;
 }
@@ -1061,6 +1062,9 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
         if (n_flush > r.flush_cap) {
             // more pairs than the list holds (the counter kept counting): the pass again with a list of that length
             ws().flush_min_cap = (size_t)n_flush;
+            struct Reset {                      // the enlarged list is for this batch only
+                ~Reset() { ws().flush_min_cap = 0; }
+            } reset_after;
             const bool own = r.d_frame_ll && r.d_frame_ll != ws().frame_ll.p;
             r = score_device(set, feat, r.d_frame_ll != nullptr, flags, own ? const_cast<float *>(r.d_frame_ll) : nullptr);
             SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));

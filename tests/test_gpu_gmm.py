@@ -28,6 +28,7 @@ def _reset_options(built_lib):
               "score_h2s_force_exc", "score_h2s_shape"):
         _lib.set_option(k, 0)
     _lib.set_option("flush_order", 2)
+    _lib.set_option("flush_list_cap", 0)
 
 
 def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
@@ -601,6 +602,33 @@ def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_b
     assert np.array_equal(fll[0] == floor32, cl)
     assert ll_close(fll[0][~cl], want[~cl]) < TOL
     assert abs(sums[0, 0] - want.sum()) < TOL * abs(want.sum())
+
+
+def test_partial_product_band_list_overflow(built_lib, flush_golden):
+    """The list of (tile, model) pairs a pass notes for the partial-product path has a capacity; a pass that notes more keeps
+    counting, and the results are fetched from a second pass with a list of the counted length.  Forced here with a
+    capacity of 1 (`flush_list_cap`): values, sums and argmax equal the default path's, bit for bit."""
+    from conftest import flush_models
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    g = flush_golden
+    for c in ("d39_k8", "d39_ubm64"):
+        X = g[c + "_X"]
+        ms = ModelSet([GMM.from_arrays(*m) for m in flush_models(g, c)])
+        utts = [X[:50], X[50:51], X[51:]]
+        for eng in (1, 0):
+            _lib.set_option("score_engine", eng)
+            _lib.set_option("flush_list_cap", 0)
+            s0, a0, f0 = ms.score(Batch.from_features(utts), frame_ll=True)
+            calls0 = _lib.flush_stats()[0]
+            _lib.set_option("flush_list_cap", 1)
+            s1, a1, f1 = ms.score(Batch.from_features(utts), frame_ll=True)
+            s2, a2 = ms.score(Batch.from_features(utts))
+            assert _lib.flush_stats()[0] >= calls0 + 2
+            assert np.array_equal(f0, f1) and np.array_equal(s0, s1) and np.array_equal(a0, a1), (c, eng)
+            assert np.array_equal(s0, s2) and np.array_equal(a0, a2), (c, eng)
+            assert ll_close(f1, g[c + "_ll"]) < TOL, (c, eng)
 
 
 def test_h2s_offset_engine_accuracy_and_exceptions(built_lib, oracle_built):

@@ -286,6 +286,62 @@ def test_em_statistics_engines_vs_oracle(built_lib, oracle_built):
         _lib.set_option("em_stats_engine", 0)
 
 
+def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, oracle_built):
+    """Frames whose log-likelihood sits in the band where the reference's partial-product flushes decide on
+    every path that scores from PCM: the fused serving step, its chunk-pipelined form (the band of ANY chunk sends the batch
+    back through one pass), the double-buffered serving stream (resolved at collect) and the one-process multi-slot
+    predictor -- all equal to the reference's arithmetic (oracle mode 0) on the device's own features.  The models sit
+    37 sigma from the features in ONE tight dimension, so that a few per cent of the frames land in the band, others beyond
+    it (clamped) and the rest before it."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet, MultiPredictor, ServingStream
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    fs, n_win, win = 16000, 16, 32000
+    ex = MfccExtractor(fs)
+    pcm = np.stack([synth.synth_speech(3 + u, 2.0, fs)[:win] for u in range(n_win)])
+    feats = ex.extract_batch(Batch.from_pcm(list(pcm)), nd=0)
+    X, off = feats.download().astype(np.float64), feats.offsets()
+    D, K = X.shape[1], 32
+    rng = np.random.default_rng(2)
+    models = []
+    for s in range(3):
+        mean = np.zeros((K, D))
+        mean[:, s] = np.linspace(-2.0, 2.0, K) + 0.01 * rng.standard_normal(K)       # the tight dimension differs per model
+        sigma = np.full((K, D), 3.0)
+        sigma[:, s] = 0.05
+        r6 = np.vectorize(lambda v: float("%g" % v))
+        models.append((np.full(K, 1.0 / K), r6(mean), sigma))
+    want_ll = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_FASTEXP) for m in models])
+    band = (want_ll < -600.0) & (want_ll > -709.0)
+    assert band.sum() > 20 and (want_ll == go.LN_1E_15).sum() > 20, (band.sum(), (want_ll == go.LN_1E_15).sum())
+    want = np.array([[want_ll[s][off[u]:off[u + 1]].sum() for s in range(3)] for u in range(n_win)])
+    gm = [GMM.from_arrays(*m) for m in models]
+    ms = ModelSet(gm)
+    ok = lambda sums: np.max(np.abs(sums - want) / np.maximum(1.0, np.abs(want))) < 1e-4
+    calls0 = _lib.flush_stats()[0]
+    try:
+        batch = Batch.from_pcm(list(pcm))
+        s_fused, a_fused = ex.predict_batch(ms, batch, nd=0)
+        assert ok(s_fused) and np.array_equal(a_fused, np.argmax(want, axis=1))
+        _lib.set_option("predict_chunks", 2)
+        s_pipe, a_pipe = ex.predict_batch(ms, batch, nd=0)
+        assert np.array_equal(s_pipe, s_fused) and np.array_equal(a_pipe, a_fused)
+    finally:
+        _lib.set_option("predict_chunks", 0)
+    for graph in (False, True):
+        st = ServingStream(ex, ms, n_win, win, nd=0, graph=graph)
+        st.submit(pcm)
+        st.submit(pcm)
+        for _ in range(2):
+            s_st, a_st, _ms = st.collect()
+            assert np.array_equal(s_st, s_fused) and np.array_equal(a_st, a_fused), graph
+    mp_ = MultiPredictor(gm, fs, n_slots=2)
+    s_m, a_m = mp_.predict(list(pcm), nd=0)
+    assert np.array_equal(s_m, s_fused) and np.array_equal(a_m, a_fused)
+    assert _lib.flush_stats()[0] >= calls0 + 5
+
+
 def test_serving_stream_double_buffered_equals_synchronous(built_lib):
     """sr_stream_*: ticks submitted two deep (H2D of tick i+1 on its own HIP stream while tick i
     computes) return exactly what the synchronous fused step returns for the same windows, with
