@@ -307,7 +307,7 @@ def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, orac
     models = []
     for s in range(3):
         mean = np.zeros((K, D))
-        mean[:, s] = np.linspace(-2.0, 2.0, K) + 0.01 * rng.standard_normal(K)       # the tight dimension differs per model
+        mean[:, s] = 1.84 + 0.01 * rng.standard_normal(K)       # 36.8 sigma from a feature value of 0; the tight dimension differs per model
         sigma = np.full((K, D), 3.0)
         sigma[:, s] = 0.05
         r6 = np.vectorize(lambda v: float("%g" % v))
