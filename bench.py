@@ -138,7 +138,7 @@ def executed_over_algorithmic(kname, S, K, D):
     alg = float(S) * K * (4 * D + 6)
     tiles = (K + 31) // 32
     mfma_flops = 2.0 * 32 * 32 * 16 / 32.0          # per frame column: one 32x32x16 MFMA covers 32 frames
-    if "h2s" in kname:
+    if "h2s" in kname or "h2p" in kname:
         kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(",")[:2])     # <KQF,KLF,waves=N>
         blocks = (S + 14) // 15
         return blocks * tiles * (kq + 15 * kl) * mfma_flops / alg

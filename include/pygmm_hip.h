@@ -249,7 +249,7 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *                  5 split-fp16 | 6 split-fp16 shared-sigma,
  *   "score_frames_per_lane" 1|2|4, "score_model_groups" n, "score_packed" -1 (scalar FMA) | 1 (packed),
  *   "score_mfma_ft" column tiles per wave, "score_h2s_force_exc" 1 (testing: everything through the
- *   exception pass of engine 6), "score_h2s_shape" 1 (4-wave workgroups) | 2 (12-wave workgroups) of engine 6,
+ *   exception pass of engine 6), "score_h2s_shape" 1 (4-wave workgroups) | 2 (12-wave workgroups) | 3 (12 waves, image loop pipelined inside the wave) of engine 6,
  *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
  *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT). */

@@ -764,7 +764,7 @@ int sr_set_option(const char *key, long value) {
         if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
         score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
     } else if (k == "score_h2s_shape") {
-        if (value < 0 || value > 2) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups) or 2 (12-wave workgroups)");
+        if (value < 0 || value > 3) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups) or 3 (12 waves, image loop pipelined inside the wave)");
         score_options().h2s_shape = (int)value;
     } else if (k == "flush_list_cap") {
         if (value < 0) fail("flush_list_cap must be >= 0");

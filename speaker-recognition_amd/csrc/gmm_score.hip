@@ -735,6 +735,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         const int64_t wide_wgs = (n32 / h2s_tiles_per_wg(H2S_WIDE_SHAPE)) * (int64_t)set.h2s.blocks.size();
         const bool wide = wide_wgs >= (int64_t)6 * ctx().n_cu;
         h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_WIDE_SHAPE : 0);
+        if (h2s_shape == 2 && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = 1;
     }
     TileTable &tt = feat.tiles_for(use_h2s ? 32 : use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
@@ -852,9 +853,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.shape = h2s_shape;
             a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
-                     "gmm_score_h2s_kernel<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
-                     "3 products as one contraction; reference-offset log-sum-exp)", h.kqf, h.klf,
-                     h2s_shape == 1 ? "waves=12" : "waves=4", SHARED_SB);
+                     "%s<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
+                     "3 products as one contraction; reference-offset log-sum-exp)", h2s_shape == 2 ? "gmm_score_h2p_kernel" : "gmm_score_h2s_kernel",
+                     h.kqf, h.klf, h2s_shape == 2 ? "waves=12, pipelined in the wave" : h2s_shape == 1 ? "waves=12" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
             const int n_launches = launch_score_h2_shared(a, h.kqf, h.klf);
             const size_t len = strlen(g_last_kernel);

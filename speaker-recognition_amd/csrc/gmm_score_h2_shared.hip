@@ -35,11 +35,14 @@
 #include "wave_ops.hpp"
 
 #include <algorithm>
+#include <cstdint>
+#include <type_traits>
 
 namespace sr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int H2S_ROUNDS_PER_LAUNCH = 12;
 constexpr float H2S_SUM_LO = 7.8886090522101181e-31f;    // 2^-100
@@ -47,10 +50,9 @@ constexpr float H2S_SUM_HI = 1.2676506002282294e+30f;    // 2^100
 constexpr float H2S_LOG2E = 1.4426950408889634f;
 
 // KN steps of one flat chain per column tile on A fragments already in registers; `init` is the C operand of the
-// first MFMA.  The MFMAs go back to back: a wave cannot hide its own vector work behind its own MFMAs (two chains
-// with the previous epilogues between the links: 904 cycles per 16 MFMAs + 64 vector ops against 1 024 one after
-// the other, scripts/ubench/mfma_lse_inwave.hip), and a dependent chain keeps its 32-cycle cadence only when nothing
-// sits between its links.  COLS = 2 (two column tiles per wave sharing every A fragment) was measured slower and is
+// first MFMA.  The MFMAs go back to back here.  (Round 2 concluded from scripts/ubench/mfma_lse_inwave.hip that a wave
+// cannot hide its own vector work behind its own MFMAs; round 3 found that benchmark's schedule was not what it asked
+// for -- see gmm_score_h2p_kernel below, which interleaves, and why that changes the time by 1-2 % only.)  COLS = 2 (two column tiles per wave sharing every A fragment) was measured slower and is
 // not instantiated.
 template <int KN, int KM, int COLS>
 __device__ __forceinline__ void h2s_chain_regs(f32x16 (&acc)[COLS], const f32x16 (&init)[COLS], const uint4 (&fr)[KM],
@@ -116,6 +118,44 @@ struct H2sArgs {
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
+
+// Close of one block's models for one 32-frame tile (both main kernels): the offset form is only trusted well inside fp32's
+// exponent range and well above the reference's underflow boundary; a tile with a frame outside goes to the exception list
+// (decided per tile of ONE utterance, so an utterance's results do not depend on the batch around it), the others leave one
+// partial per model: a fixed-order float64 sum over the wave's lanes.
+__device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBlock &sb, int blk, const float (&ssum)[SHARED_SB], float off,
+                                                bool valid, bool has, int tile_id, int64_t row, int lane, int hh, float safe_ll2) {
+    constexpr int SB = SHARED_SB;
+    bool bad = false;
+    float ll_keep[SB];
+#pragma unroll
+    for (int si = 0; si < SB; si++) {
+        const float tot = ssum[si] + other_half(ssum[si]);
+        const float ll2 = off + log2f(tot);
+        ll_keep[si] = LSE_LN2 * ll2;
+        const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
+        bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {      // wave-uniform
+        if (lane == 0 && has) {
+            const int idx = atomicAdd(a.exc_count, 1);
+            if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id, blk);
+        }
+        return;
+    }
+#pragma unroll
+    for (int si = 0; si < SB; si++) {
+        double mine = 0.0;
+        if (valid && hh == 0 && si < sb.n_models) {
+            mine = (double)ll_keep[si];
+            if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll_keep[si];
+        }
+        mine = wave_sum_f64(mine);
+        if (lane == 0 && has && si < sb.n_models)
+            a.partial[(int64_t)tile_id * a.n_models + sb.first_model + si] = mine;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // Workgroup shapes: waves per workgroup x 32-frame column tiles per wave x images per LDS stage.
 //   <4,1>   three workgroups per CU, each with its own copy of the stream (small batches)
@@ -327,41 +367,328 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         }
         // ---- close the block's models: per 32-frame tile, so an utterance's fate does not depend on its neighbours ----
 #pragma unroll
-        for (int c = 0; c < COLS; c++) {
-            bool bad = false;
-            float ll_keep[SB];
-#pragma unroll
-            for (int si = 0; si < SB; si++) {
-                const float tot = ssum[c][si] + other_half(ssum[c][si]);
-                const float ll2 = off[c] + log2f(tot);
-                ll_keep[si] = LSE_LN2 * ll2;
-                // the offset form is only trusted well inside fp32's exponent range and well above
-                // the reference's underflow boundary
-                const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
-                bad |= (valid[c] && si < sb.n_models && !ok) || a.force_exc;
-            }
-            if (__builtin_amdgcn_ballot_w64(bad) != 0) {      // wave-uniform
-                if (lane == 0 && has[c]) {
-                    const int idx = atomicAdd(a.exc_count, 1);
-                    if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id[c], blk);
-                }
-                continue;
-            }
-            // one partial per 32-frame tile and model: a fixed-order float64 sum over the wave's lanes
-#pragma unroll
-            for (int si = 0; si < SB; si++) {
-                double mine = 0.0;
-                if (valid[c] && hh == 0 && si < sb.n_models) {
-                    mine = (double)ll_keep[si];
-                    if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row[c]] = ll_keep[si];
-                }
-                mine = wave_sum_f64(mine);
-                if (lane == 0 && has[c] && si < sb.n_models)
-                    a.partial[(int64_t)tile_id[c] * a.n_models + sb.first_model + si] = mine;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int c = 0; c < COLS; c++)
+            h2s_close_block(a, sb, blk, ssum[c], off[c], valid[c], has[c], tile_id[c], row[c], lane, hh, safe_ll2);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gmm_score_h2p_kernel (round 3): the 12-wave form with the image loop software-pipelined INSIDE each wave.
+// Opt-in (score_h2s_shape = 3), parity-tested beside the other shapes; NOT the default: it is 1-2 % faster, no more.
+//
+// Round 2 read scripts/ubench/mfma_lse_inwave.hip as "a wave cannot hide its own vector work behind its own MFMAs" and built
+// the loop above on it (chain, fragment reads, epilogue, one after the other).  That microbenchmark left the interleave to
+// sched_group_barrier hints which the compiler did not follow (5 MFMAs back to back, the exps in clumps).  With the order
+// PINNED (scripts/ubench/mfma_lse_pinned.hip, profiles/r03_ubench_pinned.txt) one wave runs 8 MFMAs + 16 exp + 16 add in 330
+// cycles (466 one after the other), three waves per SIMD in 286: an MFMA occupies the matrix pipe for 32 cycles and the same
+// wave's independent vector instructions issue in its shadow.  (v_pk_add_f32 does NOT hide: 518 cycles.  Plain adds only.)
+//
+// What it bought on the real workload, and why so little (profiles/r03_h2p_parts.txt): 80.9 ms against 81.5 (configs[2]-shaped,
+// 3 M frames), 144 against 144 (configs[3]-shaped).  With its parts switched off one at a time the kernel says where the time is:
+// matrix instructions alone 27.9 ms (1.5 M frames) = the pipe at ~98 % -- at the clock the 1.3 kW cap leaves it (1.55 GHz, not
+// 2.4) -- and every other part adds about what it costs in ENERGY whether or not it overlaps in cycles: the 16 exps + 16 adds
+// +5.7 ms (hidden in MFMA shadow or not), the 8 fragment reads per image +2.0, the LDS-DMA stream +1.9, the stage barriers
+// +1.5; together 39.3.  The chip trades clock for activity: a schedule that fills idle issue slots lowers the clock by as much
+// as it gains.  What would help is fewer joules per model-tile, not a tighter schedule -- and the matrix work cannot shrink
+// inside the 1e-4 tolerance (one part product instead of three on the MAP shift: 4.7e-4 on the benchmark's own speakers;
+// fp8 cross terms: ~1e-4; scripts/emulate_split.py and DESIGN.md 2.1).
+//
+// Slot u of image i (one per MFMA of the chain):
+//     s_waitcnt lgkmcnt  fragment u is here (counting only this loop's reads: safe beside the compiler's own, returns are in order)
+//     v_mfma             acc[i & 1] <- fr[u] x bl[u] (+ Q for u = 0)
+//     ds_read_b128       fr[u] <- fragment u of image i + 1              (the register the MFMA just read)
+//     v_add_f32 x n      the exps of slot u - 1 into the running sum of image i - 1's model   (a slot late: gfx950 needs a wait
+//     v_exp_f32 x n      of acc[(i - 1) & 1], n = 2-4; none in slot 0     state between a transcendental and its consumer)
+// as ONE asm statement per slot for chains of 5+ MFMAs (statement by statement hipcc puts an s_nop between any two that share
+// a register), operation by operation for shorter chains.  sched_barrier fences each slot: the IR-level vectoriser had turned
+// builtin-based adds into v_pk_add_f32 and sunk them, the post-RA scheduler had clumped the exps.  The fragment reads are asm
+// with their own lgkmcnt bookkeeping because a compiler-visible ds_read that may alias an LDS-DMA target makes hipcc drain
+// vmcnt in front of it, and the stream here runs two stages ahead through a ring of three.  Hazards the compiler no longer
+// sees, handled by hand: MFMA result -> VALU read (slot 0 carries no exps, so a full MFMA lies between the last MFMA of an image
+// and the first exp of its values; s_nop 12 in front of the Q - O subtraction and of the final drain), VALU write -> MFMA C
+// operand (s_nop 1 after the subtraction), transcendental -> consumer (the adds trail by a slot; s_nop 0 before the last ones).
+//
+// Barrier B_S sits in front of image (S, 1): stage S + 1 has landed (each wave waits for its own pieces, then the barrier), the
+// fragments of (S + 1, 0) are read during (S, 1); the slot of stage S is free (its last reads were issued during (S, 0)) and takes
+// the LDS-DMA of stage S + 3.
+template <int I, int N, class F>
+__device__ __forceinline__ void h2p_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        h2p_for<I + 1, N>(f);
+    }
+}
+// exps of a 16-value epilogue issued in slots <= u of a KN-slot chain (none in slot 0; all after the chain when KN = 1)
+__host__ __device__ constexpr int h2p_cum(int kn, int u) { return kn <= 1 ? 0 : u <= 0 ? 0 : u >= kn - 1 ? 16 : (16 * u + (kn - 1) / 2) / (kn - 1); }
+
+// One slot of the pipelined loop as ONE asm statement (chains of 5+ MFMAs: at most 4 exps per slot).  Statement by statement
+// hipcc puts an s_nop between any two asm statements that touch the same register and after each wait in front of the MFMA:
+// 11-13 instructions per slot, and a wave issues about one instruction per 4-5 cycles -- more than the 32 cycles of MFMA
+// shadow the slot has (measured: the epilogue cost 20 % on top of the bare chains in that form).
+//   HEAD 0: first MFMA of the Q image (C = 0)   1: first MFMA of an L image (C = Q)   2: any later one (C = the accumulator)
+#define H2P_ADDS0 ""
+#define H2P_ADDS1 "v_add_f32 %[s], %[s], %[e0]\n"
+#define H2P_ADDS2 H2P_ADDS1 "v_add_f32 %[s], %[s], %[e1]\n"
+#define H2P_ADDS3 H2P_ADDS2 "v_add_f32 %[s], %[s], %[e2]\n"
+#define H2P_ADDS4 H2P_ADDS3 "v_add_f32 %[s], %[s], %[e3]\n"
+#define H2P_EXPS0 ""
+#define H2P_EXPS1 "v_exp_f32 %[e0], %[p0]\n"
+#define H2P_EXPS2 H2P_EXPS1 "v_exp_f32 %[e1], %[p1]\n"
+#define H2P_EXPS3 H2P_EXPS2 "v_exp_f32 %[e2], %[p2]\n"
+#define H2P_EXPS4 H2P_EXPS3 "v_exp_f32 %[e3], %[p3]\n"
+#define H2P_WAIT "s_waitcnt lgkmcnt(%[w])\n"
+#define H2P_MFMA0 "v_mfma_f32_32x32x16_f16 %[cur], %[fu], %[b], 0\n"
+#define H2P_MFMA1 "v_mfma_f32_32x32x16_f16 %[cur], %[fu], %[b], %[c]\n"
+#define H2P_MFMA2 "v_mfma_f32_32x32x16_f16 %[cur], %[fu], %[b], %[cur]\n"
+#define H2P_READ0 ""
+#define H2P_READ1 "ds_read_b128 %[fu], %[at] offset:%[o]\n"
+#define H2P_SLOT_ASM(H, R, NA_, NX_)                                                                                                     \
+    asm volatile(H2P_WAIT H2P_MFMA##H H2P_READ##R H2P_ADDS##NA_ H2P_EXPS##NX_                                                            \
+                 : [cur] "+v"(cur), [fu] "+v"(fu), [s] "+v"(s), [e0] "+v"(e0), [e1] "+v"(e1), [e2] "+v"(e2), [e3] "+v"(e3)                \
+                 : [b] "v"(b), [c] "v"(c), [at] "v"(at), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3), [w] "n"(W), [o] "n"(O))
+#define H2P_SLOT_NX(H, R, NA_)                                  \
+    if constexpr (NX == 0) H2P_SLOT_ASM(H, R, NA_, 0);          \
+    else if constexpr (NX == 1) H2P_SLOT_ASM(H, R, NA_, 1);     \
+    else if constexpr (NX == 2) H2P_SLOT_ASM(H, R, NA_, 2);     \
+    else if constexpr (NX == 3) H2P_SLOT_ASM(H, R, NA_, 3);     \
+    else H2P_SLOT_ASM(H, R, NA_, 4);
+#define H2P_SLOT_NA(H, R)                                \
+    if constexpr (NA == 0) { H2P_SLOT_NX(H, R, 0) }      \
+    else if constexpr (NA == 1) { H2P_SLOT_NX(H, R, 1) } \
+    else if constexpr (NA == 2) { H2P_SLOT_NX(H, R, 2) } \
+    else if constexpr (NA == 3) { H2P_SLOT_NX(H, R, 3) } \
+    else { H2P_SLOT_NX(H, R, 4) }
+template <int HEAD, bool READ, int NA, int NX, int W, int O>
+__device__ __forceinline__ void h2p_slot(f32x16 &cur, u32x4 &fu, float &s, float &e0, float &e1, float &e2, float &e3, const f16x8 &b, const f32x16 &c,
+                                         unsigned at, float p0, float p1, float p2, float p3) {
+    static_assert(NA <= 4 && NX <= 4, "at most four exps per slot");
+    if constexpr (HEAD == 0) {
+        if constexpr (READ) { H2P_SLOT_NA(0, 1) } else { H2P_SLOT_NA(0, 0) }
+    } else if constexpr (HEAD == 1) {
+        if constexpr (READ) { H2P_SLOT_NA(1, 1) } else { H2P_SLOT_NA(1, 0) }
+    } else {
+        if constexpr (READ) { H2P_SLOT_NA(2, 1) } else { H2P_SLOT_NA(2, 0) }
+    }
+}
+
+template <int KQF, int KLF>
+__global__ __launch_bounds__(12 * 64, 3)
+void gmm_score_h2p_kernel(const H2sArgs a) {
+    constexpr int SB = SHARED_SB, WAVES = 12, G = 2, NB = 3;
+    constexpr int KM = KQF > KLF ? KQF : KLF;
+    static_assert(KQF <= KLF, "the linear half is never the shorter one");
+    constexpr int IMG_U4 = KM * 64;
+    constexpr int STAGE_U4 = G * IMG_U4;
+    constexpr int N_IMG = 1 + SB;
+    constexpr int N_STAGES = N_IMG / G;
+    static_assert(N_IMG % G == 0, "stages tile the images of a mixture tile");
+    extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64]
+    __shared__ uint4 ring[NB * STAGE_U4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31;
+    const int hh = lane >> 5;
+
+    constexpr int N_PIECES = STAGE_U4 / 64;                    // 1 KiB wave-instructions per stage
+    constexpr int P_LO = N_PIECES / WAVES, P_HI = (N_PIECES + WAVES - 1) / WAVES, N_HI = N_PIECES % WAVES;
+    auto stage_load = [&](int slot, const uint4 *src) {
+#pragma unroll
+        for (int i = 0; i < P_HI; i++) {
+            const int piece = i * WAVES + wave;
+            if (piece < N_PIECES)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + piece * 64 + lane),
+                    (__attribute__((address_space(3))) void *)(ring + slot * STAGE_U4 + piece * 64), 16, 0, 0);
+        }
+    };
+    // wait until at most `keep` stages' worth of THIS wave's pieces are in flight (they land in issue order)
+    auto wait_stages = [&](int keep) {
+        if (keep <= 0 || P_HI == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (keep == 1) {
+            if (N_HI != 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_LO) : "memory");
+        } else {
+            if (N_HI != 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P_LO) : "memory");
+        }
+    };
+    auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
+
+    const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
+    const int q = blockIdx.x >> 3;
+    const int g = q % a.n_groups;
+    const int tile0 = a.tile_base + ((q / a.n_groups) * 8 + wg_lo) * WAVES;
+    if (tile0 >= a.n_tiles) return;
+    const int blk_begin = a.group_block_begin[g];
+    const int blk_end = a.group_block_begin[g + 1];
+
+    // ---- resident B fragments of this lane's frame ----
+    f16x8 bl[KLF];
+    float zmax = 0.0f;
+    const int tile_id = tile0 + wave;
+    const bool has = tile_id < a.n_tiles;
+    const TileDesc tile = a.tiles[has ? tile_id : a.n_tiles - 1];
+    const bool valid = has && col < tile.count;
+    const int64_t row = tile.start + (valid ? col : 0);
+    {
+        f16x8 bq[KQF];
+        h2s_build_b<KQF>(bq, a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
+#pragma unroll
+        for (int ks = 0; ks < KQF; ks++) h2s_bq_lds[(wave * KQF + ks) * 64 + lane] = __builtin_bit_cast(uint4, bq[ks]);
+    }
+    h2s_build_b<KLF>(bl, a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
+    const float off = a.ref_ll[row] * H2S_LOG2E;
+    if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
+    const float safe_ll2 = a.clamp ? fmaxf(LSE_MINLOG2 + LSE_NEAR + a.log2_k, a.band_hi * H2S_LOG2E + 1.0f) : -3.0e38f;
+    const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned ring_lane = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)ring + (unsigned)lane * 16u;   // LDS byte address
+
+    for (int blk = blk_begin; blk < blk_end; blk++) {
+        const SharedBlock sb = a.blocks[blk];
+        const uint4 *stream = a.params + sb.offset_u4;
+        float ssum[SB];
+#pragma unroll
+        for (int si = 0; si < SB; si++) ssum[si] = 0.0f;
+        const int n_stage_total = a.n_mix_tiles * N_STAGES;
+        u32x4 fr[KM];                         // (a native vector: asm operands cannot be HIP's struct vectors)
+        // fragment `U` of the image at LDS byte address `at`
+        auto frag_read = [&](auto U, unsigned at) {
+            constexpr int u = decltype(U)::value;
+            u32x4 &dst = fr[u];               // (an asm operand alone does not capture)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(at), "n"(u * 1024));
+        };
+
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads the previous block's last image issued for an image that is not there
+        barrier();                                            // previous block's readers are done with the ring
+        stage_load(0, stream);
+        if (n_stage_total > 1) stage_load(1, stream + (size_t)STAGE_U4);
+        if (n_stage_total > 2) stage_load(2, stream + (size_t)2 * STAGE_U4);
+        wait_stages(n_stage_total > 2 ? 2 : n_stage_total - 1);
+        barrier();
+        h2p_for<0, KQF>([&](auto U) { frag_read(U, ring_lane); });
+
+        f32x16 acc[2];
+        acc[0] = zero1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[1][r] = -1.0e30f;    // "the image before the first": its epilogue adds 16 zeros to ssum[SB - 1]
+        int S = 0, slot_cur = 0, slot_nxt = 1;                // stage counter of the block and its ring slots
+        f32x16 qacc = zero1;
+        float e[16] = {0.0f, 0.0f, 0.0f, 0.0f};               // exps on their way from the slot that made them to the slot that adds them up
+        for (int t = 0; t < a.n_mix_tiles; t++) {
+            h2p_for<0, N_IMG>([&](auto IMG) {
+                constexpr int img = decltype(IMG)::value;
+                constexpr int gi = img % G;
+                constexpr int kn = img == 0 ? KQF : KLF;                   // this image's chain
+                constexpr int kn_next = img + 1 == N_IMG ? KQF : KLF;      // fragments of the next one
+                constexpr bool carry = img != 1;                           // image 1 follows Q: nothing to add up
+                constexpr int prev_model = img == 0 ? SB - 1 : img - 2;    // model of the image before (when carry)
+                if constexpr (gi == G - 1) {
+                    wait_stages(S + 2 < n_stage_total ? 1 : 0);
+                    barrier();
+                    if (S + 3 < n_stage_total) stage_load(slot_cur, stream + (size_t)(S + 3) * STAGE_U4);
+                }
+                const unsigned next_at = ring_lane + (unsigned)((gi == G - 1 ? slot_nxt * STAGE_U4 : slot_cur * STAGE_U4 + (gi + 1) * IMG_U4) * 16);
+                f32x16 &cur = img == 0 ? qacc : acc[img & 1];
+                const f32x16 &prev = acc[(img & 1) ^ 1];                   // (image 0 follows image 15: acc[1])
+                f16x8 bqt[KQF];
+                if constexpr (img == 0) {
+#pragma unroll
+                    for (int ks = 0; ks < KQF; ks++) bqt[ks] = __builtin_bit_cast(f16x8, h2s_bq_lds[(wave * KQF + ks) * 64 + lane]);
+                }
+                constexpr bool ONE_ASM = kn >= 5;              // (shorter chains: more than 4 exps per slot)
+                constexpr int sum_model = carry ? prev_model : 0;          // (an operand has to name something)
+                if constexpr (ONE_ASM) {
+                    h2p_for<0, kn>([&](auto U) {
+                        constexpr int u = decltype(U)::value;
+                        constexpr int younger = (kn - 1 - u) + (u < kn_next ? u : kn_next);
+                        constexpr int e0 = carry ? h2p_cum(kn, u - 2) : 0, e1 = carry ? h2p_cum(kn, u - 1) : 0, e2 = carry ? h2p_cum(kn, u) : 0;
+                        constexpr int NA = e1 - e0, NX = e2 - e1;
+                        const float p0 = prev[e1 < 16 ? e1 : 15], p1 = prev[e1 + 1 < 16 ? e1 + 1 : 15], p2 = prev[e1 + 2 < 16 ? e1 + 2 : 15],
+                                    p3 = prev[e1 + 3 < 16 ? e1 + 3 : 15];
+                        if constexpr (img == 0)
+                            h2p_slot<u == 0 ? 0 : 2, (u < kn_next), NA, NX, younger, u * 1024>(cur, fr[u], ssum[sum_model], e[0], e[1], e[2], e[3], bqt[u], qacc,
+                                                                                               next_at, p0, p1, p2, p3);
+                        else
+                            h2p_slot<u == 0 ? 1 : 2, (u < kn_next), NA, NX, younger, u * 1024>(cur, fr[u], ssum[sum_model], e[0], e[1], e[2], e[3], bl[u], qacc,
+                                                                                               next_at, p0, p1, p2, p3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                } else {
+                    h2p_for<0, kn>([&](auto U) {
+                        constexpr int u = decltype(U)::value;
+                        // our reads issued after fragment u of this image: the rest of this image's, then the next image's first u
+                        constexpr int younger = (kn - 1 - u) + (u < kn_next ? u : kn_next);
+                        u32x4 &fu = fr[u];
+                        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fu) : "n"(younger));
+                        if constexpr (img == 0)
+                            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[u]), bqt[u], u == 0 ? zero1 : cur, 0, 0, 0);
+                        else
+                            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[u]), bl[u], u == 0 ? qacc : cur, 0, 0, 0);
+                        f32x16 &cpin = cur;
+                        asm volatile("" : "+v"(cpin));                         // the MFMA stays in front of this slot's vector work
+                        if constexpr (u < kn_next) frag_read(U, next_at);
+                        if constexpr (carry) {
+                            // slot u issues exps [cum(u - 1), cum(u)) and adds up the slot before's [cum(u - 2), cum(u - 1))
+                            constexpr int e0 = h2p_cum(kn, u - 2), e1 = h2p_cum(kn, u - 1), e2 = h2p_cum(kn, u);
+                            h2p_for<e0, e1>([&](auto R) {
+                                float &sv = ssum[prev_model];
+                                const float ev = e[decltype(R)::value - e0];
+                                asm volatile("v_add_f32 %0, %0, %1" : "+v"(sv) : "v"(ev));
+                            });
+                            h2p_for<e1, e2>([&](auto R) {
+                                float &ev = e[decltype(R)::value - e1];
+                                const float pv = prev[decltype(R)::value];
+                                asm volatile("v_exp_f32 %0, %1" : "=v"(ev) : "v"(pv));
+                            });
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+                h2p_for<kn, kn_next>([&](auto U) { frag_read(U, next_at); });          // (a Q image shorter than the L image after it)
+                if constexpr (carry) {
+                    constexpr int e0 = h2p_cum(kn, kn - 2), e1 = h2p_cum(kn, kn - 1);
+                    if constexpr (kn <= 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) ssum[prev_model] += __builtin_amdgcn_exp2f(prev[r]);
+                    } else {
+                        asm volatile("s_nop 0");
+                        h2p_for<e0, e1>([&](auto R) {
+                            float &sv = ssum[prev_model];
+                            const float ev = e[decltype(R)::value - e0];
+                            asm volatile("v_add_f32 %0, %0, %1" : "+v"(sv) : "v"(ev));
+                        });
+                    }
+                }
+                if constexpr (img == 0) {
+                    // Q - O.  As asm: written as vector code hipcc builds splat(O) as 16-register tuples -- several of them, hoisted
+                    // out of the tile loop and spilled (708 bytes of scratch per lane, 44 reloads per mixture tile).  An asm reader of
+                    // an MFMA result gets no hazard handling: 8 passes + 3 wait states after the chain's last MFMA (s_nop 12 = 13).
+                    asm volatile("s_nop 12");
+                    h2p_for<0, 16>([&](auto R) {
+                        float x = qacc[decltype(R)::value];
+                        asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(off));
+                        qacc[decltype(R)::value] = x;
+                    });
+                    asm volatile("s_nop 1");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (gi == G - 1) {
+                    S++;
+                    slot_cur = slot_nxt;
+                    slot_nxt = slot_nxt == NB - 1 ? 0 : slot_nxt + 1;
+                }
+            });
+        }
+        // the last image's epilogue has no chain to ride on (and its MFMAs were asm: no hazard handling from the compiler)
+        asm volatile("s_nop 12");
+#pragma unroll
+        for (int r = 0; r < 16; r++) ssum[SB - 1] += __builtin_amdgcn_exp2f(acc[(N_IMG - 1) & 1][r]);
+        h2s_close_block(a, sb, blk, ssum, off, valid, has, tile_id, row, lane, hh, safe_ll2);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // The exception pass: one wave per (32-frame tile, block) pair of the list, classic online log-sum-exp with the
@@ -448,7 +775,10 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
     }
 }
 
-template <int KQF, int KLF, int COLS, int WAVES>
+// LDS the pipelined kernel takes: its ring of three stages plus the 12 waves' quadratic-half fragments
+__host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (3 * 2 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
+
+template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false>
 static int launch_h2s(const H2sLaunch &l) {
     constexpr bool BQ_LDS = WAVES > 4;
     H2sArgs a;
@@ -497,12 +827,19 @@ static int launch_h2s(const H2sLaunch &l) {
         if constexpr (BQ_LDS) {
             static bool attr_set[MAX_DEVICES] = {};
             if (!attr_set[ctx().device]) {
-                SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                if constexpr (PIN)
+                    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2p_kernel<KQF, KLF>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                else
+                    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
                 attr_set[ctx().device] = true;
             }
         }
-        hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
+        if constexpr (PIN)
+            hipLaunchKernelGGL((gmm_score_h2p_kernel<KQF, KLF>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
+        else
+            hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
     }
     a.tile_base = 0;
     // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
@@ -511,15 +848,18 @@ static int launch_h2s(const H2sLaunch &l) {
     return n_launches;
 }
 
-// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves)
+// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves; 2: 12 waves, pipelined)
 int h2s_resident_per_cu(int kqf, int klf, int shape) { return shape == 0 ? h2s_waves_per_eu(kqf, klf, 1, 4) : 1; }
 int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : 12; }
+bool h2s_pipelined_available(int kqf, int klf) { return h2p_fits(kqf, klf); }
 
 // returns the number of launches of the main kernel the pass was cut into
 int launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
 #define SR_H2S_CASE(Q, L)                                       \
     if (KQF == Q && KLF == L) {                                 \
-        if (l.shape == 1) return launch_h2s<Q, L, 1, 12>(l);    \
+        if constexpr (h2p_fits(Q, L))                           \
+            if (l.shape == 2) return launch_h2s<Q, L, 1, 12, true>(l); \
+        if (l.shape >= 1) return launch_h2s<Q, L, 1, 12>(l);    \
         return launch_h2s<Q, L, 1, 4>(l);                       \
     }
     // KQF = ceil(3D/16), KLF = ceil((3D+2)/16): equal, or one apart at D = 5, 16, 21, 32, 37, 48

@@ -94,12 +94,13 @@ struct H2sLaunch {
     float log2_k;
     int force_exc;
     int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
-    int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles)
+    int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles); 2: 12 waves, pipelined (gmm_score_h2p_kernel)
     float band_hi = -__builtin_inff();
 };
 int launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU
 int h2s_tiles_per_wg(int shape);                        // 32-frame tiles a workgroup of that shape takes
+bool h2s_pipelined_available(int kqf, int klf);         // shape 2 (12 waves, image loop software-pipelined inside each wave) exists for these chain lengths
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;
