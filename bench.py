@@ -715,6 +715,8 @@ def main():
         return
 
     hbm = _lib.hbm_copy_gbps(1 << 30, 10)
+    # what the matrix pipe sustains on this box under its power cap: a kernel of v_mfma_f32_32x32x16_f16 chains only (csrc/probe.hip)
+    sustained = _lib.mfma_peak_probe(60.0)
     # the same step WITH the feature/scoring pipelining (8 chunks of utterances, feature kernels of chunk i+1.. on a
     # second stream under the scoring of chunk i): an option, off by default because it measures slower
     kt1 = kt
@@ -770,6 +772,15 @@ def main():
         "parity": {"all_sums_finite": bool(np.all(np.isfinite(sums))),
                    "last_two_steps_bit_identical": bool(np.array_equal(prev, sums)) if prev is not None else None},
     }
+    rf = result["roofline"]
+    rf["sustained_mfma"] = {
+        "executed_tflops": sustained[0], "clock_mhz": sustained[1],
+        "frac_of_nominal_peak": sustained[0] / MFMA16_PEAK_TFLOPS,
+        "frac_executed_of_sustained": (rf["executed_16bit_tflops"] / sustained[0]) if rf.get("executed_16bit_tflops") and sustained[0] > 0 else None,
+        "note": "measured in this run: 12 waves per CU issuing nothing but v_mfma_f32_32x32x16_f16 for ~60 ms (sr_mfma_peak_probe). The nominal "
+                "peak assumes 2.4 GHz; under the socket power cap a matrix-only kernel holds ~1.55 GHz, so this is the ceiling any MFMA kernel "
+                "longer than a few ms has on this box; the scoring kernel's parts cost time in proportion to their energy "
+                "(profiles/r03_h2p_parts.txt). `frac` above stays algorithmic flops / nominal peak."}
     if strong is not None:
         result["configs[3]_strong_scaling"] = strong
     if world == 1 and not args.no_traffic:

@@ -252,11 +252,19 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *   exception pass of engine 6), "score_h2s_shape" 1 (4-wave workgroups) | 2 (12-wave workgroups) | 3 (12 waves, image loop pipelined inside the wave) of engine 6,
  *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
- *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT). */
+ *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT),
+ *   "reference_side_effects" 1: train_model / train_model_from_ubm print the parameter block (pygmm.cc:31-41) and the
+ *   trainer writes ./gmm-training-intermediate-dump.model after every second iteration (gmm.cc:622-630), as the
+ *   reference does unconditionally; 0 (default): neither. */
 int sr_set_option(const char *key, long value);
 /* Counters of the partial-product path since the library was loaded: resolve calls, (frame tile, model) pairs
  * noted by the engines, frames re-evaluated.  Any pointer may be NULL. */
 void sr_flush_stats(long *calls, long *pairs, long *frames);
+/* Diagnostic for the roofline record: runs v_mfma_f32_32x32x16_f16 chains, nothing else, on every SIMD of the current
+ * device for about ms_target milliseconds and reports the executed TFLOP/s and the shader clock they ran at -- the matrix
+ * throughput this device sustains under its power cap (MI355X: ~1.6 PFLOP/s at ~1.55 GHz against the 2.5 PFLOP/s that
+ * 2.4 GHz would give).  Either pointer may be NULL.  0 on success. */
+int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz);
 /* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */
 const char *sr_last_score_kernel(void);
 /* The first `count` values of the random stream train_model / load draw from when no seed is given: glibc's rand()

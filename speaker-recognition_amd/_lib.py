@@ -31,6 +31,7 @@ EXT_SYMBOLS = [
     "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
     "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats", "sr_host_register", "sr_host_unregister",
+    "sr_mfma_peak_probe",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -124,6 +125,7 @@ def lib():
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
         "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
+        "sr_mfma_peak_probe": (i32, [C.c_double, dp, dp]),
         "sr_host_register": (i32, [vp, C.c_size_t]),
         "sr_host_unregister": (i32, [vp]),
         "sr_reference_rand_sample": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
@@ -233,6 +235,14 @@ def flush_stats():
     v = [C.c_long(0) for _ in range(3)]
     lib().sr_flush_stats(*[C.byref(x) for x in v])
     return tuple(int(x.value) for x in v)
+
+
+def mfma_peak_probe(ms_target: float = 50.0):
+    """(executed fp16 MFMA TFLOP/s, shader clock in MHz) of a kernel that only issues v_mfma_f32_32x32x16_f16, on the current
+    device, for about ms_target milliseconds: what the matrix pipe sustains under the socket's power cap (csrc/probe.hip)."""
+    t, f = C.c_double(0.0), C.c_double(0.0)
+    check(lib().sr_mfma_peak_probe(C.c_double(ms_target), C.byref(t), C.byref(f)), "sr_mfma_peak_probe")
+    return float(t.value), float(f.value)
 
 
 def last_score_kernel() -> str:

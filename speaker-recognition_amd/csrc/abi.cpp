@@ -22,6 +22,8 @@ void reference_rand_sample(int *out, int count);
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed);
 void set_em_stats_engine(int v);
+void set_reference_side_effects(int v);
+int reference_side_effects();
 }  // namespace sr
 
 using namespace sr;
@@ -188,9 +190,23 @@ void dump(GMM *gmm, const char *model_file) {
     SR_CATCH_VOID
 }
 
+// pygmm.cc:31-41
+static void print_param_block(const struct Parameter *param) {
+    printf("nr_instance   :   %d\n", param->nr_instance);
+    printf("nr_dim        :   %d\n", param->nr_dim);
+    printf("nr_mixture    :   %d\n", param->nr_mixture);
+    printf("min_covar     :   %f\n", param->min_covar);
+    printf("threshold     :   %f\n", param->threshold);
+    printf("nr_iteration  :   %d\n", param->nr_iteration);
+    printf("init_with_kmeans: %d\n", param->init_with_kmeans);
+    printf("concurrency   :   %d\n", param->concurrency);
+    printf("verbosity     :   %d\n", param->verbosity);
+}
+
 void train_model(GMM *gmm, double **X_in, struct Parameter *param) {
     SR_TRY
     if (!gmm || !param) fail("null argument to train_model");
+    if (reference_side_effects()) print_param_block(param);
     std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
     if (train_em(*gmm, nullptr, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
         fail("%s", last_error().c_str());
@@ -200,6 +216,7 @@ void train_model(GMM *gmm, double **X_in, struct Parameter *param) {
 void train_model_from_ubm(GMM *gmm, GMM *ubm, double **X_in, struct Parameter *param) {
     SR_TRY
     if (!gmm || !ubm || !param) fail("null argument to train_model_from_ubm");
+    if (reference_side_effects()) print_param_block(param);
     std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
     if (train_em(*gmm, ubm, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
         fail("%s", last_error().c_str());
@@ -779,6 +796,9 @@ int sr_set_option(const char *key, long value) {
             fail("flush_order must be 2 (partial products as the reference DSO's compiler forms them: even / odd dimensions) or "
                  "1 (the source's order, gmm.cc:192-195)");
         flush_order_option() = (int)value;
+    } else if (k == "reference_side_effects") {
+        if (value != 0 && value != 1) fail("reference_side_effects must be 0 or 1");
+        set_reference_side_effects((int)value);
     } else if (k == "em_stats_engine") {
         if (value != 0 && value != 1) fail("em_stats_engine must be 0 (automatic: fp64 matrix cores for dims <= 40) or 1 (vector ALU)");
         set_em_stats_engine((int)value);
@@ -796,6 +816,14 @@ int sr_set_option(const char *key, long value) {
 const char *sr_last_score_kernel(void) { return last_score_kernel(); }
 
 void sr_flush_stats(long *calls, long *pairs, long *frames) { flush_stats(calls, pairs, frames); }
+
+int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz) {
+    SR_TRY
+    if (!(ms_target > 0.0) || ms_target > 2000.0) fail("ms_target must be in (0, 2000]");
+    mfma_peak_probe(ms_target, tflops, mhz);
+    return 0;
+    SR_CATCH(-1)
+}
 
 int sr_reference_rand_sample(int *out, int count) {
     SR_TRY

@@ -414,6 +414,17 @@ static int &em_stats_engine_option() {
     return v;
 }
 void set_em_stats_engine(int v) { em_stats_engine_option() = v; }
+// The reference's trainers leave traces a drop-in user may be relying on: the parameter block on stdout at every train_model*
+// call (pygmm.cc:31-41, :64, :88) and, after every second iteration, the model written to
+// ./gmm-training-intermediate-dump.model with two lines around it (gmm.cc:622-630, unconditional: `if (true || ...)`).
+// Off by default (a library that writes into the working directory unasked is a defect to most hosts);
+// sr_set_option("reference_side_effects", 1) turns both on.
+static int &reference_side_effects_option() {
+    static int v = 0;
+    return v;
+}
+void set_reference_side_effects(int v) { reference_side_effects_option() = v; }
+int reference_side_effects() { return reference_side_effects_option(); }
 static EmWorkspace &ews() { return per_device<EmWorkspace>(); }
 
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
@@ -421,7 +432,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     ensure_device();
     if (n <= 0) fail("X.size() == 0");                       // gmm.cc:582-586
     if (dim <= 0) fail("bad dimension %d", dim);
-    if (param.verbosity >= 1)
+    if (param.verbosity >= 1 && !reference_side_effects_option())       // (with the reference's own block on, this summary would be extra)
         printf("nr_instance: %ld nr_dim: %d nr_mixture: %d min_covar: %f threshold: %f nr_iteration: %d "
                "init_with_kmeans: %d\n", n, dim, gmm.nr_mixtures, param.min_covar, param.threshold,
                param.nr_iteration, param.init_with_kmeans);
@@ -610,6 +621,16 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
                    (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
 
         if (it % 2 == 0) continue;                           // gmm.cc:622-623
+        if (reference_side_effects_option()) {               // gmm.cc:624-630
+            const char *dump_file = "gmm-training-intermediate-dump.model";
+            printf("dumping model to %s ...\n", dump_file);
+            const std::string text = gmm_format_text(gmm);
+            if (FILE *f = fopen(dump_file, "w")) {
+                fwrite(text.data(), 1, text.size(), f);
+                fclose(f);
+            }
+            printf("model dumped to %s ...\n", dump_file);
+        }
         // total log-likelihood under the updated model (gmm.cc:631-641), reference clamp on
         SRModelSet set2;
         set2.host = pack_models({&gmm});

@@ -510,3 +510,39 @@ def test_serving_stream_with_hybrid_set_under_graph_capture(built_lib):
         got.append(st.collect())
         for t in range(4):
             assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1]), (graph, t)
+
+
+def test_reference_side_effects_are_opt_in(built_lib, tmp_path, monkeypatch, capfd):
+    """The reference's train_model prints its parameter block (pygmm.cc:31-41, :64) and its trainer writes
+    ./gmm-training-intermediate-dump.model after every second iteration, announced on stdout (gmm.cc:622-630).  Off by
+    default; with sr_set_option("reference_side_effects", 1) the legacy entry point does both, and the file is the
+    model as `dump` writes it at that iteration (here the last one)."""
+    import ctypes as C
+    from speaker_recognition_amd import _lib, synth
+    L = built_lib
+    monkeypatch.chdir(tmp_path)
+    true = synth.synth_gmm(4, 6, 3)
+    X = np.ascontiguousarray(synth.draw_frames(true, 1500, 8).astype(np.float64))
+    n, d = X.shape
+    rows = (C.POINTER(C.c_double) * n)(*[C.cast(X[i].ctypes.data, C.POINTER(C.c_double)) for i in range(n)])
+    p = _lib.Parameter(nr_instance=n, nr_dim=d, nr_mixture=4, min_covar=1e-3, threshold=0.0, nr_iteration=2, init_with_kmeans=0,
+                       concurrency=2, verbosity=0)
+    dumpf = tmp_path / "gmm-training-intermediate-dump.model"
+    for on in (0, 1):
+        _lib.set_option("reference_side_effects", on)
+        L.new_gmm.restype = C.c_void_p
+        h = C.c_void_p(L.new_gmm(4, 1))
+        L.train_model(h, rows, C.byref(p))
+        C.CDLL(None).fflush(None)             # the library prints through C stdio, as the reference does
+        out = capfd.readouterr().out
+        if not on:
+            assert out == "" and not dumpf.exists()
+        else:
+            assert out.startswith("nr_instance   :   %d\nnr_dim        :   %d\nnr_mixture    :   4\nmin_covar     :   0.001000\n" % (n, d)), out
+            assert "init_with_kmeans: 0\nconcurrency   :   2\nverbosity     :   0\n" in out
+            assert "dumping model to gmm-training-intermediate-dump.model ...\nmodel dumped to gmm-training-intermediate-dump.model ...\n" in out
+            final = tmp_path / "final.model"
+            L.dump(h, str(final).encode())
+            assert dumpf.read_bytes() == final.read_bytes()
+        L.sr_free_gmm(h)
+    _lib.set_option("reference_side_effects", 0)
