@@ -474,14 +474,18 @@ __device__ __forceinline__ void h2p_slot(f32x16 &cur, u32x4 &fu, float &s, float
 template <int KQF, int KLF>
 __global__ __launch_bounds__(12 * 64, 3)
 void gmm_score_h2p_kernel(const H2sArgs a) {
-    constexpr int SB = SHARED_SB, WAVES = 12, G = 2, NB = 3;
+    // G images per stage, a ring of NB stages, the LDS-DMA of a stage issued in slot DMA_AT of the image behind the barrier.
+    // Measured on the configs[2]-shaped pass (profiles/r03_h2p_parts.txt): ring 3 x 2 images with the DMA right behind the barrier
+    // 0.988 of the round-2 kernel's time; DMA in slot 4 0.973-0.977; ring 2 x 4 images (half the barriers, the same lead of 4 images,
+    // 64 KiB + the 96 KiB of quadratic-half fragments = all 160 KiB of the CU) 0.945.
+    constexpr int SB = SHARED_SB, WAVES = 12, G = 4, NB = 2, DMA_AT = KLF / 2;
     constexpr int KM = KQF > KLF ? KQF : KLF;
     static_assert(KQF <= KLF, "the linear half is never the shorter one");
     constexpr int IMG_U4 = KM * 64;
     constexpr int STAGE_U4 = G * IMG_U4;
     constexpr int N_IMG = 1 + SB;
     constexpr int N_STAGES = N_IMG / G;
-    static_assert(N_IMG % G == 0, "stages tile the images of a mixture tile");
+    static_assert(N_IMG % G == 0 && N_STAGES >= 1, "stages tile the images of a mixture tile");
     extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64]
     __shared__ uint4 ring[NB * STAGE_U4];
 
@@ -549,10 +553,25 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
     for (int blk = blk_begin; blk < blk_end; blk++) {
         const SharedBlock sb = a.blocks[blk];
         const uint4 *stream = a.params + sb.offset_u4;
-        float ssum[SB];
+        // ssum[SB]: the LAST executed image of a mixture tile has its epilogue carried by the next tile's Q image (and by the drain
+        // behind the loop); which model that is depends on the block (below), so its sum is kept apart until the close
+        float ssum[SB + 1];
 #pragma unroll
-        for (int si = 0; si < SB; si++) ssum[si] = 0.0f;
-        const int n_stage_total = a.n_mix_tiles * N_STAGES;
+        for (int si = 0; si <= SB; si++) ssum[si] = 0.0f;
+        // A block of fewer than SB models (the last one of a set: 201 = 13 x 15 + 6) runs only the stages that hold a model: its
+        // images are there in the stream (zeros), but 8 of configs[2]'s 224 images per mixture tile are not worth 3.6 % of the pass.
+        // Stage by stage -- a scalar test per image, which this loop can afford (its order is pinned; the same test cost the
+        // round-2 loop 9 %, profiles/r02_h2s_stalls.txt section 7).
+        const int n_st = (1 + sb.n_models + G - 1) / G;       // stages per mixture tile with a model in them, 1 .. N_STAGES
+        const int n_stage_total = a.n_mix_tiles * n_st;
+        int ld_tile = 0, ld_st = 0;                           // the next stage to load: mixture tile, stage within it
+        auto stage_load_next = [&](int slot) {
+            stage_load(slot, stream + (size_t)ld_tile * (N_IMG * IMG_U4) + (size_t)ld_st * STAGE_U4);
+            if (++ld_st == n_st) {
+                ld_st = 0;
+                ld_tile++;
+            }
+        };
         u32x4 fr[KM];                         // (a native vector: asm operands cannot be HIP's struct vectors)
         // fragment `U` of the image at LDS byte address `at`
         auto frag_read = [&](auto U, unsigned at) {
@@ -563,18 +582,19 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads the previous block's last image issued for an image that is not there
         barrier();                                            // previous block's readers are done with the ring
-        stage_load(0, stream);
-        if (n_stage_total > 1) stage_load(1, stream + (size_t)STAGE_U4);
-        if (n_stage_total > 2) stage_load(2, stream + (size_t)2 * STAGE_U4);
-        wait_stages(n_stage_total > 2 ? 2 : n_stage_total - 1);
+        stage_load_next(0);
+        if (n_stage_total > 1) stage_load_next(1);
+        if (NB > 2 && n_stage_total > 2) stage_load_next(2);
+        wait_stages(n_stage_total > NB - 1 ? NB - 1 : n_stage_total - 1);
         barrier();
         h2p_for<0, KQF>([&](auto U) { frag_read(U, ring_lane); });
 
         f32x16 acc[2];
         acc[0] = zero1;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[1][r] = -1.0e30f;    // "the image before the first": its epilogue adds 16 zeros to ssum[SB - 1]
+        for (int r = 0; r < 16; r++) acc[1][r] = -1.0e30f;    // "the image before the first": its epilogue adds 16 zeros to ssum[SB]
         int S = 0, slot_cur = 0, slot_nxt = 1;                // stage counter of the block and its ring slots
+        static_assert(NB == 2 || NB == 3, "ring of two or three stages");
         f32x16 qacc = zero1;
         float e[16] = {0.0f, 0.0f, 0.0f, 0.0f};               // exps on their way from the slot that made them to the slot that adds them up
         for (int t = 0; t < a.n_mix_tiles; t++) {
@@ -584,33 +604,45 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
                 constexpr int kn = img == 0 ? KQF : KLF;                   // this image's chain
                 constexpr int kn_next = img + 1 == N_IMG ? KQF : KLF;      // fragments of the next one
                 constexpr bool carry = img != 1;                           // image 1 follows Q: nothing to add up
-                constexpr int prev_model = img == 0 ? SB - 1 : img - 2;    // model of the image before (when carry)
+                constexpr int prev_model = img == 0 ? SB : img - 2;        // sum of the image before (when carry); SB: see ssum
+                if (img / G >= n_st) return;                               // a stage of phantom models only
                 if constexpr (gi == G - 1) {
-                    wait_stages(S + 2 < n_stage_total ? 1 : 0);
+                    wait_stages(NB > 2 && S + 2 < n_stage_total ? 1 : 0);
                     barrier();
-                    if (S + 3 < n_stage_total) stage_load(slot_cur, stream + (size_t)(S + 3) * STAGE_U4);
+                    if constexpr (DMA_AT == 0)
+                        if (S + NB < n_stage_total) stage_load_next(slot_cur);
                 }
                 const unsigned next_at = ring_lane + (unsigned)((gi == G - 1 ? slot_nxt * STAGE_U4 : slot_cur * STAGE_U4 + (gi + 1) * IMG_U4) * 16);
                 f32x16 &cur = img == 0 ? qacc : acc[img & 1];
                 const f32x16 &prev = acc[(img & 1) ^ 1];                   // (image 0 follows image 15: acc[1])
-                f16x8 bqt[KQF];
+                // the wave's own quadratic-half fragments, four at a time (all KQF of them beside fr, bl and three accumulators do
+                // not fit 168 registers: hipcc spilled two bl fragments, and a scratch reload waits with vmcnt(0) -- for the whole
+                // LDS-DMA stream in flight, not only for itself)
+                constexpr int BW = KQF < 4 ? KQF : 4;
+                f16x8 bqt[BW];
+                auto bq_load = [&](int ks) { return __builtin_bit_cast(f16x8, h2s_bq_lds[(wave * KQF + ks) * 64 + lane]); };
                 if constexpr (img == 0) {
 #pragma unroll
-                    for (int ks = 0; ks < KQF; ks++) bqt[ks] = __builtin_bit_cast(f16x8, h2s_bq_lds[(wave * KQF + ks) * 64 + lane]);
+                    for (int ks = 0; ks < BW; ks++) bqt[ks] = bq_load(ks);
                 }
                 constexpr bool ONE_ASM = kn >= 5;              // (shorter chains: more than 4 exps per slot)
                 constexpr int sum_model = carry ? prev_model : 0;          // (an operand has to name something)
                 if constexpr (ONE_ASM) {
                     h2p_for<0, kn>([&](auto U) {
                         constexpr int u = decltype(U)::value;
+                        if constexpr (gi == G - 1 && DMA_AT != 0 && u == DMA_AT)
+                            if (S + NB < n_stage_total) stage_load_next(slot_cur);
                         constexpr int younger = (kn - 1 - u) + (u < kn_next ? u : kn_next);
                         constexpr int e0 = carry ? h2p_cum(kn, u - 2) : 0, e1 = carry ? h2p_cum(kn, u - 1) : 0, e2 = carry ? h2p_cum(kn, u) : 0;
                         constexpr int NA = e1 - e0, NX = e2 - e1;
                         const float p0 = prev[e1 < 16 ? e1 : 15], p1 = prev[e1 + 1 < 16 ? e1 + 1 : 15], p2 = prev[e1 + 2 < 16 ? e1 + 2 : 15],
                                     p3 = prev[e1 + 3 < 16 ? e1 + 3 : 15];
                         if constexpr (img == 0)
-                            h2p_slot<u == 0 ? 0 : 2, (u < kn_next), NA, NX, younger, u * 1024>(cur, fr[u], ssum[sum_model], e[0], e[1], e[2], e[3], bqt[u], qacc,
-                                                                                               next_at, p0, p1, p2, p3);
+                        {
+                            h2p_slot<u == 0 ? 0 : 2, (u < kn_next), NA, NX, younger, u * 1024>(cur, fr[u], ssum[sum_model], e[0], e[1], e[2], e[3], bqt[u % BW],
+                                                                                               qacc, next_at, p0, p1, p2, p3);
+                            if constexpr (u + BW < KQF) bqt[u % BW] = bq_load(u + BW);
+                        }
                         else
                             h2p_slot<u == 0 ? 1 : 2, (u < kn_next), NA, NX, younger, u * 1024>(cur, fr[u], ssum[sum_model], e[0], e[1], e[2], e[3], bl[u], qacc,
                                                                                                next_at, p0, p1, p2, p3);
@@ -619,12 +651,14 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
                 } else {
                     h2p_for<0, kn>([&](auto U) {
                         constexpr int u = decltype(U)::value;
+                        if constexpr (gi == G - 1 && DMA_AT != 0 && u == DMA_AT)
+                            if (S + NB < n_stage_total) stage_load_next(slot_cur);
                         // our reads issued after fragment u of this image: the rest of this image's, then the next image's first u
                         constexpr int younger = (kn - 1 - u) + (u < kn_next ? u : kn_next);
                         u32x4 &fu = fr[u];
                         asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(fu) : "n"(younger));
                         if constexpr (img == 0)
-                            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[u]), bqt[u], u == 0 ? zero1 : cur, 0, 0, 0);
+                            cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[u]), bqt[u % BW], u == 0 ? zero1 : cur, 0, 0, 0);
                         else
                             cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[u]), bl[u], u == 0 ? qacc : cur, 0, 0, 0);
                         f32x16 &cpin = cur;
@@ -685,8 +719,12 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
         // the last image's epilogue has no chain to ride on (and its MFMAs were asm: no hazard handling from the compiler)
         asm volatile("s_nop 12");
 #pragma unroll
-        for (int r = 0; r < 16; r++) ssum[SB - 1] += __builtin_amdgcn_exp2f(acc[(N_IMG - 1) & 1][r]);
-        h2s_close_block(a, sb, blk, ssum, off, valid, has, tile_id, row, lane, hh, safe_ll2);
+        for (int r = 0; r < 16; r++) ssum[SB] += __builtin_amdgcn_exp2f(acc[(N_IMG - 1) & 1][r]);     // (the last image of a stage is an odd one)
+        float fin[SB];
+        const int last_model = n_st * G - 2;                  // image n_st * G - 1
+#pragma unroll
+        for (int si = 0; si < SB; si++) fin[si] = ssum[si] + (si == last_model ? ssum[SB] : 0.0f);
+        h2s_close_block(a, sb, blk, fin, off, valid, has, tile_id, row, lane, hh, safe_ll2);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -775,8 +813,8 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
     }
 }
 
-// LDS the pipelined kernel takes: its ring of three stages plus the 12 waves' quadratic-half fragments
-__host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (3 * 2 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
+// LDS the pipelined kernel takes: its ring of two stages of four images plus the 12 waves' quadratic-half fragments
+__host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (2 * 4 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
 
 template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false>
 static int launch_h2s(const H2sLaunch &l) {
