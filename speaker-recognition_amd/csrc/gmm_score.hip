@@ -734,8 +734,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         const int64_t n32 = (feat.n_rows + 31) / 32 + feat.n_utt;     // upper bound of the 32-frame tiles
         const int64_t wide_wgs = (n32 / h2s_tiles_per_wg(H2S_WIDE_SHAPE)) * (int64_t)set.h2s.blocks.size();
         const bool wide = wide_wgs >= (int64_t)6 * ctx().n_cu;
-        h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_WIDE_SHAPE : 0);
-        if (h2s_shape == 2 && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = 1;
+        // (round 3: the wide shape with its image loop pipelined inside the wave where it exists -- chains of 2..8 MFMAs, D <= 42 --
+        // 6.5-8.5 % faster than the plain 12-wave kernel, profiles/r03_h2p_parts.txt)
+        h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_PIPELINED_SHAPE : 0);
+        if (h2s_shape == H2S_PIPELINED_SHAPE && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = H2S_WIDE_SHAPE;
     }
     TileTable &tt = feat.tiles_for(use_h2s ? 32 : use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;

@@ -373,8 +373,8 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// gmm_score_h2p_kernel (round 3): the 12-wave form with the image loop software-pipelined INSIDE each wave.
-// Opt-in (score_h2s_shape = 3), parity-tested beside the other shapes; NOT the default: it is 1-2 % faster, no more.
+// gmm_score_h2p_kernel (round 3): the 12-wave form with the image loop software-pipelined INSIDE each wave.  What the
+// dispatcher takes for large batches (score_h2s_shape = 3 forces it): 6.5-8.5 % faster than the plain 12-wave kernel above.
 //
 // Round 2 read scripts/ubench/mfma_lse_inwave.hip as "a wave cannot hide its own vector work behind its own MFMAs" and built
 // the loop above on it (chain, fragment reads, epilogue, one after the other).  That microbenchmark left the interleave to
@@ -383,15 +383,18 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 // cycles (466 one after the other), three waves per SIMD in 286: an MFMA occupies the matrix pipe for 32 cycles and the same
 // wave's independent vector instructions issue in its shadow.  (v_pk_add_f32 does NOT hide: 518 cycles.  Plain adds only.)
 //
-// What it bought on the real workload, and why so little (profiles/r03_h2p_parts.txt): 80.9 ms against 81.5 (configs[2]-shaped,
-// 3 M frames), 144 against 144 (configs[3]-shaped).  With its parts switched off one at a time the kernel says where the time is:
-// matrix instructions alone 27.9 ms (1.5 M frames) = the pipe at ~98 % -- at the clock the 1.3 kW cap leaves it (1.55 GHz, not
-// 2.4) -- and every other part adds about what it costs in ENERGY whether or not it overlaps in cycles: the 16 exps + 16 adds
-// +5.7 ms (hidden in MFMA shadow or not), the 8 fragment reads per image +2.0, the LDS-DMA stream +1.9, the stage barriers
-// +1.5; together 39.3.  The chip trades clock for activity: a schedule that fills idle issue slots lowers the clock by as much
-// as it gains.  What would help is fewer joules per model-tile, not a tighter schedule -- and the matrix work cannot shrink
-// inside the 1e-4 tolerance (one part product instead of three on the MAP shift: 4.7e-4 on the benchmark's own speakers;
-// fp8 cross terms: ~1e-4; scripts/emulate_split.py and DESIGN.md 2.1).
+// What that bought on the real workload, and why the schedule alone is worth so little (profiles/r03_h2p_parts.txt): 1-2 %.
+// With its parts switched off one at a time the kernel says where the time is: matrix instructions alone 27.9 ms (1.5 M frames)
+// = the pipe at ~98 % -- at the clock the 1.3 kW cap leaves it (~1.6 GHz, not 2.4; sr_mfma_peak_probe measures 1.75-1.8 PFLOP/s
+// sustained) -- and every other part adds about what it costs in ENERGY whether or not it overlaps in cycles: the 16 exps +
+// 16 adds +5.7 ms (hidden in MFMA shadow or not), the 8 fragment reads per image +2.0, the LDS-DMA stream +1.9, the stage
+// barriers +1.5.  The chip trades clock for activity.  The rest of the 6.5-8.5 % came from what the pinned structure made
+// affordable: half the barriers (a ring of 2 x 4 images: with the run-ahead DMA the lead stays 4 images), the LDS-DMA issued
+// in the middle of an image instead of in front of its first MFMA, no scratch at all (one reload in the loop = one vmcnt(0) =
+// a wait for the whole stream in flight), and the stages that hold only phantom models of a set's last block skipped (a scalar
+// test per image: this loop's order is pinned, the same test cost the round-2 loop 9 %).  The matrix work itself cannot shrink
+// inside the 1e-4 tolerance (one part product instead of three on the MAP shift: 4.7e-4 on the benchmark's own speakers; fp8
+// cross terms: ~1e-4).
 //
 // Slot u of image i (one per MFMA of the chain):
 //     s_waitcnt lgkmcnt  fragment u is here (counting only this loop's reads: safe beside the compiler's own, returns are in order)

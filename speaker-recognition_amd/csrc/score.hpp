@@ -18,7 +18,8 @@ struct ScoreOptions {
     int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
     int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
-                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS)
+                               // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS); 3 = 12 waves with the
+                               // image loop software-pipelined inside each wave (gmm_score_h2p_kernel)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
     int flush_list_cap = 0;    // testing: capacity of the list of (tile, model) pairs in the partial-product band (0 = automatic);
                                // a pass that notes more re-runs with a list of the counted length
@@ -104,7 +105,8 @@ bool h2s_pipelined_available(int kqf, int klf);         // shape 2 (12 waves, im
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;
-constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape the dispatcher takes for large batches
+constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape
+constexpr int H2S_PIPELINED_SHAPE = 2;  // the same with the image loop pipelined inside each wave: what the dispatcher takes for large batches
 void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT);   // a.params = the split image
 int split_max_ft(int ks);
 ScoreOptions &score_options();

@@ -157,6 +157,13 @@ def test_no_hot_kernel_spills(built_lib):
             assert r["scratch"] <= 400 and r["occupancy"] >= 3, (name, r)
             if "Li12E" in name:                      # the 12-wave shape (configs[2] / [3]): operands in LDS, nothing in scratch (round 3)
                 assert r["scratch"] == 0, (name, r)
+    # the pipelined 12-wave shape (the default for large batches since round 3): NOTHING in scratch -- a spill reload inside its
+    # image loop waits with vmcnt(0), i.e. for the LDS-DMA stream in flight (it cost 8 % when two fragments spilled) -- and three
+    # waves per SIMD
+    piped = {n: r for n, r in h2s.items() if "gmm_score_h2p_kernel" in n}
+    assert len(piped) >= 12
+    for name, r in piped.items():
+        assert r["scratch"] == 0 and r["occupancy"] >= 3, (name, r)
     mf = _kernel_resources("mfcc")
     head = [r for n, r in mf.items() if "mfcc_frames_fft2048_kernelIsLi4ELi1ELi12ELi16E" in n]
     assert len(head) == 1 and head[0]["scratch"] == 0 and head[0]["occupancy"] >= 3, head
