@@ -253,6 +253,7 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
  *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT),
+ *   "kmeans_assign_engine" 1: the k-means initialiser's nearest-centre search by the exact pass only (csrc/kmeans_init.hip),
  *   "reference_side_effects" 1: train_model / train_model_from_ubm print the parameter block (pygmm.cc:31-41) and the
  *   trainer writes ./gmm-training-intermediate-dump.model after every second iteration (gmm.cc:622-630), as the
  *   reference does unconditionally; 0 (default): neither. */
@@ -260,6 +261,10 @@ int sr_set_option(const char *key, long value);
 /* Counters of the partial-product path since the library was loaded: resolve calls, (frame tile, model) pairs
  * noted by the engines, frames re-evaluated.  Any pointer may be NULL. */
 void sr_flush_stats(long *calls, long *pairs, long *frames);
+/* Counters of the k-means initialiser's nearest-centre search since the library was loaded: full searches taken the fast
+ * way (one fused multiply-add per point, centre and dimension; sr_set_option("kmeans_assign_engine", 1) turns it off) and
+ * the points those left to the exact pass (near-ties; same results bit for bit).  Either pointer may be NULL. */
+void sr_kmeans_fast_stats(long *passes, long *rechecked);
 /* Diagnostic for the roofline record: runs v_mfma_f32_32x32x16_f16 chains, nothing else, on every SIMD of the current
  * device for about ms_target milliseconds and reports the executed TFLOP/s and the shader clock they ran at -- the matrix
  * throughput this device sustains under its power cap (MI355X: ~1.6 PFLOP/s at ~1.55 GHz against the 2.5 PFLOP/s that

@@ -31,7 +31,7 @@ EXT_SYMBOLS = [
     "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
     "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats", "sr_host_register", "sr_host_unregister",
-    "sr_mfma_peak_probe",
+    "sr_mfma_peak_probe", "sr_kmeans_fast_stats",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -126,6 +126,7 @@ def lib():
         "sr_last_score_kernel": (C.c_char_p, []),
         "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
         "sr_mfma_peak_probe": (i32, [C.c_double, dp, dp]),
+        "sr_kmeans_fast_stats": (None, [C.POINTER(C.c_long)] * 2),
         "sr_host_register": (i32, [vp, C.c_size_t]),
         "sr_host_unregister": (i32, [vp]),
         "sr_reference_rand_sample": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
@@ -234,6 +235,13 @@ def flush_stats():
     """(resolve calls, (tile, model) pairs noted, frames re-evaluated) of the partial-product path (csrc/gmm_flush.hip)."""
     v = [C.c_long(0) for _ in range(3)]
     lib().sr_flush_stats(*[C.byref(x) for x in v])
+    return tuple(int(x.value) for x in v)
+
+
+def kmeans_fast_stats():
+    """(full nearest-centre searches of the k-means initialiser taken the fast way, points those left to the exact pass)"""
+    v = [C.c_long(0) for _ in range(2)]
+    lib().sr_kmeans_fast_stats(*[C.byref(x) for x in v])
     return tuple(int(x.value) for x in v)
 
 

@@ -23,6 +23,8 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
              long seed);
 void set_em_stats_engine(int v);
 void set_reference_side_effects(int v);
+void set_kmeans_assign_engine(int v);
+void kmeans_fast_stats(long *passes, long *rechecked);
 int reference_side_effects();
 }  // namespace sr
 
@@ -796,6 +798,9 @@ int sr_set_option(const char *key, long value) {
             fail("flush_order must be 2 (partial products as the reference DSO's compiler forms them: even / odd dimensions) or "
                  "1 (the source's order, gmm.cc:192-195)");
         flush_order_option() = (int)value;
+    } else if (k == "kmeans_assign_engine") {
+        if (value != 0 && value != 1) fail("kmeans_assign_engine must be 0 (fast full search, exact pass for what it cannot decide) or 1 (exact pass only)");
+        set_kmeans_assign_engine((int)value);
     } else if (k == "reference_side_effects") {
         if (value != 0 && value != 1) fail("reference_side_effects must be 0 or 1");
         set_reference_side_effects((int)value);
@@ -816,6 +821,8 @@ int sr_set_option(const char *key, long value) {
 const char *sr_last_score_kernel(void) { return last_score_kernel(); }
 
 void sr_flush_stats(long *calls, long *pairs, long *frames) { flush_stats(calls, pairs, frames); }
+
+void sr_kmeans_fast_stats(long *passes, long *rechecked) { kmeans_fast_stats(passes, rechecked); }
 
 int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz) {
     SR_TRY

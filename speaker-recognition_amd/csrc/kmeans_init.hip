@@ -120,7 +120,10 @@ typedef double km_d2 __attribute__((ext_vector_type(2)));
 template <int DIM_MAX>
 __global__ __launch_bounds__(256, 2)
 void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const double *__restrict__ C,
-                          int c_begin, int c_end, double *__restrict__ dist, int *__restrict__ belong, int reset) {
+                          int c_begin, int c_end, double *__restrict__ dist, int *__restrict__ belong, int reset,
+                          const int *__restrict__ list, const int *__restrict__ n_list) {
+    // (list != nullptr: only the points list[0 .. *n_list), the ones the fast pass below could not decide)
+    const long n_work = list ? (long)*n_list : n;
     __shared__ km_d2 cs[DIM_MAX * KM_CH / 2];    // [d][KM_CH]
     double *csd = reinterpret_cast<double *>(cs);
     constexpr bool XREG = DIM_MAX <= 40;         // wider rows are re-read (L1 / L2) instead of held: 2 x 128 registers would spill
@@ -133,7 +136,8 @@ void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const do
 #pragma unroll
     for (int p = 0; p < KM_PP; p++) {
         idx[p] = ((long)blockIdx.x * KM_PP + p) * 256 + threadIdx.x;
-        valid[p] = idx[p] < n;
+        valid[p] = idx[p] < n_work;
+        if (list) idx[p] = valid[p] ? (long)list[idx[p]] : 0;
         const float *src = X + (valid[p] ? idx[p] : 0) * dim;
         xsrc[p] = src;
         if constexpr (XREG) {
@@ -143,6 +147,7 @@ void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const do
         best[p] = reset ? 1.7976931348623157e308 : valid[p] ? dist[idx[p]] : 0.0;     // reset: a fresh search (DBL_MAX, no centre yet)
         best_j[p] = reset ? -1 : valid[p] ? belong[idx[p]] : 0;
     }
+    if ((long)blockIdx.x * KM_PP * 256 >= n_work) return;         // (list mode: the grid is sized for the worst case)
     for (int c0 = c_begin; c0 < c_end; c0 += KM_CH) {
         const int nc = min(KM_CH, c_end - c0);
         __syncthreads();
@@ -192,10 +197,171 @@ void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const do
         }
 }
 
+// ---- the full search, fast (round 3) ----
+// 99 Lloyd steps of the exact pass above (10 ms each at K = 2048 on 1 M points: 3 float64 operations per point, centre and
+// dimension) were three quarters of the k-means|| start.  The DECISION only needs the exact arithmetic where two centres are
+// nearly equally close: ||x - c||^2 - ||x||^2 = ||c||^2 - 2 x.c is ONE fused multiply-add per dimension, and its error is
+// bounded by (D + 2) 2^-53 x 2 (||x||^2 + ||c||^2) < 1e-14 (||x||^2 + max ||c||^2).  A point whose best and second-best values
+// are further apart than tau = 2^-40 (||x||^2 + max ||c||^2) -- ~50 x that bound on each side, and far above the rounding of
+// the reference's own sums -- has the same nearest centre in the reference's arithmetic; its distance is then formed the
+// reference's way (subtract, multiply, add, dimension by dimension) for that one centre.  The others (exact ties between
+// duplicate centres, the odd near-tie) go on a list and through the exact pass: same belong[] and dist[], bit for bit
+// (test_kmeans_fast_assign_equals_the_exact_pass), 4 ms instead of 10.
+// chunk records for the fast search: 16 centres per record, [d][16] doubles of -2 c, then the 16 ||c||^2; padded to whole KiB so
+// that a record goes into LDS as 1 KiB LDS-DMA pieces
+__host__ __device__ constexpr int km_rec_doubles(int dim_max) { return (dim_max * KM_CH + KM_CH + 127) / 128 * 128; }
+
+__global__ __launch_bounds__(256)
+void kmeans_centre_prep_kernel(const double *__restrict__ C, int K, int dim, int dim_max, double *__restrict__ rec,
+                               double *__restrict__ cn_max_bits) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int k_pad = (K + KM_CH - 1) / KM_CH * KM_CH;
+    if (j >= k_pad) return;
+    double *r = rec + (size_t)(j / KM_CH) * km_rec_doubles(dim_max);
+    const int col = j % KM_CH;
+    if (j >= K) {                                       // padding of the last record: never wins, never the runner-up that matters
+        for (int d = 0; d < dim_max; d++) r[d * KM_CH + col] = 0.0;
+        r[dim_max * KM_CH + col] = 1.7976931348623157e308;
+        return;
+    }
+    double s = 0.0;
+    for (int d = 0; d < dim; d++) {
+        const double c = C[(size_t)j * dim + d];
+        s = fma(c, c, s);
+    }
+    // a centre with a NaN or infinite coordinate (an empty cluster: the reference divides by zero, kmeans.cc:229-233) is never
+    // STRICTLY closer than anything in the exact pass; here it gets the value 1e300 for every point, so that the search below
+    // can use plain min / max (no NaN handling) -- and if nothing else exists, the exact pass decides
+    const bool finite = s == s && s < 1.0e300;
+    for (int d = 0; d < dim_max; d++) r[d * KM_CH + col] = (finite && d < dim) ? -2.0 * C[(size_t)j * dim + d] : 0.0;
+    r[dim_max * KM_CH + col] = finite ? s : 1.0e300;
+    if (finite)
+        atomicMax(reinterpret_cast<unsigned long long *>(cn_max_bits), (unsigned long long)__double_as_longlong(s));   // s >= 0: bit order = value order
+}
+
+template <int DIM_MAX>
+__global__ __launch_bounds__(256, 2)
+void kmeans_assign_fast_kernel(const float *__restrict__ X, long n, int dim, const double *__restrict__ C, const double *__restrict__ rec,
+                               const double *__restrict__ cn_max, int K, double *__restrict__ dist,
+                               int *__restrict__ belong, int *__restrict__ list, int *__restrict__ n_list) {
+    constexpr int REC = km_rec_doubles(DIM_MAX);
+    constexpr int PIECES = REC / 128;                       // 1 KiB wave-instructions per record
+    __shared__ double buf_a[REC];                           // (two arrays, not one: hipcc then knows a read of one cannot alias the
+    __shared__ double buf_b[REC];                           //  LDS-DMA in flight into the other, and does not drain vmcnt in front of it)
+    static_assert(DIM_MAX <= 40, "rows held in registers");
+    float x[KM_PP][DIM_MAX];
+    long idx[KM_PP];
+    bool valid[KM_PP];
+    double best[KM_PP], second[KM_PP];
+    int best_j[KM_PP];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int p = 0; p < KM_PP; p++) {
+        idx[p] = ((long)blockIdx.x * KM_PP + p) * 256 + threadIdx.x;
+        valid[p] = idx[p] < n;
+        const float *src = X + (valid[p] ? idx[p] : 0) * dim;
+#pragma unroll
+        for (int d = 0; d < DIM_MAX; d++) x[p][d] = d < dim ? src[d] : 0.f;
+        best[p] = second[p] = 1.7976931348623157e308;
+        best_j[p] = -1;
+    }
+    // A record is fetched by LDS-DMA while the one before it is being used (staging through registers under the arithmetic
+    // cost seven registers this kernel does not have: 1.15 s instead of 1.07 for the K = 2048 start; two barriers and an exposed
+    // L2 round trip per chunk, as the exact pass has them, are a third of that pass's time).
+    auto fetch = [&](double *dst, int chunk) {
+        const double *src = rec + (size_t)chunk * REC;
+#pragma unroll
+        for (int i = 0; i < (PIECES + 3) / 4; i++) {
+            const int piece = i * 4 + wave;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + piece * 128 + lane * 2),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 128), 16, 0, 0);
+        }
+    };
+    auto chunk_pass = [&](const double *cur, int c0) {
+        const km_d2 *cs = reinterpret_cast<const km_d2 *>(cur);
+        const double *cns = cur + DIM_MAX * KM_CH;
+        double acc[KM_PP][KM_CH];
+#pragma unroll
+        for (int p = 0; p < KM_PP; p++)
+#pragma unroll
+            for (int j = 0; j < KM_CH; j++) acc[p][j] = cns[j];
+#pragma unroll
+        for (int d = 0; d < DIM_MAX; d++) {
+            if (d < dim) {
+                double xv[KM_PP];
+#pragma unroll
+                for (int p = 0; p < KM_PP; p++) xv[p] = (double)x[p][d];
+#pragma unroll
+                for (int j2 = 0; j2 < KM_CH / 2; j2++) {
+                    const km_d2 c = cs[d * (KM_CH / 2) + j2];
+#pragma unroll
+                    for (int p = 0; p < KM_PP; p++) {
+                        acc[p][2 * j2] = fma(xv[p], c.x, acc[p][2 * j2]);
+                        acc[p][2 * j2 + 1] = fma(xv[p], c.y, acc[p][2 * j2 + 1]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < KM_PP; p++)
+#pragma unroll
+            for (int j = 0; j < KM_CH; j++) {                     // (the padding of the last record holds DBL_MAX: it loses to everything)
+                const double v = acc[p][j];
+                second[p] = fmin(second[p], fmax(v, best[p]));    // the loser of (v, best) against the runner-up so far
+                best_j[p] = v < best[p] ? c0 + j : best_j[p];
+                best[p] = fmin(best[p], v);
+            }
+    };
+    const int n_chunks = (K + KM_CH - 1) / KM_CH;
+    fetch(buf_a, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int ch = 0; ch < n_chunks; ch += 2) {
+        if (ch + 1 < n_chunks) fetch(buf_b, ch + 1);
+        chunk_pass(buf_a, ch * KM_CH);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the next record have landed ...
+        __syncthreads();                                          // ... and everybody's; and everybody is done with buf_a
+        if (ch + 1 >= n_chunks) break;
+        if (ch + 2 < n_chunks) fetch(buf_a, ch + 2);
+        chunk_pass(buf_b, (ch + 1) * KM_CH);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const double cmax = *cn_max;
+#pragma unroll
+    for (int p = 0; p < KM_PP; p++) {
+        if (!valid[p]) continue;
+        double xn = 0.0, d2 = 1.7976931348623157e308;
+        if (best_j[p] >= 0) {
+            const double *c = C + (size_t)best_j[p] * dim;
+            d2 = 0.0;
+#pragma unroll
+            for (int d = 0; d < DIM_MAX; d++)
+                if (d < dim) {
+                    const double xd = (double)x[p][d];
+                    const double t = __dsub_rn(xd, c[d]);
+                    d2 = __dadd_rn(d2, __dmul_rn(t, t));          // the reference's arithmetic for the centre that won
+                    xn = fma(xd, xd, xn);
+                }
+        }
+        dist[idx[p]] = d2;
+        belong[idx[p]] = best_j[p];
+        const double tau = ldexp(xn + cmax, -40);
+        if (best_j[p] >= 0 && !(second[p] - best[p] >= tau && best[p] < 1.0e299)) {     // too close to call (or no finite centre): the exact pass decides
+            const int at = atomicAdd(n_list, 1);
+            list[at] = (int)idx[p];
+        }
+    }
+}
+
 struct KmWorkspace {
     DevBuf<float> X;
     DevBuf<double> C, dist;
     DevBuf<int> belong;
+    DevBuf<double> m2c, cn_max;          // the fast full search: its chunk records (-2 c, ||c||^2), the largest ||c||^2
+    DevBuf<int> list, n_list;           // points it leaves to the exact pass
     // Lloyd on the full data, cluster sums on the device
     DevBuf<unsigned> key_in, key_out, idx_in, idx_out, seg;
     DevBuf<char> sort_tmp;
@@ -203,6 +369,11 @@ struct KmWorkspace {
     DevBuf<int> csize;
 };
 KmWorkspace &kws() { return per_device<KmWorkspace>(); }
+int &kmeans_assign_engine_option() {        // 0: the fast full search with the exact pass behind it; 1: the exact pass alone
+    static int v = 0;
+    return v;
+}
+std::atomic<long> g_km_fast_passes{0}, g_km_fast_rechecked{0};     // full searches taken the fast way; points they left to the exact pass
 
 // key = worker block * K + cluster (a point without a cluster -- NaN centres -- sorts behind everything); value = the point
 __global__ __launch_bounds__(256)
@@ -295,9 +466,32 @@ void device_assign(long n, int dim, const std::vector<double> &C, int c_begin, i
         w.belong.upload(belong.data(), (size_t)n);
     }
     const unsigned grid = (unsigned)((n + 256 * KM_PP - 1) / (256 * KM_PP));
+    const bool fast = reset && c_begin == 0 && dim <= 40 && kmeans_assign_engine_option() == 0 && n < ((long)1 << 31);
+    if (fast) {
+        // one fused multiply-add per point, centre and dimension decides wherever it can; the rest goes through the exact pass
+        const int K = c_end;
+        const int dim_max = dim <= 16 ? 16 : 40;
+        const int n_chunks = (K + KM_CH - 1) / KM_CH;
+        w.m2c.ensure((size_t)n_chunks * km_rec_doubles(dim_max));
+        w.cn_max.ensure(1);
+        w.list.ensure((size_t)n);
+        w.n_list.ensure(1);
+        SR_HIP(hipMemsetAsync(w.cn_max.p, 0, sizeof(double), ctx().stream));
+        SR_HIP(hipMemsetAsync(w.n_list.p, 0, sizeof(int), ctx().stream));
+        hipLaunchKernelGGL(kmeans_centre_prep_kernel, dim3((unsigned)((n_chunks * KM_CH + 255) / 256)), dim3(256), 0, ctx().stream, w.C.p, K, dim,
+                           dim_max, w.m2c.p, w.cn_max.p);
+        if (dim <= 16)
+            hipLaunchKernelGGL(kmeans_assign_fast_kernel<16>, dim3(grid), dim3(256), 0, ctx().stream, w.X.p, n, dim, w.C.p, w.m2c.p,
+                               w.cn_max.p, K, w.dist.p, w.belong.p, w.list.p, w.n_list.p);
+        else
+            hipLaunchKernelGGL(kmeans_assign_fast_kernel<40>, dim3(grid), dim3(256), 0, ctx().stream, w.X.p, n, dim, w.C.p, w.m2c.p,
+                               w.cn_max.p, K, w.dist.p, w.belong.p, w.list.p, w.n_list.p);
+    }
+    const int *list = fast ? w.list.p : nullptr;
+    const int *n_list = fast ? w.n_list.p : nullptr;
 #define SR_KM_LAUNCH(DM)                                                                                                    \
     hipLaunchKernelGGL(kmeans_assign_kernel<DM>, dim3(grid), dim3(256), 0, ctx().stream, w.X.p, n, dim, w.C.p, c_begin, c_end, \
-                       w.dist.p, w.belong.p, reset ? 1 : 0)
+                       w.dist.p, w.belong.p, reset ? 1 : 0, list, n_list)
     if (dim <= 16) SR_KM_LAUNCH(16);
     else if (dim <= 40) SR_KM_LAUNCH(40);
     else if (dim <= 64) SR_KM_LAUNCH(64);
@@ -370,7 +564,14 @@ void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::ve
         w.bsum.download(bsum.data(), bsum.size());
         w.csum.download(csum.data(), csum.size());
         w.csize.download(csize.data(), csize.size());
+        int rechecked = 0;
+        const bool fast_pass = w.n_list.p != nullptr && kmeans_assign_engine_option() == 0 && dim <= 40;
+        if (fast_pass) w.n_list.download(&rechecked, 1);
         sync_stream();
+        if (fast_pass) {
+            g_km_fast_passes++;
+            g_km_fast_rechecked += rechecked;
+        }
         double sum = 0;
         for (int b = 0; b < n_blocks; b++) sum += bsum[b];
         if (sum < best) {
@@ -556,6 +757,12 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
 }
 
 }  // namespace
+
+void set_kmeans_assign_engine(int v) { kmeans_assign_engine_option() = v; }
+void kmeans_fast_stats(long *passes, long *rechecked) {
+    if (passes) *passes = g_km_fast_passes.load();
+    if (rechecked) *rechecked = g_km_fast_rechecked.load();
+}
 
 // The reference library's other draws from rand(), made by the legacy entry points so that the library's stream
 // stays in step with the reference's: one per Gaussian that GMM::load constructs (gmm.cc:671-676), one for the

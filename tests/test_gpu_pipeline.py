@@ -546,3 +546,40 @@ def test_reference_side_effects_are_opt_in(built_lib, tmp_path, monkeypatch, cap
             assert dumpf.read_bytes() == final.read_bytes()
         L.sr_free_gmm(h)
     _lib.set_option("reference_side_effects", 0)
+
+
+def test_kmeans_fast_assign_equals_the_exact_pass(built_lib):
+    """The k-means initialiser's full nearest-centre search decides by ||c||^2 - 2 x.c (one fused multiply-add per point,
+    centre and dimension) wherever best and second best are further apart than its error bound allows them to swap, forms
+    the winner's distance the reference's way, and leaves every other point to the exact pass (round 3).  The initial
+    means it produces must be the exact pass's to the last bit -- also when centres coincide (rows repeated many times:
+    exact ties, first centre wins) -- and the counters must show both paths were taken."""
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.pygmm import GMM
+    rng = np.random.default_rng(12)
+    cases = []
+    cent = rng.normal(0, 3, (64, 39))
+    cases.append(((cent[rng.integers(0, 64, 20000)] + rng.normal(0, 1, (20000, 39))).astype(np.float32), 64, 16))
+    base = rng.normal(0, 2, (40, 13)).astype(np.float32)                  # 40 distinct rows, each 200 times: duplicate centres are certain
+    cases.append((np.repeat(base, 200, axis=0)[rng.permutation(8000)], 48, 5))
+    cases.append(((rng.normal(0, 1, (3000, 6)) * 50 + 1000).astype(np.float32), 16, 3))   # far from the origin: a wide tau
+    for X, K, conc in cases:
+        got = []
+        for eng in (1, 0):
+            _lib.set_option("kmeans_assign_engine", eng)
+            before = _lib.kmeans_fast_stats()
+            g = GMM(nr_mixture=K, nr_iteration=0, init_with_kmeans=1, seed=4, concurrency=conc)
+            try:
+                g.fit(X)
+                got.append(g.params())
+            except _lib.SRError as e:                 # (duplicate rows can leave a cluster empty: the reference divides by zero there)
+                got.append(str(e))
+            after = _lib.kmeans_fast_stats()
+            assert (after[0] > before[0]) == (eng == 0)
+        _lib.set_option("kmeans_assign_engine", 0)
+        if isinstance(got[0], str):
+            assert got[1] == got[0]
+        else:
+            for a, b in zip(got[0], got[1]):
+                assert np.array_equal(a, b), (K, np.max(np.abs(a - b)))
+    assert _lib.kmeans_fast_stats()[1] > 0            # some points did go through the exact pass (the repeated rows)
