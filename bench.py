@@ -141,6 +141,10 @@ def executed_over_algorithmic(kname, S, K, D):
     if "h2s" in kname or "h2p" in kname:
         kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(",")[:2])     # <KQF,KLF,waves=N>
         blocks = (S + 14) // 15
+        if "h2p" in kname:      # the pipelined shape runs a block's images in stages of 4 and skips the stages that hold phantom models only
+            last = S - 15 * (blocks - 1)
+            images = 16 * (blocks - 1) + 4 * ((1 + last + 3) // 4)
+            return tiles * (blocks * kq + (images - blocks) * kl) * mfma_flops / alg
         return blocks * tiles * (kq + 15 * kl) * mfma_flops / alg
     if "bx3_shared" in kname:
         kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(","))
