@@ -142,6 +142,14 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
 // registers until the workgroup's frame range is done.  Columns: [x, 16 per block][x^2, 16 per block][the rest of x, of
 // x^2, the count] -- only the last block(s) mix kinds, so a B operand is one cvt (x) or cvt + mul (x^2).
 // Per-(frame chunk) slabs in float64, added in a fixed order by em_reduce64_kernel: deterministic.
+//
+// Tried and measured slower (round 3, scripts/ab_em.py, K = 2048 x 400 k frames x 39 dims): an 8-wave workgroup as two teams half a
+// tile apart -- one team's waves evaluating responsibilities on the vector ALU while the other's run their MFMAs, a barrier per
+// phase, the next tile's rows staged through registers a phase ahead; bit-identical sums, 5.6 ms against 4.45 ms.  A tile costs this
+// form 2 x max(A, B) where the form below pays A + B: the two phases do not overlap on this chip.  v_mfma_f64_16x16x4_f64 runs at
+// exactly the vector ALU's float64 FMA rate (78.6 TFLOP/s both) and a wave doing only those MFMAs slows its SIMD neighbour's vector
+// phase down by about as much as it gains: A + B (11 k + 13 k cycles per 128 frames x 128 mixtures) is what both forms measure,
+// 23.6 k here, 29.8 k there.  What shortens this kernel is less arithmetic in phase A, not a different interleaving.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int EMM_WAVES = 4, EMM_MB = 16, EMM_WG_MIX = EMM_WAVES * EMM_MB;
 constexpr int EMM_F = 2;                       // frames per lane in the responsibility phase: a parameter read serves both
