@@ -335,7 +335,7 @@ def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, orac
         st.submit(pcm)
         for _ in range(2):
             s_st, a_st, _ms = st.collect()
-            assert np.array_equal(s_st, s_fused) and np.array_equal(a_st, a_fused), graph
+            assert np.array_equal(s_st, s_fused) and np.array_equal(a_st, a_fused), (graph, float(np.max(np.abs(s_st - s_fused))), int(np.sum(s_st != s_fused)), _lib.last_score_kernel())
     mp_ = MultiPredictor(gm, fs, n_slots=2)
     s_m, a_m = mp_.predict(list(pcm), nd=0)
     assert np.array_equal(s_m, s_fused) and np.array_equal(a_m, a_fused)
