@@ -22,6 +22,14 @@
 // fragments (the parts of the frame's (x'^2, x', 1) vector) resident in VGPRs for the whole kernel.
 // A wave owns FT column tiles; the accumulator layout keeps a frame's 16 mixture rows in one lane,
 // so the online log-sum-exp is lane-local and the two half-waves merge once per model.
+//
+// Tried in round 3 and measured slower: this engine in the shape the shared-sigma engine's large batches take -- one 12-wave
+// workgroup per CU, a 32-frame tile per wave, ONE copy of the stream in LDS (two stages of four chunks), a barrier per four
+// chunks instead of per chunk.  Bit-identical sums; 3.40 ms against 2.83 on configs[1] (100 x 64 x 39, 1 M frames), 0.53
+// against 0.34 on the 256 x 39 point, 0.138 against 0.123 at 10 x 32 x 13.  Here a chunk is 15 MFMAs against a ~60-instruction
+// online log-sum-exp (running maximum, rescaling), a wave runs the two one after the other, and what hides the one behind the
+// other is MORE waves per SIMD (five 4-wave workgroups = 5 per SIMD) -- worth more than the third of the L2 -> LDS stream the
+// wide shape saves.  (The shared-sigma kernel's epilogue is 32 instructions with no maximum: there the wide shape wins.)
 #include "lse.hpp"
 #include "score.hpp"
 #include "wave_ops.hpp"
