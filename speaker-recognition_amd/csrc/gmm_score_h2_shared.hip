@@ -423,6 +423,18 @@ __device__ __forceinline__ void h2p_for(F &&f) {
 }
 // exps of a 16-value epilogue issued in slots <= u of a KN-slot chain (none in slot 0; all after the chain when KN = 1)
 __host__ __device__ constexpr int h2p_cum(int kn, int u) { return kn <= 1 ? 0 : u <= 0 ? 0 : u >= kn - 1 ? 16 : (16 * u + (kn - 1) / 2) / (kn - 1); }
+// (every exp has a slot, the counts never decrease, and a chain of 5+ MFMAs never asks a slot for more than the 4 that the
+// one-statement slot form has operands for)
+constexpr bool h2p_cum_ok(int kn) {
+    if (h2p_cum(kn, 0) != 0 || h2p_cum(kn, kn - 1) != 16) return false;
+    for (int u = 1; u < kn; u++) {
+        const int n = h2p_cum(kn, u) - h2p_cum(kn, u - 1);
+        if (n < 0 || (kn >= 5 && n > 4)) return false;
+    }
+    return true;
+}
+static_assert(h2p_cum_ok(2) && h2p_cum_ok(3) && h2p_cum_ok(4) && h2p_cum_ok(5) && h2p_cum_ok(6) && h2p_cum_ok(7) && h2p_cum_ok(8),
+              "distribution of a model-tile's 16 exps over the slots of the next chain");
 
 // One slot of the pipelined loop as ONE asm statement (chains of 5+ MFMAs: at most 4 exps per slot).  Statement by statement
 // hipcc puts an s_nop between any two asm statements that touch the same register and after each wait in front of the MFMA:
