@@ -15,7 +15,10 @@
 #include "mfcc.hpp"
 #include "score.hpp"
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <deque>
 
 struct SRStream {
@@ -65,7 +68,10 @@ void stream_destroy(SRStream *s) {
 void enqueue_tick(SRStream *s, SRStream::Slot &sl) {
     mfcc_extract_batch(*s->mfcc, sl.pcm, s->nd, 1, sl.feat);
     const ScoreResult r = score_device(*s->set, sl.feat, false, s->flags & 0xff);
-    sl.h_oor[0] = sl.h_oor[1] = 0;
+    // (sl.h_oor is cleared by sr_stream_submit BEFORE anything of the tick is enqueued, not here: this function also runs under
+    // stream capture right behind a plain pass of the same slot, and a host-side clear at that point races with the plain pass's
+    // copies below -- when the device won, the tick's "frames in the partial-product band" flag was lost and the tick came back
+    // unresolved: one failure in ~10 runs of the full GPU suite, round 3)
     if (r.d_oor) SR_HIP(hipMemcpyAsync(sl.h_oor, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
     // (tile, model) pairs in the band where the reference's partial-product flushes decide (lse.hpp): resolved at collect
     if (r.d_flush_count) SR_HIP(hipMemcpyAsync(sl.h_oor + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
@@ -84,6 +90,9 @@ void capture_tick(SRStream *s, SRStream::Slot &sl) {
     ctx().profiling = false;             // no event records inside the capture
     hipGraph_t g = nullptr;
     const long epoch = g_devbuf_epoch.load();
+    // test hook (tests/test_gpu_pipeline.py): hold the host back until the plain pass in front of the capture has finished on the
+    // device -- the ordering in which a host-side write during capture used to clobber that pass's result flags
+    if (const char *d = getenv("SR_DEBUG_CAPTURE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(d)));
     SR_HIP(hipStreamBeginCapture(ctx().stream, hipStreamCaptureModeThreadLocal));
     try {
         std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());
@@ -188,6 +197,7 @@ int sr_stream_submit(SRStream *s, const int16_t *pcm) {
         auto &sl = s->slot[k];
         const size_t bytes = (size_t)s->n_windows * s->window_samples * sizeof(int16_t);
         std::memcpy(sl.h_pcm, pcm, bytes);                      // caller's buffer is free again on return
+        sl.h_oor[0] = sl.h_oor[1] = 0;                          // this tick's flags: written by its device-to-host copies only
         SR_HIP(hipEventRecord(sl.t_submit, s->copy_stream));
         SR_HIP(hipMemcpyAsync(sl.pcm.pcm16.p, sl.h_pcm, bytes, hipMemcpyHostToDevice, s->copy_stream));
         SR_HIP(hipEventRecord(sl.h2d_done, s->copy_stream));
