@@ -822,3 +822,14 @@ def test_feature_space_far_from_origin(built_lib, oracle_built):
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
             assert ll_close(fll, want) < TOL, (D, shift, scale, eng, ll_close(fll, want), _lib.last_score_kernel())
     _lib.set_option("score_engine", 0)
+
+
+def test_matrix_peak_probe_reports_a_plausible_rate(built_lib):
+    """sr_mfma_peak_probe (csrc/probe.hip; bench.py's roofline.sustained_mfma): fp16 MFMA chains on every SIMD -- between a
+    third of the nominal 2.5 PFLOP/s (a throttled box) and the nominal peak itself, at a clock between 0.8 and 2.5 GHz."""
+    from speaker_recognition_amd import _lib
+    tflops, mhz = _lib.mfma_peak_probe(20.0)
+    assert 800.0 < tflops < 2600.0, tflops
+    assert 800.0 < mhz < 2500.0, mhz
+    # the two figures describe the same run: 256 CUs x 4 SIMDs x 1024 flop per cycle at a pipe that is (nearly) always busy
+    assert 0.85 < tflops * 1e12 / (mhz * 1e6 * 1024 * 1024) <= 1.02, (tflops, mhz)
