@@ -199,11 +199,20 @@ class MfccExtractor:
         out = self.extract_batch(Batch.from_pcm([signal]), nd, cmvn)
         return out.download().astype(np.float64)
 
-    def predict_batch(self, models: ModelSet, pcm: Batch, nd: int = 0, clamp_compat: bool = True):
-        """Fused serving step on resident PCM: MFCC -> CMVN/deltas -> scoring -> argmax."""
+    def predict_batch(self, models: ModelSet, pcm: Batch, nd: int = 0, clamp_compat: bool = True, out=None):
+        """Fused serving step on resident PCM: MFCC -> CMVN/deltas -> scoring -> argmax.
+        ``out`` = (float64[U, S], int32[U]) C-contiguous arrays to fill instead of fresh ones: a serving loop that keeps its result
+        buffers spares the page faults of 8 U S new bytes per call (and may page-lock them once with ``_lib.host_register``, so that
+        the results leave the device by DMA)."""
         U, S = pcm.n_utt, len(models)
-        sums = np.zeros((U, S), dtype=np.float64)
-        arg = np.full(U, -1, dtype=np.int32)
+        if out is None:
+            sums = np.zeros((U, S), dtype=np.float64)
+            arg = np.full(U, -1, dtype=np.int32)
+        else:
+            sums, arg = out
+            if sums.shape != (U, S) or sums.dtype != np.float64 or not sums.flags.c_contiguous or arg.shape != (U,) or \
+                    arg.dtype != np.int32 or not arg.flags.c_contiguous:
+                raise ValueError("out must be (float64[%d, %d], int32[%d]), C-contiguous" % (U, S, U))
         check(lib().sr_predict_pcm_batch(self._h, models._h, pcm._h, int(nd), _lib.as_dp(sums),
                                          _lib.as_i32p(arg), _lib.SR_CLAMP_COMPAT if clamp_compat else 0),
               "sr_predict_pcm_batch")
