@@ -782,6 +782,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_h2s_tiles_per_launch") {
         if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
         score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
+    } else if (k == "score_h2s_exact_offset") {
+        if (value != 0 && value != 1) fail("score_h2s_exact_offset must be 0 or 1");
+        score_options().h2s_exact_offset = (int)value;
     } else if (k == "score_h2s_shape") {
         if (value < 0 || value > 3) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups) or 3 (12 waves, image loop pipelined inside the wave)");
         score_options().h2s_shape = (int)value;

@@ -110,6 +110,7 @@ PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp);
 // dimension's sigmas) folded into the coefficients (exact), pads dead mixtures with C = -60000
 // instead of -1e30, and is only offered when every dimension's sigma range is moderate (`sigma_ratio`).
 constexpr int SPLIT_BF16X3 = 0, SPLIT_F16X2 = 1;
+constexpr int SPLIT_F16X1 = 2;      // launch-time only: the fp16 image, HIGH parts only (one part product: a few nats of error -- an offset, not a result)
 constexpr float F16_NEG_BIG = -60000.0f;
 struct PackedSplit {
     int scheme = SPLIT_BF16X3, parts = 3;

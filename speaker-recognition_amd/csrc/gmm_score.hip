@@ -818,7 +818,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 r.n_groups = 1;
                 r.n_tiles = tt_ref.n_tiles;
                 ScopedKernelTimer t(T_SCORE_REF);
-                launch_score_split(r, SPLIT_F16X2, h.ref.ks, 1);
+                // (high parts only: a third of the MFMAs; an offset a few nats off is as good as an exact one, gmm_score_split.hip)
+                launch_score_split(r, opt.h2s_exact_offset ? SPLIT_F16X2 : SPLIT_F16X1, h.ref.ks, 1);
             }
             const int n_blocks = (int)h.blocks.size();
             const size_t cap = (size_t)tt.n_tiles * n_blocks;

@@ -85,6 +85,15 @@ struct f16x2 {
     }
 };
 
+// The fp16 image with only the product of the high parts: a third of f16x2's MFMAs for a value good to a few parts in a
+// thousand of every term -- what the shared-sigma engine's reference-offset pre-pass needs (gmm_score_h2_shared.hip: any
+// offset within ~60 nats of a model's log-likelihood does; the result does not depend on it beyond the rounding of a sum).
+struct f16x1 : f16x2 {
+    static constexpr int NPROD = 1;
+    static constexpr int AI[1] = {0};
+    static constexpr int BI[1] = {0};
+};
+
 __host__ __device__ constexpr int split_waves_per_eu(int parts, int ks, int ft) {
     const int regs = ft * (ks * parts * 4 + 16) + 24 + 12 * parts;
     return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
@@ -324,6 +333,8 @@ static void dispatch_split(const MfmaLaunch &a, int KS, int FT) {
 void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT) {
     if (scheme == SPLIT_F16X2)
         dispatch_split<f16x2>(a, KS, FT);
+    else if (scheme == SPLIT_F16X1)
+        dispatch_split<f16x1>(a, KS, 1);
     else
         dispatch_split<bf16x3>(a, KS, FT);
 }

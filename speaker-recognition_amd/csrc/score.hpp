@@ -20,6 +20,7 @@ struct ScoreOptions {
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
                                // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS); 3 = 12 waves with the
                                // image loop software-pipelined inside each wave (gmm_score_h2p_kernel)
+    int h2s_exact_offset = 0;  // 1: the reference-offset pre-pass of the split-fp16 shared-sigma engine with all three part products (round 2's)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
     int flush_list_cap = 0;    // testing: capacity of the list of (tile, model) pairs in the partial-product band (0 = automatic);
                                // a pass that notes more re-runs with a list of the counted length
