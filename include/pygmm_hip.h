@@ -253,6 +253,7 @@ int sr_profile_get(int kind, double *total_ms, long *launches);
  *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
  *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
  *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT),
+ *   "score_h2s_exact_offset" 1: engine 6's reference-offset pre-pass with all three part products (default: the high parts only),
  *   "kmeans_assign_engine" 1: the k-means initialiser's nearest-centre search by the exact pass only (csrc/kmeans_init.hip),
  *   "reference_side_effects" 1: train_model / train_model_from_ubm print the parameter block (pygmm.cc:31-41) and the
  *   trainer writes ./gmm-training-intermediate-dump.model after every second iteration (gmm.cc:622-630), as the
