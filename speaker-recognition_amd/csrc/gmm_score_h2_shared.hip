@@ -648,6 +648,7 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
                         if constexpr (gi == G - 1 && DMA_AT != 0 && u == DMA_AT)
                             if (S + NB < n_stage_total) stage_load_next(slot_cur);
                         constexpr int younger = (kn - 1 - u) + (u < kn_next ? u : kn_next);
+                        static_assert(younger <= 15, "lgkmcnt is a 4-bit field");
                         constexpr int e0 = carry ? h2p_cum(kn, u - 2) : 0, e1 = carry ? h2p_cum(kn, u - 1) : 0, e2 = carry ? h2p_cum(kn, u) : 0;
                         constexpr int NA = e1 - e0, NX = e2 - e1;
                         const float p0 = prev[e1 < 16 ? e1 : 15], p1 = prev[e1 + 1 < 16 ? e1 + 1 : 15], p2 = prev[e1 + 2 < 16 ? e1 + 2 : 15],
