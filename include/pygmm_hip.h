@@ -69,8 +69,20 @@ int get_nr_mixtures(GMM *gmm);
 /* Status: 0 = ok, negative = error (text via sr_last_error(), thread-local). */
 const char *sr_last_error(void);
 
-/* Device plumbing. The HIP runtime is initialised lazily on first use (fork-safe for the
- * multiprocessing callers of src/test/test-nperson.py:135-139).  One process may drive several GPUs:
+/* Processes.  The reference's drivers fit in the parent and THEN fork a multiprocessing.Pool whose workers score
+ * (src/test/test-nperson.py:126-139, src/test/test-gmm.py:120-133); a HIP runtime does not survive fork().  So:
+ *   - the runtime is initialised lazily, at the first call that needs the device: a pool forked BEFORE that gives
+ *     every worker a runtime of its own;
+ *   - a process forked AFTER its parent used the GPU is detected (pthread_atfork + pid).  There the reference's ten
+ *     symbols above, sr_score_frames_f32 and sr_train_f32 keep working -- they are served by a helper process
+ *     (lib/sr_fork_helper next to lib/pygmm.so, spawned at the first such call, one per forked child; csrc/fork_proxy.cpp)
+ *     with the results of the in-process path; every other entry point that needs the device returns its error
+ *     status with a message naming the remedy, without touching HIP; host-only entry points (load / dump / new_gmm /
+ *     get_* / sr_gmm_* / sr_mfcc_tables ...) work as always; inherited device handles may be freed (a no-op there).
+ * sr_gpu_runtime_lost() = 1 in such a process.  Pinned by tests/test_fork.py (CPU) and tests/test_gpu_fork.py. */
+int sr_gpu_runtime_lost(void);
+
+/* Device plumbing.  One process may drive several GPUs:
  * every host thread has a current device; stream, workspaces, timers and the entry-point lock exist
  * once per device, so threads on different devices run in parallel and threads sharing a device are
  * serialised.  Handles that own device memory (SRBatch, SRModelSet, SRStream) belong to the device

@@ -80,6 +80,7 @@ def lib():
         "get_nr_mixtures": (i32, [vp]),
         # extensions
         "sr_last_error": (C.c_char_p, []),
+        "sr_gpu_runtime_lost": (i32, []),
         "sr_device_count": (i32, []),
         "sr_set_device": (i32, [i32]),
         "sr_set_thread_device": (i32, [i32]),
@@ -150,6 +151,12 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def gpu_runtime_lost() -> bool:
+    """True in a process forked after its parent initialised the GPU runtime (include/pygmm_hip.h, "Processes"): the per-model
+    entry points are served by a helper process there, the batched ones refuse."""
+    return bool(lib().sr_gpu_runtime_lost())
 
 
 def last_error() -> str:

@@ -5,6 +5,7 @@
 
 #include "batch.hpp"
 #include "common.hpp"
+#include "fork_proxy.hpp"
 #include "gmm_model.hpp"
 #include "mfcc.hpp"
 #include "score.hpp"
@@ -126,8 +127,20 @@ static uint64_t fnv1a(const void *p, size_t bytes) {
     return h;
 }
 
-static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out,
-                      int flags) {
+namespace sr {
+void score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags);
+}
+// One model against a contiguous fp32 matrix: here, or -- in a process that lost its GPU runtime to fork() -- in its helper.
+static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags) {
+    if (gpu_runtime_lost()) return fork_proxy_score(g, X, n, dim, ll_out, sum_out, flags);
+    score_one_local(g, X, n, dim, ll_out, sum_out, flags);
+}
+static int train_one(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param, long seed) {
+    if (gpu_runtime_lost()) return fork_proxy_train(gmm, ubm, X, n, dim, param, seed);
+    return train_em(gmm, ubm, X, n, dim, param, seed);
+}
+
+void sr::score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags) {
     SRModelSet &set = single_set(g);
     if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
     auto &cache = per_device<LegacyFeatureCache>();
@@ -210,7 +223,7 @@ void train_model(GMM *gmm, double **X_in, struct Parameter *param) {
     if (!gmm || !param) fail("null argument to train_model");
     if (reference_side_effects()) print_param_block(param);
     std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
-    if (train_em(*gmm, nullptr, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
+    if (train_one(*gmm, nullptr, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
         fail("%s", last_error().c_str());
     SR_CATCH_VOID
 }
@@ -220,7 +233,7 @@ void train_model_from_ubm(GMM *gmm, GMM *ubm, double **X_in, struct Parameter *p
     if (!gmm || !ubm || !param) fail("null argument to train_model_from_ubm");
     if (reference_side_effects()) print_param_block(param);
     std::vector<float> X = rows_to_f32(X_in, param->nr_instance, param->nr_dim);
-    if (train_em(*gmm, ubm, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
+    if (train_one(*gmm, ubm, X.data(), param->nr_instance, param->nr_dim, *param, -1) < 0)
         fail("%s", last_error().c_str());
     SR_CATCH_VOID
 }
@@ -262,6 +275,8 @@ int get_nr_mixtures(GMM *gmm) { return gmm ? gmm->nr_mixtures : 0; }
 // ======================= Part 2: extensions =======================
 
 const char *sr_last_error(void) { return last_error().c_str(); }
+
+int sr_gpu_runtime_lost(void) { return gpu_runtime_lost() ? 1 : 0; }
 
 int sr_device_count(void) { return visible_devices(); }
 
@@ -684,7 +699,7 @@ int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
                  const struct Parameter *param, long seed) {
     SR_TRY
     if (!gmm || !X || !param) fail("null argument to sr_train_f32");
-    return train_em(*gmm, ubm_or_null, X, n, dim, *param, seed);
+    return train_one(*gmm, ubm_or_null, X, n, dim, *param, seed);
     SR_CATCH(-1)
 }
 
@@ -817,6 +832,7 @@ int sr_set_option(const char *key, long value) {
     } else {
         fail("unknown option '%s'", key);
     }
+    fork_proxy_note_option(key, value);
     return 0;
     SR_CATCH(-1)
 }

@@ -2,6 +2,10 @@
 #include "common.hpp"
 
 #include <mutex>
+#include <new>
+
+#include <pthread.h>
+#include <unistd.h>
 
 namespace sr {
 
@@ -48,24 +52,70 @@ void set_default_device(int device) {
     tl_device = device;
 }
 
+static std::recursive_mutex *g_api_mutex = new std::recursive_mutex[MAX_DEVICES];   // leaked: usable during exit
+std::recursive_mutex &api_mutex_of(int device) { return g_api_mutex[device]; }
+std::recursive_mutex &api_mutex() { return g_api_mutex[current_device()]; }
+
+static Ctx g_ctx[MAX_DEVICES];
+static bool g_ready[MAX_DEVICES];
+static std::mutex g_mu;
+static std::mutex g_slot_mu;
+
+void reference_rand_fork_child();       // kmeans_init.hip
+
+// ---- fork (common.hpp) ----
+static std::atomic<long> g_runtime_pid{0};       // the process that made the first HIP call (0: none yet)
+static std::atomic<bool> g_runtime_lost{false};
+static std::atomic<bool> g_atfork_installed{false};
+
+static void atfork_child() {
+    // Only the forking thread exists here.  Locks another thread of the parent held at that instant would stay locked
+    // for ever: give the child fresh ones (nothing else of the library's state is shared with a thread that is gone).
+    new (&g_mu) std::mutex();
+    new (&g_slot_mu) std::mutex();
+    for (int i = 0; i < MAX_DEVICES; i++) new (&g_api_mutex[i]) std::recursive_mutex();
+    reference_rand_fork_child();
+    if (g_runtime_pid.load() != 0) g_runtime_lost.store(true);
+}
+
+void note_gpu_runtime_use() {
+    if (!g_atfork_installed.exchange(true)) (void)pthread_atfork(nullptr, nullptr, atfork_child);
+    long expected = 0;
+    (void)g_runtime_pid.compare_exchange_strong(expected, (long)getpid());
+}
+
+bool gpu_runtime_lost() {
+    if (g_runtime_lost.load(std::memory_order_relaxed)) return true;
+    // (a fork() that bypassed the handlers -- a raw clone -- is caught by the pid)
+    const long owner = g_runtime_pid.load(std::memory_order_relaxed);
+    if (owner != 0 && owner != (long)getpid()) {
+        g_runtime_lost.store(true);
+        return true;
+    }
+    return false;
+}
+
+void fail_gpu_runtime_lost(const char *what) {
+    fail("%s: this process (pid %ld) was forked after its parent (pid %ld) had initialised the GPU runtime, and HIP does "
+         "not survive fork().  The ten pygmm symbols, sr_score_frames_f32 and sr_train_f32 still work here (helper "
+         "process); for the batched sr_* interface create the pool BEFORE the first compute call or use the 'spawn' "
+         "start method",
+         what, (long)getpid(), g_runtime_pid.load());
+}
+
 int visible_devices() {
+    if (gpu_runtime_lost()) return 0;
+    note_gpu_runtime_use();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
 
-std::recursive_mutex &api_mutex() {
-    static std::recursive_mutex *m = new std::recursive_mutex[MAX_DEVICES];   // leaked: usable during exit
-    return m[current_device()];
-}
-
-static Ctx g_ctx[MAX_DEVICES];
-static bool g_ready[MAX_DEVICES];
-static std::mutex g_mu;
-
 Ctx &ctx() { return g_ctx[current_device()]; }
 
 void ensure_device() {
+    if (gpu_runtime_lost()) fail_gpu_runtime_lost("no usable GPU runtime");
+    note_gpu_runtime_use();
     const int d = current_device();
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_ready[d]) {
@@ -97,9 +147,8 @@ StreamScope::StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s
 StreamScope::~StreamScope() { ctx().stream = saved; }
 
 void *per_device_slot(void **slots, void *(*make)()) {
-    static std::mutex mu;
     const int d = current_device();
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(g_slot_mu);
     if (!slots[d]) slots[d] = make();
     return slots[d];
 }
@@ -164,6 +213,10 @@ void profile_prewarm() {
 void profile_collect() {
     auto &t = ts();
     if (t.pending.empty()) return;
+    if (gpu_runtime_lost()) {          // a forked child: the parent's events mean nothing here
+        t.pending.clear();
+        return;
+    }
     SR_HIP(hipStreamSynchronize(ctx().main));
     SR_HIP(hipStreamSynchronize(ctx().aux));
     for (auto &p : t.pending) {

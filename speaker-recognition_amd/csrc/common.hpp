@@ -50,8 +50,25 @@ int visible_devices();                   // hipGetDeviceCount, 0 on error
 // GIL) are serialised rather than left to race; callers on different devices run in parallel.
 std::recursive_mutex &api_mutex();       // of the calling thread's current device
 
-// ---- per-device context: one stream, lazily created (fork-safe: nothing touches HIP before the
-// first call that needs the device). ----
+// ---- fork().  The HIP runtime does not survive it: a process forked from one that had already used the GPU inherits
+// queues, events and device pointers the kernel driver no longer honours for it (its threads that waited on them are
+// gone), and a HIP call there may hang or crash.  The reference's own drivers do exactly that (src/test/test-nperson.py:
+// 126-139, test-gmm.py:120-133: `gmmset.fit` in the parent, THEN multiprocessing.Pool, `predict_one` in the forked
+// workers) -- harmless for its CPU library.  Here:
+//   * nothing touches HIP before the first call that needs the device, so a pool created BEFORE the first compute call
+//     gets one runtime per worker (lazy initialisation after the fork);
+//   * a process forked AFTER that is marked (pthread_atfork child handler + a pid check): every entry point that needs
+//     the device fails with an sr::Error naming the remedy instead of calling into the dead runtime, nothing of the
+//     inherited device state is freed there -- and the reference's ten symbols (+ sr_score_frames_f32 / sr_train_f32)
+//     keep WORKING: fork_proxy.cpp forwards them to a helper process (lib/sr_fork_helper, spawned on first use) that
+//     loads this library afresh and owns a runtime of its own.
+void note_gpu_runtime_use();     // call before the process's first HIP call: remembers the pid, installs the fork handler
+bool gpu_runtime_lost();         // true in a process forked from one that had used the runtime
+[[noreturn]] void fail_gpu_runtime_lost(const char *what);
+std::recursive_mutex &api_mutex_of(int device);
+
+// ---- per-device context: one stream, lazily created (nothing touches HIP before the first call that
+// needs the device: see above). ----
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // where launches go (normally `main`; StreamScope redirects)
@@ -124,7 +141,7 @@ struct DevBuf {
     void ensure(size_t count) { if (count > n) alloc(count); }
     void release() {
         if (p) {
-            (void)hipFree(p);
+            if (!gpu_runtime_lost()) (void)hipFree(p);      // (a forked child leaves its parent's allocations alone)
             g_devbuf_epoch++;
         }
         p = nullptr;
@@ -152,10 +169,10 @@ struct PinnedBuf {
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    ~PinnedBuf() { if (p && !gpu_runtime_lost()) (void)hipHostFree(p); }
     void ensure(size_t count) {
         if (count <= n) return;
-        if (p) (void)hipHostFree(p);
+        if (p && !gpu_runtime_lost()) (void)hipHostFree(p);
         p = nullptr;
         n = 0;
         SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));

@@ -42,6 +42,7 @@
 #include <cstdlib>
 #include <limits>
 #include <mutex>
+#include <new>
 #include <random>
 #include <thread>
 
@@ -770,6 +771,22 @@ void kmeans_fast_stats(long *passes, long *rechecked) {
 void burn_reference_rand(int count) {
     std::lock_guard<std::mutex> lock(g_rand_mutex);
     for (int i = 0; i < count; i++) (void)g_reference_rand.next();
+}
+// fork support (common.cpp, fork_proxy.cpp): a forked child gets a fresh lock; the generator's state travels to the helper
+// process that computes on a forked child's behalf and back, so that the library-wide stream stays the one the reference's
+// process-wide rand() would be
+void reference_rand_fork_child() { new (&g_rand_mutex) std::mutex(); }
+void reference_rand_state(int32_t *words36, bool set) {
+    std::lock_guard<std::mutex> lock(g_rand_mutex);
+    if (set) {
+        for (int i = 0; i < 34; i++) g_reference_rand.r[i] = words36[i];
+        g_reference_rand.f = words36[34];
+        g_reference_rand.b = words36[35];
+    } else {
+        for (int i = 0; i < 34; i++) words36[i] = g_reference_rand.r[i];
+        words36[34] = g_reference_rand.f;
+        words36[35] = g_reference_rand.b;
+    }
 }
 // the first `count` values of a fresh generator (test hook: compared with the C library's rand())
 void reference_rand_sample(int *out, int count) {

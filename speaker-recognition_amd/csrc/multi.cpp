@@ -242,7 +242,7 @@ SRMulti *sr_multi_create(GMM *const *models, int n_models, double fs, double win
 }
 
 void sr_multi_free(SRMulti *m) {
-    if (!m) return;
+    if (!m || gpu_runtime_lost()) return;     // (a forked child leaves its parent's device state alone: common.hpp)
     const int prev = current_device();
     for (auto &s : m->slots) {
         try {

@@ -49,6 +49,7 @@ namespace {
 
 void stream_destroy(SRStream *s) {
     if (!s) return;
+    if (gpu_runtime_lost()) return;      // a forked child: the parent's session is not ours to tear down (common.hpp); leaked
     for (auto &sl : s->slot) {
         if (sl.h_pcm) (void)hipHostFree(sl.h_pcm);
         if (sl.h_sums) (void)hipHostFree(sl.h_sums);
@@ -173,7 +174,7 @@ SRStream *sr_stream_create(SRMfcc *m, SRModelSet *set, int n_windows, int64_t wi
 }
 
 void sr_stream_free(SRStream *s) {
-    if (!s) return;
+    if (!s || gpu_runtime_lost()) return;
     const int prev = current_device();
     try {
         set_thread_device(s->device);

@@ -13,6 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from . import _lib
 from .core import Batch, ModelSet
 from .pygmm import GMM
 
@@ -75,6 +76,11 @@ class GMMSet(object):
 
     def predict_one_scores(self, x):
         """Summed log-likelihood of utterance ``x`` under every speaker model (one launch)."""
+        if _lib.gpu_runtime_lost():
+            # a worker forked after the parent used the GPU (the reference's fit-then-Pool drivers, test-nperson.py:126-139):
+            # device-resident sets cannot exist here; the reference's own speaker-by-speaker loop (gmmset.py:59-64) can --
+            # each call is served by this process's helper (csrc/fork_proxy.cpp)
+            return [float(g.score_all(x)) for g in self.gmms]
         totals, _ = self._model_set().score(Batch.from_features([x]))
         return totals[0].tolist()
 
@@ -90,6 +96,8 @@ class GMMSet(object):
         utterances = list(X)
         if not utterances:
             return []
+        if _lib.gpu_runtime_lost():
+            return [self.predict_one(x) for x in utterances]
         _, winners = self._model_set().score(Batch.from_features(utterances))
         return [None if w < 0 else self.y[w] for w in winners]
 
