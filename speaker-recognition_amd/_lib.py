@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("SR_PYGMM_LIB") or os.path.join(_HERE, "lib", "pygmm.s
 LEGACY_SYMBOLS = ["new_gmm", "load", "dump", "train_model", "train_model_from_ubm", "score_all",
                   "score_batch", "score_instance", "get_dim", "get_nr_mixtures"]
 EXT_SYMBOLS = [
-    "sr_last_error", "sr_device_count", "sr_set_device", "sr_set_thread_device", "sr_get_device", "sr_device_synchronize",
+    "sr_last_error", "sr_gpu_runtime_lost", "sr_device_count", "sr_set_device", "sr_set_thread_device", "sr_get_device", "sr_device_synchronize",
     "sr_device_name", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
     "sr_gmm_loads", "sr_score_frames_f32", "sr_modelset_create", "sr_modelset_free",
     "sr_modelset_size", "sr_modelset_info", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",

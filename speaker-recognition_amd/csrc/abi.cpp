@@ -808,6 +808,10 @@ int sr_set_option(const char *key, long value) {
         score_options().flush_list_cap = (int)value;
     } else if (k == "score_h2s_force_exc") {
         score_options().h2s_force_exc = value != 0;
+    } else if (k == "score_split_shape") {
+        if (value != 0 && value != 1 && value != 8 && value != 12 && value != 16)
+            fail("score_split_shape must be 0 (automatic), 1 (4-wave workgroups) or 8 / 12 / 16 (waves of the wide, pipelined form)");
+        score_options().split_shape = (int)value;
     } else if (k == "score_mfma_ft") {
         if (value < 0 || value > 4) fail("score_mfma_ft must be 0..4");
         score_options().mfma_ft = (int)value;

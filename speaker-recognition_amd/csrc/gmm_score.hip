@@ -739,7 +739,24 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_PIPELINED_SHAPE : 0);
         if (h2s_shape == H2S_PIPELINED_SHAPE && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = H2S_WIDE_SHAPE;
     }
-    TileTable &tt = feat.tiles_for(use_h2s ? 32 : use_mat ? 128 * FT : 256 * F);
+    // the generic split-fp16 engine as ONE wide workgroup per CU (gmm_score_splitp.hip) once the batch fills the chip: the 4-wave
+    // kernel re-streams every chunk per 128 frames, and the LDS-DMA that takes is what bounds it on large batches
+    int splitp_w = 0, split_cpm = 0;
+    if (use_h2 && FT == 1 && opt.split_shape != 1) {
+        const std::vector<int> &mcb = split.model_chunk_begin;
+        split_cpm = S > 0 ? mcb[1] - mcb[0] : 0;
+        for (int s = 1; s < S; s++)
+            if (mcb[s + 1] - mcb[s] != split_cpm) split_cpm = 0;       // models of different orders: the 4-wave kernel
+        if (split_cpm > 0) {
+            const int64_t n32 = (feat.n_rows + 31) / 32 + feat.n_utt;  // upper bound of the 32-frame tiles
+            // short streams (few chunks per frame prologue) want two workgroups per CU: one's prologue under the other's chains
+            const int want = opt.split_shape ? opt.split_shape : ((int64_t)S * split_cpm <= 16 ? 8 : 16);
+            const int w = splitp_waves(SPLIT_F16X2, split.ks, want);
+            if (w > 0 && (opt.split_shape || (n32 / w) * (int64_t)std::min(S, 16) >= (int64_t)6 * ctx().n_cu * splitp_resident_per_cu(w)))
+                splitp_w = w;
+        }
+    }
+    TileTable &tt = feat.tiles_for((use_h2s || splitp_w) ? 32 : use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
@@ -758,9 +775,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
             const int target = use_h2s ? ctx().n_cu * h2s_resident_per_cu(set.h2s.kqf, set.h2s.klf, h2s_shape) * 6 : use_shared ? ctx().n_cu * 2 * 6
+                               : splitp_w ? ctx().n_cu * splitp_resident_per_cu(splitp_w) * 12
                                : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
-            // (the split-fp16 shared-sigma engine's workgroups take several 32-frame tiles each)
-            const int n_wg_tiles = use_h2s ? (tt.n_tiles + h2s_tiles_per_wg(h2s_shape) - 1) / h2s_tiles_per_wg(h2s_shape) : tt.n_tiles;
+            // (the split-fp16 shared-sigma engine's workgroups, and the wide generic ones, take several 32-frame tiles each)
+            const int n_wg_tiles = use_h2s ? (tt.n_tiles + h2s_tiles_per_wg(h2s_shape) - 1) / h2s_tiles_per_wg(h2s_shape)
+                                   : splitp_w ? (tt.n_tiles + splitp_w - 1) / splitp_w : tt.n_tiles;
             G = (target + n_wg_tiles - 1) / n_wg_tiles;
         }
         const int n_units = use_h2s ? (int)set.h2s.blocks.size()
@@ -915,7 +934,13 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_tiles = tt.n_tiles;
             a.band_hi = fp.band_hi;
             ScopedKernelTimer t(T_SCORE);
-            if (use_h2) {
+            if (use_h2 && splitp_w) {
+                snprintf(g_last_kernel, sizeof(LastKernel::name),
+                         "gmm_score_splitp_kernel<f16x2,%d,waves=%d> (3 x v_mfma_f32_32x32x16_f16 per fp32 product; log-sum-exp pipelined "
+                         "under the next chunk's MFMAs)", split.ks, splitp_w);
+                if (!launch_score_splitp(a, SPLIT_F16X2, split.ks, splitp_w, split_cpm))
+                    fail("no wide split-fp16 kernel for %d contraction steps and %d waves", split.ks, splitp_w);
+            } else if (use_h2) {
                 snprintf(g_last_kernel, sizeof(LastKernel::name),
                          "gmm_score_split_kernel<f16x2,%d,%d> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)", split.ks, FT);
                 launch_score_split(a, SPLIT_F16X2, split.ks, FT);

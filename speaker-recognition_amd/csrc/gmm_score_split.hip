@@ -32,67 +32,12 @@
 // wide shape saves.  (The shared-sigma kernel's epilogue is 32 instructions with no maximum: there the wide shape wins.)
 #include "lse.hpp"
 #include "score.hpp"
+#include "split_schemes.hpp"
 #include "wave_ops.hpp"
 
 #include <algorithm>
 
 namespace sr {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-struct bf16x3 {
-    static constexpr int PARTS = 3, NPROD = 6;
-    typedef bf16x8 frag;
-    // small products first, and consecutive MFMAs share one operand
-    static constexpr int AI[6] = {2, 1, 1, 0, 0, 0};
-    static constexpr int BI[6] = {0, 0, 1, 1, 2, 0};
-    static constexpr bool SCALED = false;
-    __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-    // 16-bit patterns of the parts of v (round-to-nearest-even at each step: the split is exact)
-    __device__ static __forceinline__ void split(float v, uint32_t (&p)[3]) {
-        auto rne = [](float f) {
-            const uint32_t u = __float_as_uint(f);
-            return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-        };
-        const uint32_t p0 = rne(v);
-        const float r1 = v - __uint_as_float(p0);
-        const uint32_t p1 = rne(r1);
-        const float r2 = r1 - __uint_as_float(p1);
-        p[0] = p0 >> 16;
-        p[1] = p1 >> 16;
-        p[2] = rne(r2) >> 16;
-    }
-};
-
-struct f16x2 {
-    static constexpr int PARTS = 2, NPROD = 3;
-    typedef f16x8 frag;
-    static constexpr int AI[3] = {1, 0, 0};
-    static constexpr int BI[3] = {0, 1, 0};
-    static constexpr bool SCALED = true;
-    __device__ static __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-    __device__ static __forceinline__ void split(float v, uint32_t (&p)[2]) {
-        const _Float16 h = (_Float16)v;                    // v_cvt_f16_f32, RNE, gradual underflow
-        const _Float16 l = (_Float16)(v - (float)h);
-        p[0] = (uint32_t)__builtin_bit_cast(unsigned short, h);
-        p[1] = (uint32_t)__builtin_bit_cast(unsigned short, l);
-    }
-};
-
-// The fp16 image with only the product of the high parts: a third of f16x2's MFMAs for a value good to a few parts in a
-// thousand of every term -- what the shared-sigma engine's reference-offset pre-pass needs (gmm_score_h2_shared.hip: any
-// offset within ~60 nats of a model's log-likelihood does; the result does not depend on it beyond the rounding of a sum).
-struct f16x1 : f16x2 {
-    static constexpr int NPROD = 1;
-    static constexpr int AI[1] = {0};
-    static constexpr int BI[1] = {0};
-};
 
 __host__ __device__ constexpr int split_waves_per_eu(int parts, int ks, int ft) {
     const int regs = ft * (ks * parts * 4 + 16) + 24 + 12 * parts;

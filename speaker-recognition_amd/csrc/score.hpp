@@ -20,6 +20,9 @@ struct ScoreOptions {
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
                                // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS); 3 = 12 waves with the
                                // image loop software-pipelined inside each wave (gmm_score_h2p_kernel)
+    int split_shape = 0;       // workgroup shape of the generic split-fp16 engine: 0 = automatic; 1 = 4 waves (gmm_score_split_kernel);
+                               // 16 / 12 / 8 = gmm_score_splitp_kernel with that many waves (one 32-frame tile each, log-sum-exp pipelined
+                               // under the next chunk's MFMAs; 16 and 12: one workgroup per CU, 8: two)
     int h2s_exact_offset = 0;  // 1: the reference-offset pre-pass of the split-fp16 shared-sigma engine with all three part products (round 2's)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
     int flush_list_cap = 0;    // testing: capacity of the list of (tile, model) pairs in the partial-product band (0 = automatic);
@@ -110,6 +113,12 @@ constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape
 constexpr int H2S_PIPELINED_SHAPE = 2;  // the same with the image loop pipelined inside each wave: what the dispatcher takes for large batches
 void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT);   // a.params = the split image
 int split_max_ft(int ks);
+// gmm_score_splitp.hip: the same engines as ONE wide workgroup per CU (12 or 16 waves, a 32-frame tile each, the chunk's log-sum-exp
+// pipelined under the next chunk's MFMAs); `a.tiles` = 32-frame tiles.  splitp_waves: waves per workgroup of the variant that exists
+// for this layout (`want` = 0, 12 or 16), 0 = none.
+int splitp_waves(int scheme, int ks, int want);
+int splitp_resident_per_cu(int waves);
+bool launch_score_splitp(const MfmaLaunch &a, int scheme, int KS, int waves, int chunks_per_model);
 ScoreOptions &score_options();
 const char *last_score_kernel();   // name of the kernel variant the last scoring call launched
 

@@ -30,7 +30,7 @@ def _reset_options(built_lib):
     from speaker_recognition_amd import _lib
     yield
     for k in ("score_frames_per_lane", "score_model_groups", "score_packed", "score_engine", "score_mfma_ft", "mfcc_generic",
-              "score_h2s_force_exc", "score_h2s_shape"):
+              "score_h2s_force_exc", "score_h2s_shape", "score_split_shape"):
         _lib.set_option(k, 0)
     _lib.set_option("flush_order", 2)
     _lib.set_option("flush_list_cap", 0)
@@ -382,6 +382,52 @@ def test_random_shapes_all_engines(built_lib, oracle_built):
                     assert arg[u] == int(np.argmax(w)), (case, eng, u)
 
 
+def test_wide_split_shapes_equal_the_four_wave_kernel(built_lib, oracle_built):
+    """gmm_score_splitp_kernel (round 4: one wide workgroup per CU, a 32-frame tile per wave, a chunk's log-sum-exp under the next
+    chunk's MFMAs) runs the 4-wave kernel's arithmetic value by value: the per-frame log-likelihoods are EQUAL bit for bit; the
+    sums differ by the order of float64 additions only; and both agree with the oracle.  Shapes around every border the kernel
+    has: 1 .. 13 chunks per model (stage of 4 or 2, ring of 3), 1 .. 37 models (slab flush every 16), model groups, ragged
+    utterances, tiles that end inside a workgroup, frames at the reference's underflow clamp, with it on and off."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(404)
+    cases = [(39, 64, 5), (39, 256, 1), (13, 32, 37), (26, 96, 17), (39, 416, 2), (20, 160, 3), (5, 33, 16), (40, 64, 4), (48, 32, 2), (34, 128, 33)]
+    for case, (D, K, S) in enumerate(cases):
+        models = [synth.synth_gmm(K, D, 900 + 10 * case + s) for s in range(S)]
+        lens = [int(v) for v in rng.choice([1, 31, 32, 33, 100, 511, 512, 513, 700, 1030], size=int(rng.integers(2, 7)))]
+        utts = [synth.draw_frames(models[u % S], n, 50 + 100 * case + u, outlier_frac=0.02) for u, n in enumerate(lens)]
+        X = np.concatenate(utts).astype(np.float64)
+        want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        _lib.set_option("score_engine", 5)
+        for clamp in (True, False):
+            _lib.set_option("score_split_shape", 1)
+            _lib.set_option("score_model_groups", 0)
+            sums0, arg0, fll0 = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=clamp)
+            assert "gmm_score_split_kernel" in _lib.last_score_kernel()
+            if clamp:
+                assert ll_close(fll0, want) < TOL
+            for waves in (8, 12, 16):
+                for groups in (0, 1, 3):
+                    _lib.set_option("score_split_shape", waves)
+                    _lib.set_option("score_model_groups", groups)
+                    sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=clamp)
+                    name = _lib.last_score_kernel()
+                    assert "gmm_score_splitp_kernel" in name, (case, waves, name)
+                    assert np.array_equal(fll, fll0), (case, D, K, S, waves, groups, clamp, float(np.max(np.abs(fll - fll0))))
+                    assert np.array_equal(arg, arg0)
+                    assert np.max(np.abs(sums - sums0) / np.maximum(1.0, np.abs(sums0))) < 1e-12
+                    sums2, arg2 = ms.score(Batch.from_features(utts), clamp_compat=clamp)          # without the per-frame output; deterministic
+                    assert np.array_equal(sums2, sums) and np.array_equal(arg2, arg)
+    # models of different orders: the wide form declines, the 4-wave kernel takes the set
+    mixed = [synth.synth_gmm(64, 13, 1), synth.synth_gmm(128, 13, 2)]
+    _lib.set_option("score_split_shape", 16)
+    ModelSet([GMM.from_arrays(*m) for m in mixed]).score(Batch.from_features([synth.draw_frames(mixed[0], 300, 3)]))
+    assert "gmm_score_split_kernel" in _lib.last_score_kernel()
+
+
 def test_concurrent_host_threads(built_lib, oracle_built):
     """ctypes releases the GIL, so Python threads reach the library concurrently; the entry points
     serialise on one lock (one stream and cached workspaces per process) and every thread still gets
@@ -516,12 +562,16 @@ def test_clamp_band_matches_reference_all_engines(built_lib, clamp_golden):
         m = _gmm(g, c)
         X, ref = g[c + "_X"], g[c + "_ll"]
         clamped = ref == np.log(1e-15)
-        for eng in (1, 2, 3, 5, 0):
+        for eng, wide in ((1, 0), (2, 0), (3, 0), (5, 1), (5, 8), (5, 12), (5, 16), (0, 0)):
             _lib.set_option("score_engine", eng)
+            _lib.set_option("score_split_shape", wide)       # the generic split-fp16 engine: 4-wave kernel / the wide pipelined forms
             ll = m.score(X)
-            assert np.array_equal(ll == floor32, clamped), (c, eng, _lib.last_score_kernel())
-            assert ll_close(ll[~clamped], ref[~clamped]) < TOL, (c, eng)
+            assert np.array_equal(ll == floor32, clamped), (c, eng, wide, _lib.last_score_kernel())
+            assert ll_close(ll[~clamped], ref[~clamped]) < TOL, (c, eng, wide)
             assert abs(m.score_all(X) - float(np.sum(ref))) < TOL * abs(float(np.sum(ref)))
+            if wide > 1:
+                assert "gmm_score_splitp_kernel" in _lib.last_score_kernel() and "waves=%d" % wide in _lib.last_score_kernel()
+        _lib.set_option("score_split_shape", 0)
 
 
 def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_built, flush_golden):
@@ -559,24 +609,26 @@ def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_b
         utts = [X[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         ms = ModelSet([GMM.from_arrays(*mm) for mm in models])
         want_sums = np.array([[ref[s][a:b].sum() for s in range(len(models))] for a, b in zip(cuts[:-1], cuts[1:])])
-        engines = [(1, 0, 0), (0, 0, 0)]
+        engines = [(1, 0, 0, 0), (0, 0, 0, 0)]
         if c in conditioned:
-            engines += [(3, 0, 0), (5, 0, 0)]
+            engines += [(3, 0, 0, 0), (5, 0, 0, 1), (5, 0, 0, 8), (5, 0, 0, 12), (5, 0, 0, 16)]
         if len(models) >= 12:
-            engines += [(4, 0, 0), (6, 1, 0), (6, 2, 0), (6, 3, 0), (6, 1, 1)]
-        for eng, shape, force in engines:
+            engines += [(4, 0, 0, 0), (6, 1, 0, 0), (6, 2, 0, 0), (6, 3, 0, 0), (6, 1, 1, 0)]
+        for eng, shape, force, wide in engines:
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_h2s_shape", shape)
             _lib.set_option("score_h2s_force_exc", force)
+            _lib.set_option("score_split_shape", wide)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
-            assert np.array_equal(fll == floor32, clamped), (c, eng, shape, force, _lib.last_score_kernel())
-            assert ll_close(fll[~clamped], ref[~clamped]) < TOL, (c, eng)
-            assert np.max(np.abs(sums - want_sums) / np.maximum(1.0, np.abs(want_sums))) < TOL, (c, eng, shape, force)
+            assert np.array_equal(fll == floor32, clamped), (c, eng, shape, force, wide, _lib.last_score_kernel())
+            assert ll_close(fll[~clamped], ref[~clamped]) < TOL, (c, eng, wide)
+            assert np.max(np.abs(sums - want_sums) / np.maximum(1.0, np.abs(want_sums))) < TOL, (c, eng, shape, force, wide)
             sums2, arg2 = ms.score(Batch.from_features(utts))
             assert np.array_equal(sums2, sums) and np.array_equal(arg2, arg), (c, eng)       # same with sums only; deterministic
             _lib.set_option("score_h2s_force_exc", 0)
         _lib.set_option("score_engine", 0)
         _lib.set_option("score_h2s_shape", 0)
+        _lib.set_option("score_split_shape", 0)
         # ---- the source's order of the partial products instead of the compiler's (a DSO built without reassociation)
         _lib.set_option("flush_order", 1)
         ll = m.score(X)
