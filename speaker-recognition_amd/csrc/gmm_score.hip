@@ -749,10 +749,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             if (mcb[s + 1] - mcb[s] != split_cpm) split_cpm = 0;       // models of different orders: the 4-wave kernel
         if (split_cpm > 0) {
             const int64_t n32 = (feat.n_rows + 31) / 32 + feat.n_utt;  // upper bound of the 32-frame tiles
-            // short streams (few chunks per frame prologue) want two workgroups per CU: one's prologue under the other's chains
-            const int want = opt.split_shape ? opt.split_shape : ((int64_t)S * split_cpm <= 16 ? 8 : 16);
+            // Measured (profiles/r04_splitp.txt): every shape of this engine delivers the same MFMAs per second on real data -- the
+            // socket's power cap sets the clock by the kernel's activity (zero-filled operands: 1.46x faster, same instructions) --
+            // so the shapes differ by single percents: 8 waves (two workgroups per CU, one's frame prologue under the other's
+            // chains) wins or ties from ~32 chunks per prologue up (configs[1]: 2.69 against 2.78-2.99 ms), the 4-wave kernel keeps
+            // the short streams (one 256-mixture model: 0.33 against 0.38 ms) and the small batches
+            const int want = opt.split_shape ? opt.split_shape : 8;
             const int w = splitp_waves(SPLIT_F16X2, split.ks, want);
-            if (w > 0 && (opt.split_shape || (n32 / w) * (int64_t)std::min(S, 16) >= (int64_t)6 * ctx().n_cu * splitp_resident_per_cu(w)))
+            if (w > 0 && (opt.split_shape || ((int64_t)S * split_cpm >= 32 &&
+                                              (n32 / w) * (int64_t)std::min(S, 16) >= (int64_t)6 * ctx().n_cu * splitp_resident_per_cu(w))))
                 splitp_w = w;
         }
     }
