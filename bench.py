@@ -16,8 +16,12 @@ copied back to the host.
 `--gpus N`: one rank per GPU, utterances shard by rank, models replicated, no data-path collective
 (SURVEY.md 8e); per-GPU work is fixed ("weak").  Launched by torch.distributed.run the ranks come
 with RANK/LOCAL_RANK/WORLD_SIZE set; launched plainly with --gpus N > 1 this script spawns the N
-ranks itself (gloo rendezvous on 127.0.0.1).  torch is used only for the barrier / max-over-ranks of
-the elapsed time -- never for device work.
+ranks itself.  The barrier / max-over-ranks / gather of the per-rank figures go over the package's own
+Unix-domain-socket rendezvous (speaker-recognition_amd/rendezvous.py): nothing here imports torch
+(`--rendezvous gloo` keeps torch.distributed as the carrier).  Every rank pins itself to the cores of its
+GPU's NUMA node.  At N > 1 the line also carries the weak-scaling efficiency against rank 0 running the same
+step ALONE in the same run, the configs[3] strong-scaling split, and the ONE-process path over the N devices
+(sr_multi_predict_pcm from page-locked host PCM).
 
 Beside the headline the JSON line carries a `configs` block (N = 1 only, outside the timed region):
 configs[1], a stated sub-sample of one rank's configs[3] shard, configs[4] latencies, and the
@@ -150,7 +154,7 @@ def executed_over_algorithmic(kname, S, K, D):
         kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(","))
         blocks = (S + 14) // 15
         return blocks * tiles * 6 * (kq + 15 * kl) * mfma_flops / alg
-    if "split_kernel<f16x2" in kname or "split_kernel<bf16x3" in kname:
+    if "split_kernel<f16x2" in kname or "split_kernel<bf16x3" in kname or "splitp_kernel<f16x2" in kname:
         ks = int(kname.split("<")[1].split(",")[1])
         prod = 3 if "f16x2" in kname else 6
         return S * tiles * prod * ks * mfma_flops / alg
@@ -289,23 +293,25 @@ def block_cfg1(_lib, ex, base, hbm, preq):
     _lib.profile_reset()
     el, (sums, arg) = timed(step, 0, 10, _lib.synchronize)
     kt = kernel_times(_lib, 10)
-    _lib.set_option("predict_chunks", 4)
-    step()
-    el4, _ = timed(step, 0, 10, _lib.synchronize)                   # the pipelining option, for the record
-    _lib.set_option("predict_chunks", 0)
     kname = _lib.last_score_kernel()
-    # parity sample (checked by the oracle subprocess): 2 utterances x 6 models on the device's own features
-    fb = ex.extract_batch(Batch.from_pcm([cat[off[u]:off[u + 1]] for u in (0, 1)]), nd=ND)
-    preq["configs[1]"] = {"models": raw[:6], "X": fb.download().astype(np.float64), "offsets": fb.offsets(),
-                          "device_sums": sums[:2, :6]}
+    # parity samples for the pool of host cores (oracle subprocess): the first 200 utterances x ALL 100 models -- per frame on
+    # their own batch (features = the device's own MFCC output), per utterance against the sums of the TIMED 1 M-frame pass --
+    # and the feature stage of the same 200 utterances against the float64 restatement of MFCC.py
+    n200 = min(200, CFG1_UTTS)
+    fb = ex.extract_batch(Batch.from_pcm((cat[:off[n200]], off[:n200 + 1])), nd=ND)
+    X200 = fb.download()
+    s200, a200, f200 = ms.score(fb, frame_ll=True)
+    preq["configs[1]"] = {"models": raw, "X": X200, "offsets": fb.offsets(), "device_sums": sums[:n200], "device_frame_ll": f200}
+    preq["mfcc_configs[1]_audio"] = {"kind": "mfcc", "pcm": cat[:off[n200]], "sample_offsets": off[:n200 + 1], "fs": FS, "mfcc_kw": MFCC_KW,
+                                     "nd": ND, "device_feats": X200, "offsets": fb.offsets()}
+    small_vs_timed = float(np.max(np.abs(s200 - sums[:n200]) / np.maximum(1.0, np.abs(s200))))
     return {"workload": "BASELINE.json configs[1]: 39-dim MFCC+delta+delta-delta, 100 speaker GMMs x 64 mixtures, %d utterances x %d frames" % (CFG1_UTTS, FRAMES_PER_UTT),
             "frames_per_s": n_frames * 10 / el, "ms_per_step": 1e3 * el / 10,
             "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
             "sum_of_kernels_ms": sum(v["ms_per_step"] for v in kt.values()),
-            "ms_per_step_with_predict_chunks_4": 1e3 * el4 / 10,
             "roofline": score_roofline(kname, n_frames, CFG1_MODELS, CFG1_MIX, DIM, kt["gmm_score"]["ms_per_step"] * 1e-3, hbm),
             "mfcc_roofline": mfcc_roofline(CFG1_UTTS * (FRAMES_PER_UTT + ND), kt["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
-            "parity": None}
+            "parity": {"small_batch_sums_vs_timed_pass_max_rel": small_vs_timed}}
 
 
 def block_legacy(_lib):
@@ -459,7 +465,8 @@ def block_published_em(_lib):
 
 def block_multi_slot(_lib, ex, base):
     """The one-process multi-GPU path (sr_multi_predict_pcm: a host thread + model replica per slot, PCM from HOST memory
-    in every call) on the configs[1] workload with 2 slots on this one GPU, beside the resident-PCM step of the same work."""
+    in every call, uploaded and scored in up to 8 pieces without a host wait in between) on the configs[1] workload with 1 and
+    2 slots on this one GPU, beside the resident-PCM step of the same work."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.core import Batch, ModelSet, MultiPredictor
     from speaker_recognition_amd.pygmm import GMM
@@ -477,7 +484,7 @@ def block_multi_slot(_lib, ex, base):
     for pinned in (False, True):
         if pinned:
             _lib.host_register(cat)            # what a serving loop does once with its PCM ring: the copy engines read it in place
-        for slots in (1, 2, 4):
+        for slots in (1, 2):
             mp_ = MultiPredictor(gm, FS, n_slots=slots, **MFCC_KW)
             f = lambda: mp_.predict_concat(cat, off, nd=ND)
             f(); f()
@@ -489,8 +496,77 @@ def block_multi_slot(_lib, ex, base):
         if pinned:
             _lib.host_unregister(cat)
     out["pcie_floor_ms"] = cat.nbytes / 55e9 * 1e3
-    out["note"] = ("every call moves the PCM host -> device; a slot uploads and scores its utterances in 4 pieces, the copy of a piece "
-                   "under the scoring of the pieces before it; pcie_floor_ms = the PCM at 55 GB/s")
+    out["note"] = ("every call moves the PCM host -> device; a slot uploads its utterances in up to 8 pieces on the copy stream and enqueues every "
+                   "piece's kernels + result copies behind its upload event, one host wait at the end; pcie_floor_ms = the PCM at 55 GB/s; "
+                   "floor of the whole call ~ max(copy, kernels) + the first piece")
+    return out
+
+
+def block_serving_small(_lib, ex, base, ms, S, K, hbm):
+    """The serving shape between a 61-frame window and a 10 M-frame batch: 1, 8 and 64 short utterances (300 frames = 3 s) per
+    call against the whole 201 x 512 set -- one utterance against a 200-speaker set is what gui/interface.py:85-94 does per
+    decision.  PCM from HOST memory in every call (in-place update of a device batch), per-call latency at the host,
+    the scoring kernel's HIP-event time and its roofline fraction."""
+    from speaker_recognition_amd.core import Batch
+    L, shift = ex.FRAME_LEN, ex.FRAME_SHIFT
+    T = 300
+    n_samples = (T + ND - 1) * shift + L
+    out = {"workload": "1 / 8 / 64 utterances x %d frames (16 kHz, %d samples each) per call against %d models x %d mixtures x %d dims, PCM from "
+                       "host memory in every call" % (T, n_samples, S, K, DIM)}
+    for U in (1, 8, 64):
+        clips = [np.ascontiguousarray(base[u % len(base)][:n_samples]) for u in range(U)]
+        cat = np.concatenate(clips)
+        batch = Batch.from_pcm(clips)
+        lat = []
+        for i in range(130):
+            if i == 30:
+                _lib.profile_reset()
+            t0 = time.perf_counter()
+            batch.update_pcm(cat)
+            sums, arg = ex.predict_batch(ms, batch, nd=ND)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
+        ms_r, _ = _lib.profile_get(_lib.T_SCORE_REF)
+        ms_m, _ = _lib.profile_get(_lib.T_MFCC)
+        lat = np.array(lat[30:])
+        kname = _lib.last_score_kernel()
+        rf = score_roofline(kname, U * T, S, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm)
+        out["utterances_%d" % U] = {"latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
+                                    "decisions_per_s": U / (float(np.median(lat)) * 1e-3),
+                                    "scoring_kernel_ms": (ms_k + ms_r) / max(1, n_k), "mfcc_kernel_ms": ms_m / max(1, n_k),
+                                    "kernel": kname.split(" (")[0], "frac_algorithmic": rf["frac"], "frac_executed_mfma": rf["frac_executed_mfma"],
+                                    "algorithmic_tflops": rf["achieved"], "all_finite": bool(np.all(np.isfinite(sums)))}
+    return out
+
+
+def block_one_process_multi(_lib, base, n_devices, device_override):
+    """N > 1 only: sr_multi_predict_pcm with one slot per device (a host thread + model replica each, pinned to its GPU's NUMA
+    node), the configs[1] workload PER DEVICE (weak scaling: N x 1000 utterances), PCM from page-locked host memory in every
+    call -- beside the N-process number of the headline.  With --device-override the slots stack on one device (code path only)."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import MultiPredictor
+    from speaker_recognition_amd.pygmm import GMM
+    gm = [GMM.from_arrays(*synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s)) for s in range(CFG1_MODELS)]
+    out = {"workload": "configs[1] per device (1000 utterances x 1000 frames each, 100 x 64 mixtures), one process, one slot per device, "
+                       "page-locked host PCM -> device in every call"}
+    per = {}
+    for n in sorted({1, n_devices}):
+        cat, off = make_pcm(base[:CFG1_MODELS], CFG1_UTTS * n, 0)
+        _lib.host_register(cat)
+        try:
+            mp_ = MultiPredictor(gm, FS, n_slots=n, **MFCC_KW)
+            f = lambda: mp_.predict_concat(cat, off, nd=ND)
+            f(); f()
+            el, (s2, a2) = timed(f, 0, 5)
+            per[n] = CFG1_UTTS * n * FRAMES_PER_UTT * 5 / el
+            out["slots_%d" % n] = {"ms_per_call": 1e3 * el / 5, "frames_per_s": per[n], "slot_devices": mp_.slot_devices(),
+                                   "slot_numa_nodes": mp_.slot_numa_nodes(), "slot_seconds": [float(v) for v in mp_.slot_seconds],
+                                   "all_utterances_decided": bool(np.all(a2 >= 0))}
+            del mp_
+        finally:
+            _lib.host_unregister(cat)
+    if n_devices > 1 and 1 in per:
+        out["scaling_efficiency_vs_one_slot"] = per[n_devices] / (n_devices * per[1])
     return out
 
 
@@ -616,7 +692,10 @@ def main():
     ap.add_argument("--cfg3-total-frames", type=int, default=CFG3_TOTAL_FRAMES,
                     help="testing only: total frames of the configs[3] job the ranks split (default: its stated 100 M)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc sub-runs that fill roofline.traffic")
-    ap.add_argument("--cpu-sample-utts", type=int, default=4)
+    ap.add_argument("--cpu-sample-utts", type=int, default=4, help="utterances of the single-call CPU leg (reference DSO, concurrency = cores)")
+    ap.add_argument("--cpu-pool-utts", type=int, default=64, help="utterances of the Pool leg (reference DSO over (utterance, model group) tasks on all cores, all models)")
+    ap.add_argument("--rendezvous", choices=("socket", "gloo"), default=os.environ.get("SR_RENDEZVOUS", "socket"),
+                    help="how the N ranks meet on the host: the package's Unix-domain socket (no torch) or torch.distributed over gloo")
     ap.add_argument("--device-override", type=int, default=-1,
                     help="testing only: put every rank on this device (N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -628,17 +707,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != max(1, args.gpus) and rank == 0:
         print("bench.py: note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus), file=sys.stderr)
-    dist = None
+    grp = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        from speaker_recognition_amd import rendezvous
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         sys.stdout.flush()
         keep = os.dup(1)
-        os.dup2(2, 1)                                    # gloo announces its connections on stdout: ONE JSON line is the contract
+        os.dup2(2, 1)                                    # (gloo announces its connections on stdout: ONE JSON line is the contract)
         try:
-            dist.init_process_group(backend="gloo")      # host-side barrier / reduction only
-            dist.barrier()
+            grp = rendezvous.init(args.rendezvous)       # host-side barrier / gather only; the default imports no torch
+            grp.barrier()
         finally:
             sys.stdout.flush()
             os.dup2(keep, 1)
@@ -651,6 +729,7 @@ def main():
     if dev >= _lib.device_count():
         sys.exit("bench.py: rank %d wants device %d but only %d visible" % (rank, dev, _lib.device_count()))
     _lib.set_device(dev)
+    numa_node = _lib.bind_thread_near_device(dev)          # this rank's host thread next to its GPU's PCIe root (-1: platform does not say)
     ex = MfccExtractor(FS, **MFCC_KW)
     L, shift = ex.FRAME_LEN, ex.FRAME_SHIFT
     n_samples = (FRAMES_PER_UTT + ND - 1) * shift + L
@@ -668,8 +747,8 @@ def main():
 
     def barrier():
         _lib.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if grp is not None:
+            grp.barrier()
 
     # the results of consecutive steps go into two page-locked buffers in turn, as a serving loop would keep them (fresh numpy
     # arrays are 16 MB of page faults and a staged copy per step: 0.2 ms of the ~3.3 ms a step spends outside its kernels; the last
@@ -681,6 +760,18 @@ def main():
     _lib.profile_enable(True)      # HIP-event kernel timers (pre-warms the runtime's event pool once)
     for i in range(args.warmup):
         step(i)
+    # N > 1: rank 0 runs the same step ALONE first (the others wait), so that the line carries its own weak-scaling reference
+    alone_rate = None
+    if grp is not None:
+        barrier()
+        if rank == 0:
+            k = max(1, min(3, args.steps))
+            t0 = time.perf_counter()
+            for i in range(k):
+                step(i)
+            _lib.synchronize()
+            alone_rate = n_frames * k / (time.perf_counter() - t0)
+        barrier()
     _lib.profile_reset()           # timed region starts with zeroed timers
     fl0 = _lib.flush_stats()
     barrier()
@@ -691,13 +782,12 @@ def main():
     elapsed = time.perf_counter() - t0
     prev = outs[args.steps & 1][0] if args.steps > 1 else None       # the step before the last
     rank_rate = n_frames * args.steps / elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        rates = [None] * world
-        dist.all_gather_object(rates, rank_rate)
+    if grp is not None:
+        elapsed = grp.all_max(elapsed)
+        info = grp.all_gather({"rate": rank_rate, "device": dev, "numa_node": numa_node})
+        rates = [v["rate"] for v in info]
     else:
+        info = [{"rate": rank_rate, "device": dev, "numa_node": numa_node}]
         rates = [rank_rate]
     kt = kernel_times(_lib, args.steps)
     kname = _lib.last_score_kernel()
@@ -705,38 +795,34 @@ def main():
     # ---- N > 1: north_star's configs[3] split -- the N ranks share the 100 M frames (strong scaling), every rank with
     #      the whole 2048-mixture UBM + 1000 speakers; wall time = the slowest rank's
     strong = None
-    if dist is not None and not args.no_config_blocks:
+    one_process = None
+    if grp is not None and not args.no_config_blocks:
         del pcm
         mine = block_cfg3(_lib, None, None, world, rank, barrier, args.cfg3_total_frames)
-        t = torch.tensor([mine["s_per_pass"]], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, {"frames": mine["frames"], "s_per_pass": mine["s_per_pass"], "own_speaker_wins": mine["parity"]["own_speaker_wins"]})
+        wall = grp.all_max(mine["s_per_pass"])
+        per_rank = grp.all_gather({"frames": mine["frames"], "s_per_pass": mine["s_per_pass"], "own_speaker_wins": mine["parity"]["own_speaker_wins"]})
         strong = {"workload": "BASELINE.json configs[3] at its stated size: 2048-mixture UBM + 1000 MAP speakers, 100 M frames split by utterance "
                               "over %d ranks (strong scaling; models replicated; no collective on the data path)" % world,
-                  "frames_total": sum(p["frames"] for p in per_rank), "stated_frames": CFG3_TOTAL_FRAMES, "n_gpus": world, "wall_s": float(t[0]),
-                  "frames_per_s": sum(p["frames"] for p in per_rank) / float(t[0]), "per_rank": per_rank,
+                  "frames_total": sum(p["frames"] for p in per_rank), "stated_frames": CFG3_TOTAL_FRAMES, "n_gpus": world, "wall_s": wall,
+                  "frames_per_s": sum(p["frames"] for p in per_rank) / wall, "per_rank": per_rank,
                   "roofline_rank0": mine["roofline"], "scaling": "strong"}
+        # the ONE-process path over the same N devices (a host thread + model replica per GPU, PCM from page-locked host memory in
+        # every call): rank 0 drives it while the other ranks idle at the barrier below
+        if rank == 0:
+            try:
+                one_process = block_one_process_multi(_lib, base, world, args.device_override)
+            except Exception as e:
+                one_process = {"error": "%s: %s" % (type(e).__name__, e)}
+        grp.barrier()
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
+        if grp is not None:
+            grp.barrier()
         return
 
     hbm = _lib.hbm_copy_gbps(1 << 30, 10)
     # what the matrix pipe sustains on this box under its power cap: a kernel of v_mfma_f32_32x32x16_f16 chains only (csrc/probe.hip)
     sustained = _lib.mfma_peak_probe(60.0)
-    # the same step WITH the feature/scoring pipelining (8 chunks of utterances, feature kernels of chunk i+1.. on a
-    # second stream under the scoring of chunk i): an option, off by default because it measures slower
     kt1 = kt
-    el8, kt8 = None, None
-    if not args.no_config_blocks and world == 1:
-        _lib.set_option("predict_chunks", 8)
-        step8 = lambda: ex.predict_batch(ms, pcm, nd=ND)       # (fresh outputs: the timed loop's last two results are checked below)
-        step8()
-        _lib.profile_reset()
-        el8, _ = timed(step8, 0, 2, _lib.synchronize)
-        kt8 = kernel_times(_lib, 2)
-        _lib.set_option("predict_chunks", 0)
     score_s = (kt1["gmm_score"]["ms_per_step"] + kt1["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
     result = {
         "metric": "frames/sec scored (MFCC+GMM)",
@@ -761,16 +847,16 @@ def main():
                    "frames_per_gpu": n_frames, "models": S, "mixtures": CFG2_MIX, "dim": DIM,
                    "sharding": "utterances/%d ranks, models replicated, no collective" % world},
         "rank_frames_per_s": rates,
-        "scaling_efficiency_vs_rank0_alone": None,
+        "ranks": info,
+        "rank0_alone_frames_per_s": alone_rate,
+        # weak scaling: N ranks, each with the N = 1 workload; 1.0 = every rank as fast in company as rank 0 alone in this same run
+        "scaling_efficiency_vs_rank0_alone": (world * n_frames * args.steps / elapsed) / (world * alone_rate) if alone_rate else None,
+        "rendezvous": args.rendezvous if world > 1 else None,
         "roofline": score_roofline(kname, n_frames, S, CFG2_MIX, DIM, score_s, hbm),
         "mfcc_roofline": mfcc_roofline(args.utts * (FRAMES_PER_UTT + ND), kt1["mfcc_frames"]["ms_per_step"] * 1e-3, hbm),
         "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt.items()},
         "kernel_launches_per_step": {k: v["launches"] / max(1, args.steps) for k, v in kt.items()},
         "sum_of_kernels_ms": sum(v["ms_per_step"] for v in kt.values()),
-        "pipelined_option": None if kt8 is None else {"predict_chunks": 8, "ms_per_step": 1e3 * el8 / 2, "kernel_ms_per_step": {k: v["ms_per_step"] for k, v in kt8.items()},
-                             "note": "feature kernels of chunk i+1.. on a second stream under the scoring of chunk i (sr_set_option "
-                                     "predict_chunks): built for overlap, measures slower than one pass (the feature kernels starve next to "
-                                     "the scoring kernel), so it is off by default"},
         "hbm_copy_ceiling_GBps": hbm,
         # frames whose log-likelihood sits where the reference's flushes of PARTIAL products decide: noted by the
         # engine per (32-frame tile, model), re-evaluated with the reference's own arithmetic inside the timed step (csrc/gmm_flush.hip)
@@ -792,6 +878,8 @@ def main():
                 "(profiles/r03_h2p_parts.txt). `frac` above stays algorithmic flops / nominal peak."}
     if strong is not None:
         result["configs[3]_strong_scaling"] = strong
+    if one_process is not None:
+        result["one_process_all_devices"] = one_process
     if world == 1 and not args.no_traffic:
         tb, td = measure_traffic(kname.split("<")[0].split()[0], ["--utts", str(args.utts)])
         result["roofline"]["traffic"] = tb
@@ -806,8 +894,15 @@ def main():
             p = os.path.join(tmp, "m%d.model" % i)
             models[i].dump(p)
             files.append(p)
+        all_files = []
+        for i in range(S):
+            p = os.path.join(tmp, "m%d.model" % i)
+            if i not in sample_models:
+                models[i].dump(p)
+            all_files.append(p)
         spec = dict(fs=FS, mfcc_kw=MFCC_KW, nd=ND, n_utt=args.cpu_sample_utts, seconds=10.04, seed=AUDIO_SEED,
-                    n_speakers=CFG2_SPEAKERS, model_files=files, single_core_models=2)
+                    n_speakers=CFG2_SPEAKERS, model_files=files, single_core_models=2,
+                    pool_utts=args.cpu_pool_utts, pool_model_files=all_files)
         cb, err = cpu_baseline_leg(spec)
         if cb is None:
             result["cpu_baseline"] = {"error": err}
@@ -816,21 +911,45 @@ def main():
             sub = ModelSet([GMM.load(f) for f in files])
             dsums, darg = ex.predict_batch(sub, Batch.from_pcm(sample), nd=ND)
             csums = np.array(cb["sums"])
-            scale = S / float(len(files))                  # the CPU leg scored len(files) of the S models
+            scale = S / float(len(files))                  # the single-call leg scored len(files) of the S models
             t_total = (cb["t_mfcc_pool_s"] or cb["t_mfcc_s"]) + cb["t_gmm_s"] * scale
-            result["cpu_baseline"] = {
-                "value": cb["n_frames"] / t_total, "unit": "frames/s", "cores": cb["cores"], "kind": cb["kind"],
-                "sample": "%d utterances x 10.04 s (%d frames) of the same workload; GMM: the reference's compiled C++ score_batch "
-                          "(concurrency = cores) on %d of the %d models, scaled linearly to all of them; MFCC: float64 numpy "
-                          "restatement of MFCC.py through multiprocessing.Pool(%d)" % (spec["n_utt"], cb["n_frames"], len(files), S, cb["pool_procs"]),
-                "gmm_frames_per_s_all_models": cb["gmm_frames_per_s"] / scale,
-                "gmm_frames_per_s_all_models_concurrency_1": (cb["gmm_frames_per_s_1core"] / scale) if cb["gmm_frames_per_s_1core"] else None,
-                "mfcc_frames_per_s_pool": cb["mfcc_frames_per_s_pool"], "mfcc_frames_per_s_1proc": cb["mfcc_frames_per_s_1proc"],
-            }
+            single = {"value": cb["n_frames"] / t_total, "unit": "frames/s", "cores": cb["cores"],
+                      "sample": "%d utterances x 10.04 s (%d frames); GMM: ONE score_batch call per model with concurrency = cores (the reference's "
+                                "thread pool inside the call, gmm.cc:533-560) on %d of the %d models, scaled linearly to all of them; MFCC: float64 "
+                                "numpy restatement of MFCC.py through multiprocessing.Pool(%d)" % (spec["n_utt"], cb["n_frames"], len(files), S, cb["pool_procs"]),
+                      "gmm_frames_per_s_all_models": cb["gmm_frames_per_s"] / scale,
+                      "gmm_frames_per_s_all_models_concurrency_1": (cb["gmm_frames_per_s_1core"] / scale) if cb["gmm_frames_per_s_1core"] else None,
+                      "mfcc_frames_per_s_pool": cb["mfcc_frames_per_s_pool"], "mfcc_frames_per_s_1proc": cb["mfcc_frames_per_s_1proc"]}
             result["parity"].update({
                 "cpu_sample_argmax_mismatches": int(np.sum(darg != np.array(cb["argmax"]))),
                 "cpu_sample_max_rel_sum_diff": float(np.max(np.abs(dsums - csums) / np.maximum(1.0, np.abs(csums)))),
                 "cpu_sample": "%d utterances x %d models vs the reference's C++ scorer on the float64 numpy MFCC" % (spec["n_utt"], len(files))})
+            pool = cb.get("pool")
+            if pool and "error" not in pool:
+                # the reference at its best on this host: its own driver's parallelism (a process pool over utterances,
+                # test-gmm.py:128-133), all 201 models, every core busy -- and the end-to-end parity sample that goes with it
+                psample = [synth.synth_speech(u % CFG2_SPEAKERS, 10.04, FS, seed=AUDIO_SEED + u) for u in range(pool["utterances"])]
+                psums, parg = ex.predict_batch(ms, Batch.from_pcm(psample), nd=ND)
+                want = np.array(pool["sums"])
+                result["cpu_baseline"] = {
+                    "value": pool["frames_per_s"], "unit": "frames/s", "cores": cb["cores"], "cores_busy": pool["processes"], "kind": cb["kind"],
+                    "sample": "%d utterances x 10.04 s (%d frames) of the same workload, ALL %d models: the reference's compiled C++ score_batch "
+                              "(concurrency = 1 per call) over %d (utterance, %d-model group) tasks on a multiprocessing.Pool(%d) -- the parallelism "
+                              "of the reference's own drivers (src/test/test-gmm.py:128-133) -- + the float64 numpy restatement of MFCC.py on "
+                              "the same pool" % (pool["utterances"], pool["frames"], pool["models"], pool["tasks"], pool["models_per_task"], pool["processes"]),
+                    "gmm_frames_per_s_all_models": pool["gmm_frames_per_s_all_models"], "mfcc_frames_per_s": pool["mfcc_frames_per_s"],
+                    "t_gmm_pool_s": pool["t_gmm_pool_s"], "t_mfcc_pool_s": pool["t_mfcc_pool_s"],
+                    "single_call_concurrency_cores": single}
+                result["parity"]["end_to_end_cpu_pool_sample"] = {
+                    "utterances": pool["utterances"], "models": pool["models"],
+                    "argmax_mismatches": int(np.sum(parg != np.array(pool["argmax"]))),
+                    "max_rel_sum_diff": float(np.max(np.abs(psums - want) / np.maximum(1.0, np.abs(want)))),
+                    "what": "device: PCM -> MFCC -> CMVN/deltas -> all models; CPU: float64 restatement of MFCC.py -> the reference's compiled "
+                            "C++ scorer (its own remez5 exp); per-utterance sums and argmax"}
+            else:
+                single["kind"] = cb["kind"]
+                single["pool_leg"] = pool
+                result["cpu_baseline"] = single
     if world == 1 and not args.no_config_blocks:
         blocks, preq = {}, {}
         # headline parity for the pool of host cores: the first 200 utterances x ALL 201 models -- per frame on their own
@@ -846,13 +965,14 @@ def main():
         except Exception as e:
             result["parity"]["headline_sample_error"] = "%s: %s" % (type(e).__name__, e)
         del pcm
-        for name, fn in (("configs[1]", lambda: block_cfg1(_lib, ex, base, hbm, preq)),
+        for name, fn in (("serving_small_batch", lambda: block_serving_small(_lib, ex, base, ms, S, CFG2_MIX, hbm)),
+                         ("configs[1]", lambda: block_cfg1(_lib, ex, base, hbm, preq)),
                          ("configs[3]_rank_shard", lambda: block_cfg3(_lib, hbm, preq, total_frames=args.cfg3_total_frames)),
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
                          ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
                          ("reference_published_em", lambda: block_published_em(_lib)),
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
-                         ("sr_multi_predict_pcm_2_slots", lambda: block_multi_slot(_lib, ex, base)),
+                         ("sr_multi_predict_pcm_host_pcm", lambda: block_multi_slot(_lib, ex, base)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
             if os.environ.get("SR_BENCH_BLOCKS") and name not in os.environ["SR_BENCH_BLOCKS"].split(","):
                 continue                                    # (experiments: a chosen subset of the blocks)
@@ -873,14 +993,16 @@ def main():
                     blocks[name]["parity"] = dict(blocks[name].get("parity") or {}, **v)
                 elif name == "configs[2]_headline":
                     result["parity"]["headline_200_utterances_x_all_models"] = v
+                elif name.startswith("mfcc_"):
+                    result["parity"][name] = v
                 elif name == "_checker":
                     result["parity"]["checker"] = v
         except Exception as e:
             blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
         result["configs"] = blocks
     print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
+    if grp is not None:
+        grp.barrier()
 
 
 if __name__ == "__main__":

@@ -95,6 +95,10 @@ int sr_set_thread_device(int device);
 int sr_get_device(void);
 int sr_device_synchronize(void);
 int sr_device_name(char *buf, int buflen);
+/* NUMA: the node of `device` per sysfs (-1: unknown); sr_bind_thread_near_device pins the CALLING host thread to that node's
+ * cores and returns the node (-1: left alone).  The slot threads of sr_multi_* do it themselves. */
+int sr_device_numa_node(int device);
+int sr_bind_thread_near_device(int device);
 
 /* Model handles beyond the legacy constructors. */
 void sr_free_gmm(GMM *gmm);
@@ -205,6 +209,7 @@ int sr_host_register(void *p, size_t bytes);
 int sr_host_unregister(void *p);
 int sr_multi_slots(SRMulti *m);
 int sr_multi_slot_device(SRMulti *m, int slot);
+int sr_multi_slot_numa_node(SRMulti *m, int slot);      /* where the slot's host thread was pinned in its last pass (-1: nowhere) */
 int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_offsets, int n_utt,
                          int nd, double *sums_out /*[U][S]*/, int *argmax_out /*[U]*/,
                          double *slot_seconds_out, int flags);

@@ -8,6 +8,14 @@ The CPU leg of bench.py: on a bounded sample of the bench workloa
 * the float64 numpy restatement of its MFCC.py (oracle/mfcc_oracle.py) single-process AND through
   ``multiprocessing.Pool(nproc)`` over utterances (what test-gmm.py:128-133 / :207-212 does);
 
+* and -- "pool_utts" > 0 -- the reference at its best on this host: the way its own drivers use the
+  cores, a multiprocessing.Pool over utterances (src/test/test-gmm.py:128-133), here over (utterance,
+  group of models) tasks so that every core has work: each worker loads the reference DSO and the
+  models it needs once and calls ``score_batch(..., concurrency = 1)``; features from the Pool'd MFCC
+  leg; ALL the models, >= 64 utterances.  Its rate is what bench.py reports as ``cpu_baseline.value``
+  (the single-call concurrency = cores figure stays beside it), and its per-utterance sums / argmax
+  are the end-to-end parity sample (reference MFCC.py restatement -> reference DSO);
+
 and prints one JSON line with the per-utterance sums and argmax, so that bench.py can compare the
 device path on exactly this sample.  Run as a subprocess so that the reference DSO's -ffast-math
 FTZ/DAZ switch and its thread pool stay out of the benchmark process.  Falls back to the C
@@ -31,11 +39,79 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 _SPEC = None
+_POOL_FEATS = None        # the Pool leg's utterances (float64 [T, D] each), inherited by its forked workers
+_POOL_PATHS = None
+_POOL_STATE = {}          # per worker: the reference library and the model handles it has loaded
 
 
 def _extract(p):
     from oracle import mfcc_oracle as mo
     return mo.extract(_SPEC["fs"], p, diff=_SPEC["nd"] > 0, nd=max(1, _SPEC["nd"]), **_SPEC["mfcc_kw"])
+
+
+def _pool_score(task):
+    """(utterance, first model, one past the last) -> (utterance, first model, [sum of per-frame LL per model])"""
+    from oracle import gmm_oracle as go
+    u, s0, s1 = task
+    st = _POOL_STATE
+    if "ref" not in st:
+        st["ref"] = go.RefLib()
+        st["handles"] = {}
+        st["rows"] = {}
+    ref = st["ref"]
+    if u not in st["rows"]:
+        st["rows"] = {u: ref.rows(_POOL_FEATS[u])}              # (one utterance's row pointers at a time)
+    rows, keep = st["rows"][u]
+    n, d = keep.shape
+    out = np.empty(n)
+    outp = out.ctypes.data_as(go.C.POINTER(go.C.c_double))
+    sums = []
+    for s in range(s0, s1):
+        h = st["handles"].get(s)
+        if h is None:
+            h = st["handles"][s] = ref.load(_POOL_PATHS[s])
+        ref.lib.score_batch(h, rows, outp, n, d, 1)
+        sums.append(float(out.sum()))
+    return u, s0, sums
+
+
+def pool_leg(spec, cores):
+    """The reference DSO over (utterance, model group) tasks on a Pool of all cores + the MFCC restatement on the same Pool size."""
+    global _POOL_FEATS, _POOL_PATHS
+    from oracle import gmm_oracle as go
+    from speaker_recognition_amd import synth
+    U = int(spec["pool_utts"])
+    n_spk = spec.get("n_speakers", 1)
+    pcm = [synth.synth_speech(u % n_spk, spec["seconds"], spec["fs"], seed=spec["seed"] + u) for u in range(U)]
+    procs = max(1, min(cores, U))
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_extract, pcm[:procs])                           # start-up outside the timed part
+        t0 = time.perf_counter()
+        feats = pool.map(_extract, pcm)
+        t_mfcc = time.perf_counter() - t0
+    # (the device scores fp32 features; so does this leg, as the other one)
+    _POOL_FEATS = [np.ascontiguousarray(f.astype(np.float32).astype(np.float64)) for f in feats]
+    _POOL_PATHS = list(spec["pool_model_files"])
+    S = len(_POOL_PATHS)
+    n_frames = int(sum(len(f) for f in _POOL_FEATS))
+    if not os.path.exists(go.REF_SO):
+        return None
+    # model groups: about 4 tasks per core, no group larger than 16 models (a straggler's length)
+    groups_per_utt = max(1, min(S, -(-4 * cores // U)))
+    gsz = max(1, min(16, -(-S // groups_per_utt)))
+    tasks = [(u, s0, min(S, s0 + gsz)) for u in range(U) for s0 in range(0, S, gsz)]
+    procs = max(1, min(cores, len(tasks)))
+    sums = np.zeros((U, S))
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_pool_score, [(u % U, 0, 1) for u in range(procs)], chunksize=1)     # DSO load + first model, untimed
+        t0 = time.perf_counter()
+        for u, s0, part in pool.imap_unordered(_pool_score, tasks, chunksize=1):
+            sums[u, s0:s0 + len(part)] = part
+        t_gmm = time.perf_counter() - t0
+    return {"utterances": U, "models": S, "frames": n_frames, "processes": procs, "tasks": len(tasks), "models_per_task": gsz,
+            "t_mfcc_pool_s": t_mfcc, "t_gmm_pool_s": t_gmm, "frames_per_s": n_frames / (t_mfcc + t_gmm),
+            "gmm_frames_per_s_all_models": n_frames / t_gmm, "mfcc_frames_per_s": n_frames / t_mfcc,
+            "sums": sums.tolist(), "argmax": np.argmax(sums, axis=1).tolist()}
 
 
 def main():
@@ -69,6 +145,15 @@ def main():
         t_pool = None
     X = np.ascontiguousarray(np.concatenate(feats).astype(np.float32).astype(np.float64))
     off = np.concatenate([[0], np.cumsum([len(f) for f in feats])])
+
+    # the Pool leg first: this process has not loaded the reference DSO yet (its -ffast-math start-up code switches FTZ / DAZ on
+    # for the thread, and forked workers would inherit that into their MFCC arithmetic)
+    pool = None
+    if spec.get("pool_utts", 0) > 0 and spec.get("pool_model_files"):
+        try:
+            pool = pool_leg(spec, cores)
+        except Exception as e:                                    # the single-call leg still stands
+            pool = {"error": "%s: %s" % (type(e).__name__, e)}
 
     tmp = tempfile.mkdtemp()
     if spec.get("model_files"):
@@ -114,6 +199,7 @@ def main():
         t_gmm = time.perf_counter() - t0
         kind, used = "port", 1
     print(json.dumps({
+        "pool": pool,
         "kind": kind, "cores": used, "n_frames": n_frames, "n_models": S,
         "t_mfcc_s": t_mfcc, "t_mfcc_pool_s": t_pool, "pool_procs": procs, "t_gmm_s": t_gmm, "t_gmm_1core_s": t_gmm_1,
         "frames_per_s": n_frames / ((t_pool if t_pool else t_mfcc) + t_gmm),

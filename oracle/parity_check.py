@@ -9,7 +9,16 @@ Checker leg of bench.py.  Reads a pickle {name: spec} with
     "offsets"           int[U + 1]
     "device_sums"       float64[U, S]   (optional)   "device_frame_ll"  float32[S, n]  (optional)
 
-scores every frame under every model with the C restatement of the reference's arithmetic (oracle/gmm_oracle.c mode 3 =
+or, for the FEATURE stage (spec key "kind": "mfcc"),
+
+    "pcm"               int16[n_samples]   concatenated utterances     "sample_offsets"  int[U + 1]
+    "fs", "mfcc_kw", "nd"                  the extractor's parameters
+    "device_feats"      float32[n_frames, D]  what the device produced (MFCC -> CMVN -> deltas)   "offsets" int[U + 1]
+
+runs the float64 numpy restatement of the reference's MFCC.py / utils.py (oracle/mfcc_oracle.py) on every utterance -- Pool over
+utterances, as src/test/test-gmm.py:207-212 -- and reports max / mean |device - oracle| (SURVEY.md 8d gates: 1e-3 / 1e-5).
+
+The GMM specs: scores every frame under every model with the C restatement of the reference's arithmetic (oracle/gmm_oracle.c mode 3 =
 mode 0, what the reference's C ABI computes, to remez5's 1.2e-6: score_batch_fast) on ALL host cores --
 multiprocessing.Pool over (model, frame range) tasks, the shape of the reference's own test driver
 (src/test/test-gmm.py:128-133) -- and prints one JSON line {name: {...}}: worst per-frame and per-utterance relative
@@ -73,11 +82,35 @@ def _task(t):
     return name, s, worst, clamp_bad, parts
 
 
+def _mfcc_task(t):
+    """(name, utterance) -> (name, max |diff|, sum |diff|, count) of the device's features against mfcc_oracle"""
+    from oracle import mfcc_oracle as mo
+    name, u = t
+    r = _REQ[name]
+    so, fo = r["sample_offsets"], r["offsets"]
+    ref = mo.extract(r["fs"], r["pcm"][so[u]:so[u + 1]], diff=r["nd"] > 0, nd=max(1, r["nd"]), **r["mfcc_kw"])
+    dev = r["device_feats"][fo[u]:fo[u + 1]].astype(np.float64)
+    if ref.shape != dev.shape:
+        return name, float("inf"), float("inf"), 1
+    d = np.abs(dev - ref)
+    return name, float(d.max()) if d.size else 0.0, float(d.sum()), int(d.size)
+
+
 def main():
     from oracle import gmm_oracle as go
     if not os.path.exists(go.ORACLE_SO):
         go.build(ref=False)
-    req = pickle.load(open(sys.argv[1], "rb"))
+    req_all = pickle.load(open(sys.argv[1], "rb"))
+    mfcc_req = {k: v for k, v in req_all.items() if v.get("kind") == "mfcc"}
+    req = {k: v for k, v in req_all.items() if v.get("kind") != "mfcc"}
+    mfcc_tasks = []
+    for name, r in mfcc_req.items():
+        r["pcm"] = np.asarray(r["pcm"])
+        r["sample_offsets"] = np.asarray(r["sample_offsets"], dtype=np.int64)
+        r["offsets"] = np.asarray(r["offsets"], dtype=np.int64)
+        r["device_feats"] = np.asarray(r["device_feats"], dtype=np.float32)
+        _REQ[name] = r
+        mfcc_tasks += [(name, u) for u in range(len(r["sample_offsets"]) - 1)]
     tasks = []
     for name, r in req.items():
         if "models" not in r:
@@ -92,15 +125,27 @@ def main():
                 tasks.append((name, s, f0, min(n, f0 + FRAME_CHUNK)))
         _REQ[name] = r
     cores = os.cpu_count() or 1
-    procs = max(1, min(cores, len(tasks)))
+    procs = max(1, min(cores, len(tasks) + len(mfcc_tasks)))
     t0 = time.perf_counter()
+    mfcc_results = []
     if procs > 1:
         with mp.get_context("fork").Pool(procs) as pool:
-            results = pool.map(_task, tasks, chunksize=max(1, len(tasks) // (8 * procs)))
+            results = pool.map(_task, tasks, chunksize=max(1, len(tasks) // (8 * procs))) if tasks else []
+            if mfcc_tasks:
+                mfcc_results = pool.map(_mfcc_task, mfcc_tasks, chunksize=1)
     else:
         results = [_task(t) for t in tasks]
+        mfcc_results = [_mfcc_task(t) for t in mfcc_tasks]
     elapsed = time.perf_counter() - t0
     out = {}
+    for name, r in mfcc_req.items():
+        mine = [x for x in mfcc_results if x[0] == name]
+        n = sum(x[3] for x in mine)
+        out[name] = {"utterances": len(mine), "frames": int(len(r["device_feats"])), "dims": int(r["device_feats"].shape[1]) if r["device_feats"].ndim == 2 else 0,
+                     "max_abs_diff_vs_oracle": max(x[1] for x in mine) if mine else None,
+                     "mean_abs_diff_vs_oracle": (sum(x[2] for x in mine) / n) if n else None,
+                     "gates": "SURVEY.md 8d: max <= 1e-3, mean <= 1e-5 after CMVN (the deltas, up to 4 x a term's error, are in the figures)",
+                     "oracle": "oracle/mfcc_oracle.py (float64 numpy restatement of MFCC.py:49-79, utils.py:24-31), Pool over utterances"}
     for name, r in req.items():
         U, S = len(r["offsets"]) - 1, len(r["models"])
         want = np.zeros((U, S))

@@ -20,7 +20,7 @@ LEGACY_SYMBOLS = ["new_gmm", "load", "dump", "train_model", "train_model_from_ub
                   "score_batch", "score_instance", "get_dim", "get_nr_mixtures"]
 EXT_SYMBOLS = [
     "sr_last_error", "sr_gpu_runtime_lost", "sr_device_count", "sr_set_device", "sr_set_thread_device", "sr_get_device", "sr_device_synchronize",
-    "sr_device_name", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
+    "sr_device_name", "sr_device_numa_node", "sr_bind_thread_near_device", "sr_multi_slot_numa_node", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
     "sr_gmm_loads", "sr_score_frames_f32", "sr_modelset_create", "sr_modelset_free",
     "sr_modelset_size", "sr_modelset_info", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
     "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_reset_pcm", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
@@ -87,6 +87,9 @@ def lib():
         "sr_get_device": (i32, []),
         "sr_device_synchronize": (i32, []),
         "sr_device_name": (i32, [C.c_char_p, i32]),
+        "sr_device_numa_node": (i32, [i32]),
+        "sr_bind_thread_near_device": (i32, [i32]),
+        "sr_multi_slot_numa_node": (i32, [vp, i32]),
         "sr_free_gmm": (None, [vp]),
         "sr_gmm_from_arrays": (vp, [i32, i32, dp, dp, dp]),
         "sr_gmm_get_params": (i32, [vp, dp, dp, dp]),
@@ -213,6 +216,11 @@ def hbm_copy_gbps(nbytes: int = 1 << 30, iters: int = 10) -> float:
 
 def device_count() -> int:
     return int(lib().sr_device_count())
+
+
+def bind_thread_near_device(device: int) -> int:
+    """Pin the calling host thread to the cores of `device`'s NUMA node (sysfs); -> the node, -1 when left alone."""
+    return int(lib().sr_bind_thread_near_device(int(device)))
 
 
 def device_name() -> str:

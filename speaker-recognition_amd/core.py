@@ -290,6 +290,10 @@ class MultiPredictor:
     def slot_devices(self):
         return [lib().sr_multi_slot_device(self._h, i) for i in range(self.n_slots)]
 
+    def slot_numa_nodes(self):
+        """NUMA node every slot's host thread pinned itself to in the last call (-1: the platform does not say)."""
+        return [lib().sr_multi_slot_numa_node(self._h, i) for i in range(self.n_slots)]
+
     def predict(self, signals, nd=0, clamp_compat=True):
         """``signals``: list of int16 arrays.  -> (sums[U, S], argmax[U])."""
         sigs = [np.ascontiguousarray(s, dtype=np.int16) for s in signals]

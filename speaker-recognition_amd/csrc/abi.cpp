@@ -25,6 +25,9 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
 void set_em_stats_engine(int v);
 void set_reference_side_effects(int v);
 void set_kmeans_assign_engine(int v);
+}
+std::atomic<int> &stream_debug_capture_delay_ms();      // stream.cpp
+namespace sr {
 void kmeans_fast_stats(long *passes, long *rechecked);
 int reference_side_effects();
 }  // namespace sr
@@ -321,6 +324,24 @@ int sr_device_name(char *buf, int buflen) {
     SR_CATCH(-1)
 }
 
+int sr_device_numa_node(int device) {
+    try {
+        return device_numa_node(device);
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+
+int sr_bind_thread_near_device(int device) {
+    try {
+        return bind_thread_near_device(device);
+    } catch (const std::exception &e) {
+        set_error("%s", e.what());
+        return -1;
+    }
+}
+
 void sr_free_gmm(GMM *gmm) { delete gmm; }
 
 GMM *sr_gmm_from_arrays(int K, int D, const double *weights, const double *mean, const double *sigma) {
@@ -575,24 +596,12 @@ SRBatch *sr_mfcc_extract_batch(SRMfcc *m, SRBatch *pcm, int nd, int cmvn) {
     SR_CATCH(nullptr)
 }
 
-// The fused serving step.  Optionally pipelined ("predict_chunks" n): the batch is cut into n chunks of
-// whole utterances, the feature stage (MFCC -> CMVN/deltas) of every chunk runs on the device's second
-// stream, and the scoring of chunk i on the main stream starts as soon as its features are there --
-// the feature kernels (vector ALU + LDS) of chunk i+1.. under the scoring kernel (matrix cores) of
-// chunk i.  Built for VERDICT r1 item 4 and measured slower than one pass on this chip (see below).
-struct PredictPipe {
-    static constexpr int MAX_CHUNKS = MFCC_SLOTS - 1;
-    SRBatch feat[MAX_CHUNKS];
-    hipEvent_t ready[MAX_CHUNKS] = {};
-    PinnedBuf<double> sums;
-    PinnedBuf<int> argmax, oor;
-};
-
-static int &predict_chunks_option() {
-    static int v = 0;       // 0 = automatic, 1 = one pass (no pipelining), n = that many chunks
-    return v;
-}
-
+// The fused serving step: PCM batch -> MFCC -> CMVN / deltas -> all models -> sums + argmax on the host, one pass.
+// (Rounds 1-3 carried an option that cut the batch into chunks and ran the feature kernels of chunk i + 1 on a second stream under the
+// scoring of chunk i.  It measured slower on every workload -- configs[1] 5.12 ms in one pass against 5.17 / 5.43 / 5.87 ms with 2 / 4 /
+// 8 chunks, configs[2] 337 against 350 ms and later 267 against 538: next to the power-capped scoring kernel the feature launches stretch
+// from 20 to 271 ms and the scoring chunks pay their tails, profiles/r02_overlap.txt -- and its second stream did not wait for the
+// uploads of sr_multi_predict_pcm's pieces.  Removed in round 4.)
 static void predict_unpipelined(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out, int *argmax_out,
                                 int flags) {
     SRBatch *feat_ws = &per_device<SRBatch>();   // reused across steps: the serving loop allocates nothing
@@ -611,77 +620,7 @@ namespace sr {
 void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out, int *argmax_out, int flags) {
     if (!m || !set || !pcm) fail("null argument");
     ensure_device();
-    const int U = pcm->n_utt;
-    const int S = set->host.n_models;
-    int64_t total_frames = 0;
-    for (int u = 0; u < U; u++) total_frames += mfcc_num_frames(*m, pcm->offsets[u + 1] - pcm->offsets[u]);
-    // Measured (scripts/debug/overlap_try.py, profiles/r02_overlap.txt): on configs[1] 5.12 ms per step in one
-    // pass against 5.17 / 5.43 / 5.87 ms with 2 / 4 / 8 chunks, on configs[2] 337 against 350 ms with 8 -- the
-    // feature kernels starve next to the scoring kernel (270 ms of MFCC launches instead of 20) and the scoring
-    // chunks pay their tails, so the pipelining is OFF unless asked for ("predict_chunks" n >= 2).
-    int chunks = predict_chunks_option();
-    (void)total_frames;
-    if (chunks == 0) chunks = 1;
-    chunks = std::max(1, std::min(std::min(chunks, PredictPipe::MAX_CHUNKS), U / 8));
-    if (m->n_lpc > 0) chunks = 1;
-    if (chunks <= 1) {
-        predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags);
-        return;
-    }
-    auto &pp = per_device<PredictPipe>();
-    // chunk boundaries: whole utterances, about equal sample counts
-    int bound[PredictPipe::MAX_CHUNKS + 1];
-    bound[0] = 0;
-    const int64_t total = pcm->offsets[U] - pcm->offsets[0];
-    for (int c = 1; c < chunks; c++) {
-        const int64_t want = pcm->offsets[0] + total * c / chunks;
-        int u = (int)(std::lower_bound(pcm->offsets.begin(), pcm->offsets.end(), want) - pcm->offsets.begin());
-        bound[c] = std::max(bound[c - 1], std::min(u, U));
-    }
-    bound[chunks] = U;
-    pp.sums.ensure((size_t)std::max(1, U) * S);
-    pp.argmax.ensure((size_t)std::max(1, U));
-    pp.oor.ensure(2 * PredictPipe::MAX_CHUNKS);
-    for (int c = 0; c < chunks; c++) {
-        if (!pp.ready[c]) SR_HIP(hipEventCreateWithFlags(&pp.ready[c], hipEventDisableTiming));
-        pp.oor.p[c] = pp.oor.p[PredictPipe::MAX_CHUNKS + c] = 0;
-    }
-    {
-        StreamScope feature_stage(ctx().aux);
-        for (int c = 0; c < chunks; c++) {
-            mfcc_extract_range(*m, *pcm, bound[c], bound[c + 1], nd, 1, pp.feat[c], 1 + c);
-            SR_HIP(hipEventRecord(pp.ready[c], ctx().stream));
-        }
-    }
-    for (int c = 0; c < chunks; c++) {
-        const int u0 = bound[c], n = bound[c + 1] - bound[c];
-        if (n == 0) continue;
-        SR_HIP(hipStreamWaitEvent(ctx().stream, pp.ready[c], 0));
-        const ScoreResult r = score_device(*set, pp.feat[c], false, flags);
-        SR_HIP(hipMemcpyAsync(pp.sums.p + (size_t)u0 * S, r.d_sums, (size_t)n * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
-        SR_HIP(hipMemcpyAsync(pp.argmax.p + u0, r.d_argmax, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-        if (r.d_oor) SR_HIP(hipMemcpyAsync(pp.oor.p + c, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-        if (r.d_flush_count)
-            SR_HIP(hipMemcpyAsync(pp.oor.p + PredictPipe::MAX_CHUNKS + c, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-    }
-    sync_stream();
-    bool saturated = false, band = false;
-    for (int c = 0; c < chunks; c++) {
-        saturated |= pp.oor.p[c] != 0;
-        band |= pp.oor.p[PredictPipe::MAX_CHUNKS + c] != 0;
-    }
-    if (band && !saturated) {
-        // frames in the band where the reference's partial-product flushes decide (lse.hpp): one pass, resolved there
-        predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags);
-        return;
-    }
-    if (saturated) {
-        // a frame left the fp16 engine's range: the whole batch again, one pass, fp32-grade engines
-        predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags | SCORE_PRECISE);
-        return;
-    }
-    if (sums_out && U) std::memcpy(sums_out, pp.sums.p, (size_t)U * S * sizeof(double));
-    if (argmax_out && U) std::memcpy(argmax_out, pp.argmax.p, (size_t)U * sizeof(int));
+    predict_unpipelined(m, set, pcm, nd, sums_out, argmax_out, flags);
 }
 }  // namespace sr
 
@@ -791,9 +730,6 @@ int sr_set_option(const char *key, long value) {
             fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores), "
                  "4 (split-bf16, shared-sigma form), 5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form)");
         score_options().engine = (int)value;
-    } else if (k == "predict_chunks") {
-        if (value < 0 || value > PredictPipe::MAX_CHUNKS) fail("predict_chunks must be 0 (automatic) .. %d", PredictPipe::MAX_CHUNKS);
-        predict_chunks_option() = (int)value;
     } else if (k == "score_h2s_tiles_per_launch") {
         if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
         score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
@@ -831,6 +767,9 @@ int sr_set_option(const char *key, long value) {
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
+    } else if (k == "debug_capture_delay_ms") {
+        if (value < 0 || value > 1000) fail("debug_capture_delay_ms must be 0 .. 1000");
+        stream_debug_capture_delay_ms().store((int)value);         // test hook (tests/test_gpu_pipeline.py)
     } else if (k == "mfcc_generic") {
         mfcc_set_force_generic(value != 0);
     } else {

@@ -5,7 +5,11 @@
 #include <new>
 
 #include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
 
 namespace sr {
 
@@ -141,6 +145,60 @@ void ensure_device() {
     SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].copy, hipStreamNonBlocking));
     g_ctx[d].stream = g_ctx[d].main;
     g_ready[d] = true;
+}
+
+// ---------------- NUMA ----------------
+static bool read_small_file(const std::string &path, char *buf, size_t cap) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+
+int device_numa_node(int device) {
+    static int cache[MAX_DEVICES];
+    static bool have[MAX_DEVICES];
+    check_device_index(device);
+    if (have[device]) return cache[device];
+    int node = -1;
+    if (!gpu_runtime_lost()) {
+        note_gpu_runtime_use();
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+            for (char *c = bus; *c; c++) *c = (char)tolower(*c);          // sysfs spells the address in lower case
+            char txt[64];
+            if (read_small_file(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", txt, sizeof txt)) node = atoi(txt);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    cache[device] = node;
+    have[device] = true;
+    return node;
+}
+
+int bind_thread_near_device(int device) {
+    const int node = device_numa_node(device);
+    if (node < 0) return -1;
+    char txt[4096];
+    if (!read_small_file("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", txt, sizeof txt)) return -1;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_set = 0;
+    for (char *tok = strtok(txt, ",\n"); tok; tok = strtok(nullptr, ",\n")) {      // "0-63,128-191"
+        int lo = 0, hi = 0;
+        const int got = sscanf(tok, "%d-%d", &lo, &hi);
+        if (got == 1) hi = lo;
+        if (got >= 1)
+            for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) {
+                CPU_SET(c, &set);
+                n_set++;
+            }
+    }
+    if (n_set == 0 || sched_setaffinity(0, sizeof set, &set) != 0) return -1;
+    return node;
 }
 
 StreamScope::StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s; }

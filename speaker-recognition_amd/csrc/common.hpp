@@ -78,6 +78,12 @@ struct Ctx {
     bool profiling = false;
     int n_cu = 256;
 };
+// NUMA: a host thread that feeds a GPU (uploads from its memory, waits on its events) belongs on the cores next to that GPU's
+// PCIe root.  device_numa_node: the node of `device` from sysfs (/sys/bus/pci/devices/<bus id>/numa_node), -1 when the platform
+// does not say; bind_thread_near_device: pins the CALLING thread to that node's cores (sched_setaffinity) and returns the node
+// (-1: left alone).  Used by the slot threads of sr_multi_* and, through sr_bind_thread_near_device, by bench.py's ranks.
+int device_numa_node(int device);
+int bind_thread_near_device(int device);
 Ctx &ctx();             // of the calling thread's current device
 void ensure_device();   // hipSetDevice(current) for THIS thread + lazy stream; throws sr::Error when no usable GPU
 

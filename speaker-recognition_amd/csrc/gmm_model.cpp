@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -310,7 +311,9 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
                 }
                 c *= LOG2E;
                 *cslot = (std::isfinite(c) && c > (double)NEG_BIG) ? (float)c : NEG_BIG;
-                if (std::isfinite(up)) lift[s] = std::max(lift[s], up);
+                // (a degenerate mixture -- sigma 0 or negative: -ln sigma is inf or NaN -- must not lower the band: with an infinite
+                // band every frame of the set goes through the exact partial-product path instead of being silently skipped)
+                lift[s] = std::isfinite(up) ? std::max(lift[s], up) : std::numeric_limits<double>::infinity();
             }
         }
     });

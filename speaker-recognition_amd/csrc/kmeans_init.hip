@@ -723,11 +723,26 @@ std::vector<double> kmeans_parallel_init(const float *X, long n, int dim, int K,
         for (int i = lo; i < hi; i++)
             pdist[i] = std::min(pdist[i], sparse_distsqr(cand.data() + (size_t)i * dim, c, dim) * weight[i]);
     };
-    std::vector<std::thread> pp_workers;
+    // (joined on every way out: an exception between here and the end -- bad_alloc, a fail() -- would otherwise destroy
+    // joinable threads, i.e. std::terminate, with the workers spinning on a round that never comes)
+    std::atomic<bool> abort_workers{false};
+    struct Joiner {
+        std::vector<std::thread> th;
+        std::atomic<bool> &abort;
+        ~Joiner() {
+            abort.store(true, std::memory_order_release);
+            for (auto &t : th)
+                if (t.joinable()) t.join();
+        }
+    } workers{{}, abort_workers};
+    auto &pp_workers = workers.th;
     for (int t = 1; t < pp_threads; t++)
         pp_workers.emplace_back([&, t] {
             for (int k = 1; k < K; k++) {
-                while (round_go.load(std::memory_order_acquire) < k) std::this_thread::yield();
+                while (round_go.load(std::memory_order_acquire) < k) {
+                    if (abort_workers.load(std::memory_order_acquire)) return;
+                    std::this_thread::yield();
+                }
                 upd(t, k);
                 round_done.fetch_add(1, std::memory_order_release);
             }

@@ -830,24 +830,23 @@ int mfcc_waves_per_block() { return mfcc_wpb_flag(); }
 void mfcc_set_waves_per_block(int w) { mfcc_wpb_flag() = (w == 12) ? 12 : 4; }
 void mfcc_set_force_generic(bool on) { mfcc_force_generic_flag() = on; }
 
-struct MfccWorkspace {
+struct MfccScratch {
     DevBuf<float> raw;
     DevBuf<int64_t> raw_off;
     std::vector<int64_t> raw_off_host;   // what raw_off currently holds (skip the upload + sync when unchanged)
 };
-struct MfccWorkspaces {
-    MfccWorkspace slot[MFCC_SLOTS];
-};
-static MfccWorkspace &mws(int slot) { return per_device<MfccWorkspaces>().slot[slot]; }   // leaked on purpose: no hipFree at exit
+MfccScratch *mfcc_scratch_new() { return new MfccScratch(); }
+void mfcc_scratch_delete(MfccScratch *s) { delete s; }
 
 // PCM batch -> feature batch.  `out` is reused when it is large enough (serving loop).
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out) {
-    mfcc_extract_range(m, pcm, 0, pcm.n_utt, nd, cmvn, out, 0);
+    mfcc_extract_with(m, pcm, nd, cmvn, out, &per_device<MfccScratch>());     // (the device's own: leaked on purpose, no hipFree at exit)
 }
 
-void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmvn, SRBatch &out, int slot) {
+void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, MfccScratch *scratch) {
     ensure_device();
-    if (u0 < 0 || u1 > pcm.n_utt || u0 > u1 || slot < 0 || slot >= MFCC_SLOTS) fail("bad utterance range");
+    if (!scratch) fail("null feature workspace");
+    const int u0 = 0, u1 = pcm.n_utt;
     if (pcm.kind != SRBatch::PCM16 && pcm.kind != SRBatch::PCMF32) fail("MFCC needs a PCM batch");
     pcm.bind_device();
     out.bind_device();
@@ -864,7 +863,7 @@ void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmv
         out_off[u + 1] = out_off[u] + std::max<int64_t>(0, T - nd);
     }
     const int64_t NF = raw_off[U];
-    auto &w = mws(slot);
+    auto &w = *scratch;
     w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
     bool uploaded = false;
     if (w.raw_off_host != raw_off) {

@@ -26,10 +26,13 @@ struct SRMfcc {
 namespace sr {
 int64_t mfcc_num_frames(const SRMfcc &m, int64_t n_samples);
 void mfcc_extract_batch(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out);
-// The same for utterances [u0, u1) of `pcm` only, with workspace slot `slot` (1..MFCC_SLOTS-1: the
-// pipelined predict path keeps one per chunk so that alternating shapes do not thrash the cached tables).
-constexpr int MFCC_SLOTS = 9;
-void mfcc_extract_range(SRMfcc &m, SRBatch &pcm, int u0, int u1, int nd, int cmvn, SRBatch &out, int slot);
+// The feature stage's device workspace (raw cepstra + their frame offsets).  mfcc_extract_batch uses the calling device's own;
+// a caller that alternates between batches of different shapes (the pieces of sr_multi_predict_pcm) keeps one per shape so that
+// the cached offset table is not re-uploaded -- and the stream not synchronised -- on every call.
+struct MfccScratch;
+MfccScratch *mfcc_scratch_new();
+void mfcc_scratch_delete(MfccScratch *s);
+void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, MfccScratch *scratch);
 void mfcc_set_force_generic(bool on);
 void mfcc_set_waves_per_block(int w);   // 4 or 12 waves per workgroup in the FFT-2048 kernel
 void lpc_extract_into(SRMfcc &m, SRBatch &pcm, const int64_t *d_frame_off, int64_t n_frames, int n_lpc,

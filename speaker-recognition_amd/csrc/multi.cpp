@@ -30,14 +30,21 @@
 
 using namespace sr;
 
-constexpr int MULTI_CHUNKS = 4;         // a slot's utterances are uploaded and scored in this many pieces
+constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
 
 struct SRMulti {
+    // One piece of a slot's utterances: its PCM on the device, the feature stage's workspace and output, page-locked result
+    // buffers.  Everything a piece needs is its own, so that pieces of different shapes -- and of different slots on one device --
+    // never re-upload a cached table (that would synchronise the stream in the middle of the pipeline).
     struct Chunk {
         std::unique_ptr<SRBatch> pcm;
         PinnedBuf<int16_t> staging;         // only used when the caller's PCM is not page-locked
-        hipEvent_t uploaded = nullptr;
+        hipEvent_t uploaded = nullptr, done = nullptr;
         int u0 = 0, u1 = 0;                 // range of the slot's utterances
+        SRBatch feat;
+        MfccScratch *scratch = nullptr;
+        PinnedBuf<double> h_sums;
+        PinnedBuf<int> h_argmax, h_flags;   // h_flags: {a frame saturated the fp16 engine, (tile, model) pairs in the partial-product band}
     };
     struct Slot {
         int device = 0;
@@ -49,6 +56,7 @@ struct SRMulti {
         std::vector<int> argmax;
         std::string error;
         double seconds = 0.0;               // wall time of the slot's last pass
+        int numa_node = -1;                 // where the slot's host thread was pinned (-1: nowhere)
     };
     std::unique_ptr<SRMfcc> mfcc;           // host tables shared; device tables per GPU inside
     std::deque<Slot> slots;                // (a slot owns page-locked buffers and events: not movable)
@@ -99,30 +107,45 @@ bool host_pinned(const void *p) {
     return at.type == hipMemoryTypeHost;
 }
 
-// One slot: its utterances cut into MULTI_CHUNKS pieces of whole utterances; every piece goes host -> device on the
-// device's copy stream (queued in order: piece 0 first, and behind the pieces of the slots that queued earlier) while the
-// pieces before it are being scored on the main stream -- PCM from pageable caller memory passes through a page-locked
-// staging buffer filled by this thread, one piece ahead of the copy engine; page-locked caller memory is read in place.
-// Scoring takes the device's lock piece by piece, so slots that share a GPU interleave.  (Round 2 copied the whole
-// slot into a std::vector, uploaded it from pageable memory and synchronised before the first kernel: 4.8x the
-// resident-PCM step on the configs[1] workload.)
+// One slot: its utterances cut into up to MULTI_CHUNKS pieces of whole utterances.  Every piece goes host -> device on the
+// device's copy stream (queued in order, an event behind it) -- from the caller's own memory when that is page-locked, else
+// through a page-locked staging buffer this thread fills one piece ahead of the copy engine -- and its kernels (MFCC, CMVN /
+// deltas, all models, finalize) plus the copies of its results into page-locked buffers are ENQUEUED on the main stream behind
+// that event, piece after piece, without a host synchronisation in between: the copy of piece i + 1 runs under the kernels of
+// piece i, and the host waits once, at the end.  (Round 3 scored the pieces one synchronous call each: four waits per slot and a
+// quarter of the PCM uploaded before the first kernel -- 8.8 ms on configs[1] where copy and kernels are 5.8 and 5.7 ms.)  What
+// needs the host in the loop -- a frame that saturated the fp16 engine, frames in the band of the reference's partial-product
+// flushes (lse.hpp) -- is noticed in the piece's flags afterwards and that piece is scored again, synchronously, from its
+// features, which are still on the device (as csrc/stream.cpp does for a serving tick).
+// The device's lock is taken piece by piece, so slots that share a GPU interleave on its stream.
 void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *off, int nd, int flags, bool pinned) {
+    auto drain = [&]() {                   // nothing of this call may still be reading the caller's buffer when it returns
+        try {
+            (void)hipStreamSynchronize(ctx().copy);
+            (void)hipStreamSynchronize(ctx().main);
+        } catch (...) {
+        }
+    };
     try {
         set_thread_device(s.device);
         ensure_device();
+        s.numa_node = bind_thread_near_device(s.device);       // this thread fills staging buffers and waits on this GPU's events
         const auto t0 = std::chrono::steady_clock::now();
         const int U = (int)s.utts.size();
+        const int S = m->n_models;
         s.offsets.assign(U + 1, 0);
         for (int i = 0; i < U; i++) s.offsets[i + 1] = s.offsets[i] + (off[s.utts[i] + 1] - off[s.utts[i]]);
-        s.sums.assign((size_t)U * m->n_models, 0.0);
+        s.sums.assign((size_t)U * S, 0.0);
         s.argmax.assign((size_t)U, -1);
-        // piece boundaries: whole utterances, about equal sample counts
-        const int n_chunks = std::max(1, std::min(MULTI_CHUNKS, U));
+        // piece boundaries: whole utterances, about equal sample counts; pieces of at least ~2 MB of PCM (smaller ones are
+        // all launch overhead and kernel tails)
+        const int64_t total = s.offsets[U];
+        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(MULTI_CHUNKS, U), total / ((int64_t)1 << 20)));
         for (int c = 0; c < MULTI_CHUNKS; c++) {
             auto &ch = s.chunk[c];
             ch.u0 = ch.u1 = 0;
             if (c >= n_chunks) continue;
-            const int64_t lo = s.offsets[U] * c / n_chunks, hi = s.offsets[U] * (c + 1) / n_chunks;
+            const int64_t lo = total * c / n_chunks, hi = total * (c + 1) / n_chunks;
             ch.u0 = c == 0 ? 0 : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), lo) - s.offsets.begin());
             ch.u1 = c == n_chunks - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
             ch.u0 = std::min(ch.u0, U);
@@ -134,6 +157,8 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
             auto &ch = s.chunk[c];
             if (!ch.pcm) ch.pcm = std::make_unique<SRBatch>();
             if (!ch.uploaded) SR_HIP(hipEventCreateWithFlags(&ch.uploaded, hipEventDisableTiming));
+            if (!ch.done) SR_HIP(hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+            if (!ch.scratch) ch.scratch = mfcc_scratch_new();
             SRBatch &b = *ch.pcm;
             const int nu = ch.u1 - ch.u0;
             const int64_t base = s.offsets[ch.u0], n_samp = s.offsets[ch.u1] - base;
@@ -152,6 +177,10 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                     b.d_offsets.upload(b.offsets.data(), b.offsets.size());
                     sync_stream();
                 }
+                ch.h_sums.ensure((size_t)std::max(1, nu) * S);
+                ch.h_argmax.ensure((size_t)std::max(1, nu));
+                ch.h_flags.ensure(2);
+                ch.h_flags.p[0] = ch.h_flags.p[1] = 0;         // (nothing of this piece is in flight: the previous call waited for it)
             }
             if (!pinned) ch.staging.ensure((size_t)std::max<int64_t>(1, n_samp));
             // runs of utterances that are neighbours in the caller's buffer travel as one copy
@@ -171,23 +200,44 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                 i = j + 1;
             }
             SR_HIP(hipEventRecord(ch.uploaded, ctx().copy));
+            // ---- its kernels and result copies behind the event: launches only
+            if (nu == 0) continue;
+            std::lock_guard<std::recursive_mutex> lock(api_mutex());
+            SR_HIP(hipStreamWaitEvent(ctx().stream, ch.uploaded, 0));
+            mfcc_extract_with(*m->mfcc, b, nd, 1, ch.feat, ch.scratch);
+            const ScoreResult r = score_device(*s.set, ch.feat, false, flags);
+            if (r.d_oor) SR_HIP(hipMemcpyAsync(ch.h_flags.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            if (r.d_flush_count) SR_HIP(hipMemcpyAsync(ch.h_flags.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            SR_HIP(hipMemcpyAsync(ch.h_sums.p, r.d_sums, (size_t)nu * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+            SR_HIP(hipMemcpyAsync(ch.h_argmax.p, r.d_argmax, (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            SR_HIP(hipEventRecord(ch.done, ctx().stream));
         }
-        // ---- score: piece by piece, each as soon as it has arrived
+        // ---- collect: one wait per piece, in order; the rare piece that needs the host is redone from its features
         for (int c = 0; c < n_chunks; c++) {
             auto &ch = s.chunk[c];
             const int nu = ch.u1 - ch.u0;
             if (nu == 0) continue;
-            std::lock_guard<std::recursive_mutex> lock(api_mutex());
-            SR_HIP(hipStreamWaitEvent(ctx().stream, ch.uploaded, 0));
-            predict_pcm(m->mfcc.get(), s.set.get(), ch.pcm.get(), nd, s.sums.data() + (size_t)ch.u0 * m->n_models,
-                        s.argmax.data() + ch.u0, flags);
+            SR_HIP(hipEventSynchronize(ch.done));
+            if (ch.h_flags.p[0] != 0 || ch.h_flags.p[1] != 0) {
+                std::lock_guard<std::recursive_mutex> lock(api_mutex());
+                const int fl = flags | (ch.h_flags.p[0] != 0 ? SCORE_PRECISE : 0);
+                ScoreResult r = score_device(*s.set, ch.feat, false, fl);
+                if (!fetch_results(*s.set, ch.feat, fl, r, ch.h_sums.p, ch.h_argmax.p, nullptr)) {
+                    r = score_device(*s.set, ch.feat, false, fl | SCORE_PRECISE);
+                    fetch_results(*s.set, ch.feat, fl | SCORE_PRECISE, r, ch.h_sums.p, ch.h_argmax.p, nullptr);
+                }
+            }
+            std::memcpy(s.sums.data() + (size_t)ch.u0 * S, ch.h_sums.p, (size_t)nu * S * sizeof(double));
+            std::memcpy(s.argmax.data() + ch.u0, ch.h_argmax.p, (size_t)nu * sizeof(int));
         }
+        SR_HIP(hipStreamSynchronize(ctx().copy));              // (pieces without utterances still queued their empty copies)
         s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     } catch (const std::exception &e) {
         s.error = e.what();
-        (void)hipStreamSynchronize(ctx().copy);        // nothing of this call may still be reading the caller's buffer
+        drain();
     } catch (...) {
         s.error = "unknown C++ exception";
+        drain();
     }
 }
 
@@ -253,7 +303,11 @@ void sr_multi_free(SRMulti *m) {
             for (auto &ch : s.chunk) {
                 ch.pcm.reset();
                 if (ch.uploaded) (void)hipEventDestroy(ch.uploaded);
-                ch.uploaded = nullptr;
+                if (ch.done) (void)hipEventDestroy(ch.done);
+                ch.uploaded = ch.done = nullptr;
+                if (ch.scratch) mfcc_scratch_delete(ch.scratch);
+                ch.scratch = nullptr;
+                ch.feat = SRBatch();
             }
         } catch (...) {
         }
@@ -286,6 +340,9 @@ int sr_host_unregister(void *p) {
 }
 
 int sr_multi_slots(SRMulti *m) { return m ? (int)m->slots.size() : 0; }
+int sr_multi_slot_numa_node(SRMulti *m, int slot) {
+    return (m && slot >= 0 && slot < (int)m->slots.size()) ? m->slots[slot].numa_node : -1;
+}
 int sr_multi_slot_device(SRMulti *m, int slot) {
     return (m && slot >= 0 && slot < (int)m->slots.size()) ? m->slots[slot].device : -1;
 }
@@ -298,6 +355,7 @@ int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_o
         for (int u = 0; u < n_utt; u++)
             if (sample_offsets[u + 1] < sample_offsets[u]) fail("sample_offsets must be non-decreasing");
         if (sample_offsets[n_utt] > 0 && !pcm) fail("null PCM pointer");
+        if (gpu_runtime_lost()) fail_gpu_runtime_lost("sr_multi_predict_pcm");
         partition(sample_offsets, n_utt, m->slots);
         const bool pinned = sample_offsets[n_utt] > 0 && host_pinned(pcm) &&
                             host_pinned(pcm + sample_offsets[n_utt] - 1);

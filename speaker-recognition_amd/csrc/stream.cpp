@@ -45,6 +45,13 @@ struct SRStream {
 
 using namespace sr;
 
+// test hook, off unless sr_set_option("debug_capture_delay_ms", n) turns it on (it used to be an environment variable read on
+// every capture: a stray variable could stall serving, and getenv races with a concurrent setenv)
+std::atomic<int> &stream_debug_capture_delay_ms() {
+    static std::atomic<int> v{0};
+    return v;
+}
+
 namespace {
 
 void stream_destroy(SRStream *s) {
@@ -93,7 +100,7 @@ void capture_tick(SRStream *s, SRStream::Slot &sl) {
     const long epoch = g_devbuf_epoch.load();
     // test hook (tests/test_gpu_pipeline.py): hold the host back until the plain pass in front of the capture has finished on the
     // device -- the ordering in which a host-side write during capture used to clobber that pass's result flags
-    if (const char *d = getenv("SR_DEBUG_CAPTURE_DELAY_MS")) std::this_thread::sleep_for(std::chrono::milliseconds(atoi(d)));
+    if (const int d = stream_debug_capture_delay_ms().load()) std::this_thread::sleep_for(std::chrono::milliseconds(d));
     SR_HIP(hipStreamBeginCapture(ctx().stream, hipStreamCaptureModeThreadLocal));
     try {
         std::lock_guard<std::recursive_mutex> _api_lock(api_mutex());

@@ -3,7 +3,8 @@ no data-path collective.  One process per GPU (RANK / LOCAL_RANK / WORLD_SIZE fr
 launcher); every rank scores its own utterances with the fused device step and only the
 per-utterance results (argmax + optionally the S sums) are gathered on the host -- 4 bytes per
 utterance, the host-side gather the reference's multiprocessing.Pool does
-(src/test/test-gmm.py:129-133), with `gloo` carrying it.  xGMI / RCCL are not involved.
+(src/test/test-gmm.py:129-133) -- over rendezvous.py's Unix-domain socket (no torch; ``backend="gloo"``
+or SR_RENDEZVOUS=gloo keeps torch.distributed as the carrier).  xGMI / RCCL are not involved.
 """
 from __future__ import annotations
 
@@ -13,7 +14,7 @@ import numpy as np
 
 
 def rank_env():
-    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    """(rank, local_rank, world_size) from the launcher's environment (torch.distributed.run's names)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
@@ -33,22 +34,12 @@ def partition_utterances(lengths, n_parts: int):
     return [np.array(sorted(p), dtype=np.int64) for p in parts]
 
 
-def init_process_group():
-    """gloo group for the host-side gather (rendezvous on 127.0.0.1 unless told otherwise)."""
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group(backend="gloo")
-    return dist
-
-
-def predict_sharded(n_utt: int, lengths, compute, n_models: int, want_sums: bool = False):
+def predict_sharded(n_utt: int, lengths, compute, n_models: int, want_sums: bool = False, backend: str | None = None):
     """Run ``compute(indices) -> (sums[len(indices), S] or None, argmax[len(indices)])`` on this
     rank's shard and gather the full result on every rank.
 
     Returns (argmax[n_utt] int32, sums[n_utt, S] float64 or None).  With WORLD_SIZE == 1 this is
-    a plain call (no torch import)."""
+    a plain call."""
     rank, _, world = rank_env()
     parts = partition_utterances(lengths, world)
     mine = parts[rank]
@@ -62,17 +53,13 @@ def predict_sharded(n_utt: int, lengths, compute, n_models: int, want_sums: bool
             fs = np.zeros((n_utt, n_models))
             fs[mine] = sums
         return full, fs
-    import torch
-    dist = init_process_group()
-    # fixed-size exchange: every rank contributes a dense [n_utt] vector (-2 = not mine)
-    buf = torch.full((n_utt,), -2, dtype=torch.int32)
-    buf[torch.from_numpy(mine)] = torch.from_numpy(arg)
-    dist.all_reduce(buf, op=dist.ReduceOp.MAX)     # shards are disjoint: MAX picks the owner's value
-    full = buf.numpy().copy()
-    fs = None
-    if want_sums:
-        sb = torch.zeros((n_utt, n_models), dtype=torch.float64)
-        sb[torch.from_numpy(mine)] = torch.from_numpy(np.asarray(sums, dtype=np.float64))
-        dist.all_reduce(sb, op=dist.ReduceOp.SUM)
-        fs = sb.numpy().copy()
+    from . import rendezvous
+    grp = rendezvous.init(backend)
+    # every rank contributes its (indices, argmax[, sums]); shards are disjoint and cover every utterance
+    full = np.full(n_utt, -1, dtype=np.int32)
+    fs = np.zeros((n_utt, n_models)) if want_sums else None
+    for idx, a, sm in grp.all_gather((mine, arg, np.asarray(sums, dtype=np.float64) if want_sums else None)):
+        full[idx] = a
+        if want_sums and len(idx):
+            fs[idx] = sm
     return full, fs

@@ -1,4 +1,5 @@
-"""CPU: the N>1 path -- utterance partition + host-side gather over gloo (world_size 2).
+"""CPU: the N>1 path -- utterance partition + host-side gather (world_size 2 and 3), over the package's own torch-free
+rendezvous (speaker-recognition_amd/rendezvous.py, with torch made unimportable in the workers) and over gloo.
 The per-shard compute is stood in by the oracle here (the GPU step is covered by -m gpu)."""
 import os
 import socket
@@ -23,10 +24,12 @@ def test_partition_covers_and_balances():
     assert [len(p) for p in partition_utterances([], 4)] == [0, 0, 0, 0]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="socket"):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SR_RENDEZVOUS=backend)
     sys.path.insert(0, ROOT)
+    if backend == "socket":
+        sys.modules["torch"] = None          # `import torch` raises ImportError from here on: the socket path must not need it
     from oracle import gmm_oracle as go
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.shard import predict_sharded
@@ -46,19 +49,55 @@ def _worker(rank, world, port, q):
     q.put((rank, ok, arg.tolist()))
 
 
-def test_two_rank_gather_matches_single_process():
-    import torch.multiprocessing as mp
+def _run_ranks(world, backend):
+    import multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(60)
     assert all(ok for _, ok, _ in res)
-    assert res[0][2] == res[1][2]          # every rank ends with the same full answer
+    assert all(r[2] == res[0][2] for r in res)          # every rank ends with the same full answer
+
+
+def test_two_and_three_rank_gather_without_torch():
+    _run_ranks(2, "socket")
+    _run_ranks(3, "socket")
+
+
+def test_two_rank_gather_over_gloo():
+    _run_ranks(2, "gloo")
+
+
+def _rdzv_worker(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    sys.modules["torch"] = None
+    from speaker_recognition_amd.rendezvous import SocketGroup
+    g = SocketGroup(rank, world, key=key, timeout=60)
+    g.barrier()
+    got = g.all_gather({"rank": rank, "payload": list(range(rank))})
+    mx = g.all_max(10.0 + rank)
+    g.barrier()
+    g.close()
+    q.put((rank, [d["rank"] for d in got], mx))
+
+
+def test_socket_group_collectives():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "sr-test-%d" % os.getpid()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 4, key, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert [r[1] for r in res] == [[0, 1, 2, 3]] * 4 and all(r[2] == 13.0 for r in res)
