@@ -671,6 +671,18 @@ def block_trained(_lib, ex, base):
             "best_speaker_beats_ubm_fraction": float(np.mean(sums[:, 1:].max(axis=1) > sums[:, 0]))}
 
 
+def usable_cores():
+    """cores this container may use: affinity mask and cgroup CPU quota (os.cpu_count() reports the machine's)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(float(q) / float(p)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_leg(spec):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), json.dumps(spec)],
                          capture_output=True, text=True, timeout=1500)
@@ -693,7 +705,9 @@ def main():
                     help="testing only: total frames of the configs[3] job the ranks split (default: its stated 100 M)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc sub-runs that fill roofline.traffic")
     ap.add_argument("--cpu-sample-utts", type=int, default=4, help="utterances of the single-call CPU leg (reference DSO, concurrency = cores)")
-    ap.add_argument("--cpu-pool-utts", type=int, default=64, help="utterances of the Pool leg (reference DSO over (utterance, model group) tasks on all cores, all models)")
+    ap.add_argument("--cpu-pool-utts", type=int, default=0,
+                    help="utterances of the Pool leg (reference DSO over (utterance, model group) tasks on every usable core, all models); "
+                         "0 = 64 when the container may use >= 64 cores, else 32 (a bounded ~20 s of CPU work either way)")
     ap.add_argument("--rendezvous", choices=("socket", "gloo"), default=os.environ.get("SR_RENDEZVOUS", "socket"),
                     help="how the N ranks meet on the host: the package's Unix-domain socket (no torch) or torch.distributed over gloo")
     ap.add_argument("--device-override", type=int, default=-1,
@@ -902,7 +916,7 @@ def main():
             all_files.append(p)
         spec = dict(fs=FS, mfcc_kw=MFCC_KW, nd=ND, n_utt=args.cpu_sample_utts, seconds=10.04, seed=AUDIO_SEED,
                     n_speakers=CFG2_SPEAKERS, model_files=files, single_core_models=2,
-                    pool_utts=args.cpu_pool_utts, pool_model_files=all_files)
+                    pool_utts=args.cpu_pool_utts or (64 if usable_cores() >= 64 else 32), pool_model_files=all_files)
         cb, err = cpu_baseline_leg(spec)
         if cb is None:
             result["cpu_baseline"] = {"error": err}
@@ -932,7 +946,8 @@ def main():
                 psums, parg = ex.predict_batch(ms, Batch.from_pcm(psample), nd=ND)
                 want = np.array(pool["sums"])
                 result["cpu_baseline"] = {
-                    "value": pool["frames_per_s"], "unit": "frames/s", "cores": cb["cores"], "cores_busy": pool["processes"], "kind": cb["kind"],
+                    "value": pool["frames_per_s"], "unit": "frames/s", "cores": pool["processes"], "cores_busy": pool["processes"], "kind": cb["kind"],
+                    "host": cb.get("host"),
                     "sample": "%d utterances x 10.04 s (%d frames) of the same workload, ALL %d models: the reference's compiled C++ score_batch "
                               "(concurrency = 1 per call) over %d (utterance, %d-model group) tasks on a multiprocessing.Pool(%d) -- the parallelism "
                               "of the reference's own drivers (src/test/test-gmm.py:128-133) -- + the float64 numpy restatement of MFCC.py on "

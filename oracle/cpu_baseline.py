@@ -33,10 +33,13 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from oracle import hostinfo  # noqa: E402
+
+hostinfo.single_thread_blas()          # every pool worker does its own BLAS calls: one thread each
+
+import numpy as np  # noqa: E402
 
 _SPEC = None
 _POOL_FEATS = None        # the Pool leg's utterances (float64 [T, D] each), inherited by its forked workers
@@ -122,7 +125,7 @@ def main():
 
     fs = spec["fs"]
     n_utt, seconds = spec["n_utt"], spec["seconds"]
-    cores = os.cpu_count() or 1
+    cores = hostinfo.effective_cores()            # what this container may use (cgroup quota / affinity), not what the machine has
     n_spk = spec.get("n_speakers", spec.get("n_models", 1))
     pcm = [synth.synth_speech(u % n_spk, seconds, fs, seed=spec["seed"] + u) for u in range(n_utt)]
 
@@ -199,6 +202,7 @@ def main():
         t_gmm = time.perf_counter() - t0
         kind, used = "port", 1
     print(json.dumps({
+        "host": hostinfo.describe(),
         "pool": pool,
         "kind": kind, "cores": used, "n_frames": n_frames, "n_models": S,
         "t_mfcc_s": t_mfcc, "t_mfcc_pool_s": t_pool, "pool_procs": procs, "t_gmm_s": t_gmm, "t_gmm_1core_s": t_gmm_1,

@@ -235,6 +235,11 @@ struct FlushWorkspace {
     DevBuf<int> utts;
 };
 
+struct FlushHostStaging {          // page-locked: the small copies back do not queue behind a bulk upload's staging
+    PinnedBuf<int2> list;
+    PinnedBuf<double> tile_sum;
+};
+
 struct FlushStats {
     std::atomic<long> calls{0}, pairs{0}, frames{0};
 };
@@ -256,9 +261,12 @@ void flush_stats(long *calls, long *pairs, long *frames) {
 // Re-evaluates every frame of the `count` noted (tile, model) pairs (device list `d_list`, any order; tiles of `tt`)
 // with the reference's arithmetic and completes the device-resident results: sums[u][s] += the tiles' sums (added on
 // the host in (tile, model) order: deterministic), the argmax of the utterances touched, the per-frame values.
-void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *d_sums,
-                   int *d_argmax, float *d_frame_ll) {
-    if (count <= 0) return;
+// The device part + one host wait: the exact kernels run on the list AS THE DEVICE LEFT IT (the order in which gmm_finalize_kernel's
+// atomics appended the pairs decides nothing: a pair's sum is its own), list and tile sums come back together, and the host sorts
+// the pairs by (tile, model) before it adds them up -- the deterministic order of additions, one synchronisation instead of two.
+// -> patches (utterance, model, sum to add), sorted, and the utterances they touch.
+static void flush_evaluate(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, float *d_frame_ll,
+                           std::vector<FlushPatch> &patches, std::vector<int> &utts) {
     auto &fw = per_device<FlushWorkspace>();
     const int S = set.host.n_models;
     // the per-model record table of the vector layout (always resident: upload_model_set)
@@ -275,58 +283,67 @@ void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const in
         set.d_flush_models.upload(reinterpret_cast<const int *>(fm.data()), (size_t)2 * S);
         sync_stream();
     }
-    std::vector<int2> list((size_t)count);
-    SR_HIP(hipMemcpyAsync(list.data(), d_list, (size_t)count * sizeof(int2), hipMemcpyDeviceToHost, ctx().stream));
-    sync_stream();
-    std::sort(list.begin(), list.end(), [](const int2 &a, const int2 &b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
-    fw.sorted.upload(list.data(), list.size());
-    fw.tile_sum.ensure(list.size());
+    const size_t n_pairs = (size_t)count;
+    fw.tile_sum.ensure(n_pairs);
     const int fpt = tt.frames_per_tile;
     // batches of pairs: the per-frame scratch stays below 64 MiB
     const size_t per_batch = std::max<size_t>(1, ((size_t)64 << 20) / ((size_t)fpt * sizeof(float)));
-    fw.exact.ensure(std::min(per_batch, list.size()) * (size_t)fpt);
-    long frames = 0;
-    for (size_t base = 0; base < list.size(); base += per_batch) {
-        const size_t n = std::min(per_batch, list.size() - base);
+    fw.exact.ensure(std::min(per_batch, n_pairs) * (size_t)fpt);
+    for (size_t base = 0; base < n_pairs; base += per_batch) {
+        const size_t n = std::min(per_batch, n_pairs - base);
         const dim3 grid((unsigned)n, (unsigned)((fpt + 3) / 4));
 #define SR_FLUSH_LAUNCH(ORDER)                                                                                            \
         hipLaunchKernelGGL(gmm_flush_exact_kernel<ORDER>, grid, dim3(256), 0, ctx().stream, feat.data.p, set.d_center0.p,  \
                            set.d_params.p, reinterpret_cast<const FlushModel *>(set.d_flush_models.p), tt.d_tiles.p,       \
-                           fw.sorted.p + base, feat.dim, set.host.dp, fpt, feat.n_rows,                        \
+                           d_list + base, feat.dim, set.host.dp, fpt, feat.n_rows,                                         \
                            (float)(-708.396418532264 + set.host.flush_band), fw.exact.p, d_frame_ll)
         if (flush_order_option() == 1) SR_FLUSH_LAUNCH(1); else SR_FLUSH_LAUNCH(2);
 #undef SR_FLUSH_LAUNCH
         hipLaunchKernelGGL(gmm_flush_tile_sum_kernel, dim3((unsigned)n), dim3(64), 0, ctx().stream, fw.exact.p, tt.d_tiles.p,
-                           fw.sorted.p + base, fpt, fw.tile_sum.p + base);
+                           d_list + base, fpt, fw.tile_sum.p + base);
         SR_HIP(hipGetLastError());
     }
-    std::vector<double> tile_sum(list.size());
-    fw.tile_sum.download(tile_sum.data(), tile_sum.size());
+    auto &hs = per_device<FlushHostStaging>();
+    hs.list.ensure(n_pairs);
+    hs.tile_sum.ensure(n_pairs);
+    SR_HIP(hipMemcpyAsync(hs.list.p, d_list, n_pairs * sizeof(int2), hipMemcpyDeviceToHost, ctx().stream));
+    SR_HIP(hipMemcpyAsync(hs.tile_sum.p, fw.tile_sum.p, n_pairs * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
     sync_stream();
-    // (utterance, model) patches: the list is sorted by tile, tiles are in utterance order
+    // (utterance, model) patches: pairs in (tile, model) order -- tiles are in utterance order --, one patch per (utterance, model)
+    long frames = 0;
+    std::vector<std::pair<int64_t, double>> acc;     // key = (tile * S + model), then (utt * S + model)
+    acc.reserve(n_pairs);
+    for (size_t i = 0; i < n_pairs; i++) acc.emplace_back((int64_t)hs.list.p[i].x * S + hs.list.p[i].y, hs.tile_sum.p[i]);
+    std::sort(acc.begin(), acc.end(), [](const auto &a, const auto &b) { return a.first < b.first; });   // (a pair occurs once: no ties)
+    for (auto &e : acc) {
+        const TileDesc &td = tt.h_tiles[(size_t)(e.first / S)];
+        frames += td.count;
+        e.first = (int64_t)td.utt * S + (e.first % S);
+    }
+    std::stable_sort(acc.begin(), acc.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    patches.clear();
+    utts.clear();
+    for (size_t i = 0; i < acc.size();) {
+        size_t j = i;
+        double d = 0.0;
+        for (; j < acc.size() && acc[j].first == acc[i].first; j++) d += acc[j].second;
+        patches.push_back(FlushPatch{(int)(acc[i].first / S), (int)(acc[i].first % S), d});
+        if (utts.empty() || utts.back() != patches.back().utt) utts.push_back(patches.back().utt);
+        i = j;
+    }
+    g_flush_stats.calls++;
+    g_flush_stats.pairs += (long)n_pairs;
+    g_flush_stats.frames += frames;
+}
+
+void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *d_sums,
+                   int *d_argmax, float *d_frame_ll) {
+    if (count <= 0) return;
+    auto &fw = per_device<FlushWorkspace>();
+    const int S = set.host.n_models;
     std::vector<FlushPatch> patches;
     std::vector<int> utts;
-    {
-        std::vector<std::pair<int64_t, double>> acc;     // key = utt * S + model
-        acc.reserve(list.size());
-        for (size_t i = 0; i < list.size(); i++) {
-            const TileDesc &td = tt.h_tiles[(size_t)list[i].x];
-            frames += td.count;
-            acc.emplace_back((int64_t)td.utt * S + list[i].y, tile_sum[i]);
-        }
-        std::stable_sort(acc.begin(), acc.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-        for (size_t i = 0; i < acc.size();) {
-            size_t j = i;
-            double d = 0.0;
-            for (; j < acc.size() && acc[j].first == acc[i].first; j++) d += acc[j].second;
-            patches.push_back(FlushPatch{(int)(acc[i].first / S), (int)(acc[i].first % S), d});
-            if (utts.empty() || utts.back() != patches.back().utt) utts.push_back(patches.back().utt);
-            i = j;
-        }
-        g_flush_stats.calls++;
-        g_flush_stats.pairs += (long)list.size();
-        g_flush_stats.frames += frames;
-    }
+    flush_evaluate(set, feat, tt, d_list, count, d_frame_ll, patches, utts);
     fw.patches.upload(patches.data(), patches.size());
     fw.utts.upload(utts.data(), utts.size());
     hipLaunchKernelGGL(gmm_flush_patch_kernel, dim3((unsigned)((patches.size() + 255) / 256)), dim3(256), 0, ctx().stream,
@@ -335,6 +352,30 @@ void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const in
                        d_argmax);
     SR_HIP(hipGetLastError());
     sync_stream();       // the uploads above read host vectors that die with this frame
+}
+
+// The same, completing HOST copies of the results (sr_multi_predict_pcm's pieces: their sums and argmax are already in
+// page-locked host memory when the count is known): nothing goes back to the device, one host wait in all.
+void flush_resolve_host(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *h_sums,
+                        int *h_argmax) {
+    if (count <= 0) return;
+    const int S = set.host.n_models;
+    std::vector<FlushPatch> patches;
+    std::vector<int> utts;
+    flush_evaluate(set, feat, tt, d_list, count, nullptr, patches, utts);
+    for (const FlushPatch &p : patches) h_sums[(size_t)p.utt * S + p.model] += p.delta;
+    for (int u : utts) {                     // first maximum wins (gmm_flush_argmax_kernel, gmmset.py:62-64)
+        double best = -INFINITY;
+        int best_i = -1;
+        for (int s = 0; s < S; s++) {
+            const double v = h_sums[(size_t)u * S + s];
+            if (v > best) {
+                best = v;
+                best_i = s;
+            }
+        }
+        h_argmax[u] = best_i;
+    }
 }
 
 }  // namespace sr

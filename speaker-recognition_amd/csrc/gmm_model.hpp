@@ -210,8 +210,15 @@ struct SRModelSet {
     // Hybrid form of an ill-conditioned set (score.hpp): the mixtures whose expanded form would cancel in fp32 (tight and
     // far from the centre) as one sub-set on the direct-form vector engine, the rest as another on the matrix cores;
     // the two per-frame log-likelihoods are merged by a log-add-exp.  Empty unless the set needed it.
-    std::vector<int> gcb_host;       // model-group table of the last scoring call (chunk / block index per group) ...
-    sr::DevBuf<int> d_gcb;           // ... and its device copy
+    // Model-group tables (chunk / block index per group) of recent scoring calls and their device copies: the number of groups
+    // follows the batch's size, and a caller that alternates between sizes (the pieces of sr_multi_predict_pcm) must not re-upload
+    // -- and synchronise the stream -- on every call.  A handful of entries, oldest replaced.
+    struct GroupTable {
+        std::vector<int> host;
+        sr::DevBuf<int> dev;
+    };
+    std::vector<std::unique_ptr<GroupTable>> group_tables;
+    size_t group_table_next = 0;
     sr::DevBuf<int> d_flush_models;  // per model {first record, records} of the vector layout (gmm_flush.hip; built on first use)
     std::unique_ptr<SRModelSet> hy_good, hy_bad;
     int hy_bad_mixtures = 0;         // mixtures of the set's largest model that went to the vector engine

@@ -761,7 +761,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 splitp_w = w;
         }
     }
-    TileTable &tt = feat.tiles_for((use_h2s || splitp_w) ? 32 : use_mat ? 128 * FT : 256 * F);
+    TileTable &tt = feat.tiles_for((use_h2s || use_split) ? 32 : use_mat ? 128 * FT : 256 * F);
     const int U = feat.n_utt;
 
     auto &w = ws();
@@ -780,11 +780,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // fp32 matrix kernels; the split-bf16 kernel's workgroups are short, and every extra
             // group re-reads the frame tile, so ~6 rounds (4 resident per CU) are enough there
             const int target = use_h2s ? ctx().n_cu * h2s_resident_per_cu(set.h2s.kqf, set.h2s.klf, h2s_shape) * 6 : use_shared ? ctx().n_cu * 2 * 6
-                               : splitp_w ? ctx().n_cu * splitp_resident_per_cu(splitp_w) * 12
+                               : splitp_w ? ctx().n_cu * splitp_resident_per_cu(splitp_w) * 8
                                : use_split ? ctx().n_cu * 4 * 6 : ctx().n_cu * 3 * 16;
             // (the split-fp16 shared-sigma engine's workgroups, and the wide generic ones, take several 32-frame tiles each)
             const int n_wg_tiles = use_h2s ? (tt.n_tiles + h2s_tiles_per_wg(h2s_shape) - 1) / h2s_tiles_per_wg(h2s_shape)
-                                   : splitp_w ? (tt.n_tiles + splitp_w - 1) / splitp_w : tt.n_tiles;
+                                   : splitp_w ? (tt.n_tiles + splitp_w - 1) / splitp_w
+                                   : use_split ? (tt.n_tiles + 4 * FT - 1) / (4 * FT) : tt.n_tiles;
             G = (target + n_wg_tiles - 1) / n_wg_tiles;
         }
         const int n_units = use_h2s ? (int)set.h2s.blocks.size()
@@ -804,9 +805,21 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         bool uploaded = false;
         // the group table lives with the SET (a hybrid set's two halves, or sets scored in turn, each keep theirs: no
         // re-upload -- and no stream synchronisation, which a captured serving tick could not take -- in steady state)
-        if (set.gcb_host != gcb) {
-            set.gcb_host = gcb;
-            set.d_gcb.upload(set.gcb_host.data(), set.gcb_host.size());
+        const int *d_gcb = nullptr;
+        for (auto &gt : set.group_tables)
+            if (gt->host == gcb) d_gcb = gt->dev.p;
+        if (!d_gcb) {
+            constexpr size_t MAX_GROUP_TABLES = 8;
+            if (set.group_tables.size() < MAX_GROUP_TABLES) {
+                set.group_tables.push_back(std::make_unique<SRModelSet::GroupTable>());
+                set.group_table_next = set.group_tables.size() - 1;
+            }
+            auto &gt = *set.group_tables[set.group_table_next];
+            set.group_table_next = (set.group_table_next + 1) % MAX_GROUP_TABLES;
+            sync_stream();                        // (a replaced table may still be read by a launch in flight)
+            gt.host = gcb;
+            gt.dev.upload(gt.host.data(), gt.host.size());
+            d_gcb = gt.dev.p;
             uploaded = true;
         }
         w.partial.ensure((size_t)tt.n_tiles * S * ((use_split || use_shared || use_h2s) ? 1 : 4));
@@ -821,7 +834,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             used_oor = true;
             // pre-pass: the reference model's per-frame LL (natural log, no clamp) = the offset
             w.ref_ll.ensure((size_t)std::max<int64_t>(1, feat.n_rows));
-            TileTable &tt_ref = feat.tiles_for(128);     // the pre-pass keeps one column tile per wave
+            TileTable &tt_ref = feat.tiles_for(32);      // (the generic split kernel's unit: a 32-frame tile per wave)
             w.ref_partial.ensure((size_t)tt_ref.n_tiles);
             {
                 MfmaLaunch r;
@@ -855,7 +868,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.tiles = tt.d_tiles.p;
             a.params = set.d_h2s_params.p;
             a.blocks = set.d_h2s_blocks.p;
-            a.group_block_begin = set.d_gcb.p;
+            a.group_block_begin = d_gcb;
             a.center = set.d_h2s_center.p;
             a.scale = set.d_h2s_scale.p;
             a.q_desc = set.d_h2s_qdesc.p;
@@ -894,7 +907,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.tiles = tt.d_tiles.p;
             a.params = set.d_shared_params.p;
             a.blocks = set.d_shared_blocks.p;
-            a.group_block_begin = set.d_gcb.p;
+            a.group_block_begin = d_gcb;
             a.center = set.d_shared_center.p;
             a.partial = w.partial.p;
             a.frame_ll = fll;
@@ -920,7 +933,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                        : use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
                                  : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
             a.chunks = use_h2 ? set.d_h2_chunks.p : use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
-            a.group_chunk_begin = set.d_gcb.p;
+            a.group_chunk_begin = d_gcb;
             a.center = use_h2 ? set.d_h2_center.p : use_bx3 ? set.d_bx3_center.p : set.d_center.p;
             if (use_h2) {
                 w.oor.ensure(1);
@@ -964,7 +977,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.params = reinterpret_cast<const float4 *>(set.d_params.p);
             a.center = set.d_center0.p;
             a.chunks = set.d_chunks.p;
-            a.group_chunk_begin = set.d_gcb.p;
+            a.group_chunk_begin = d_gcb;
             a.partial = w.partial.p;
             a.frame_ll = fll;
             a.n_frames = feat.n_rows;

@@ -59,19 +59,21 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
     typedef typename SC::frag frag;
     __shared__ uint4 lds_a[TILE_U4];
     __shared__ uint4 lds_b[TILE_U4];
-    __shared__ double close_slot[2][4];        // the four waves' sums of a closed model, two generations
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31;                 // frame column inside a 32-frame tile
     const int hh = lane >> 5;                  // which 8 of the 16 contraction indices of a step
+    // Round 4: the unit of work is a 32-frame tile of ONE utterance per (wave, column tile) -- as in the wide form of this engine
+    // (gmm_score_splitp.hip) and the shared-sigma engines -- instead of a 128-frame tile per workgroup: a workgroup takes 4 FT
+    // consecutive tiles and may straddle utterances, short utterances pad to 32 frames instead of 128, and both forms of the engine
+    // leave the SAME partial per (32-frame tile, model): which one a batch's size selects does not show in the results.
     const int tile_lo = blockIdx.x & 7;        // XCD-aware order, as gmm_score_kernel
     const int q = blockIdx.x >> 3;
     const int g = q % n_groups;
-    const int tile_id = (q / n_groups) * 8 + tile_lo;
-    if (tile_id >= n_tiles) return;
-    const TileDesc tile = tiles[tile_id];
+    const int tile0 = ((q / n_groups) * 8 + tile_lo) * (4 * FT);
+    if (tile0 >= n_tiles) return;
     const int chunk_begin = group_chunk_begin[g];
     const int chunk_end = group_chunk_begin[g + 1];
 
@@ -95,14 +97,17 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
     //      upper slot carries the constant 1 that picks up C_k (8 KS > dim, so it is free).
     //      breg[ft][ks][part] = the 16-bit parts of this lane's 8 slots of step ks. ----
     frag breg[FT][KS][P];
-    bool valid[FT];
+    bool valid[FT], has[FT];
+    int tile_id[FT];
     int64_t row[FT];
     float zmax = 0.0f;
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) {
-        const int local = (wave * FT + ft) * 32 + col;
-        valid[ft] = local < tile.count;
-        row[ft] = tile.start + (valid[ft] ? local : 0);
+        tile_id[ft] = tile0 + wave * FT + ft;
+        has[ft] = tile_id[ft] < n_tiles;
+        const TileDesc tile = tiles[has[ft] ? tile_id[ft] : n_tiles - 1];
+        valid[ft] = has[ft] && col < tile.count;
+        row[ft] = tile.start + (valid[ft] ? col : 0);
         const float *src = X + row[ft] * dim;
         float xs[8 * KS];
 #pragma unroll
@@ -158,19 +163,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
     const float near_thr = lse_near_threshold(clamp);
     dma_publish_barrier();
 
-    // A model's four wave sums meet in LDS and leave as ONE double per (tile, model): the store
-    // happens after the chunk's closing barrier, at the top of the next chunk (or after the loop).
-    int pending_model = -1, pending_gen = 0, gen = 0;
-    auto flush_pending = [&]() {
-        if (pending_model >= 0 && tid == 0) {
-            const double *p = close_slot[pending_gen];
-            partial[(int64_t)tile_id * n_models + pending_model] = ((p[0] + p[1]) + p[2]) + p[3];
-        }
-        pending_model = -1;
-    };
-
     auto do_chunk = [&](const uint4 *cur, uint4 *other, int c) {
-        flush_pending();
         const int model_done = done_next;
         if (c + 1 < chunk_end) {
             stage(other, c + 1);
@@ -207,27 +200,24 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
 
         if (model_done >= 0) {
             const int s = model_done;
-            double mine = 0.0;
-            bool hot = false;              // a frame in the band of the reference's partial-product flushes (lse.hpp)
 #pragma unroll
             for (int ft = 0; ft < FT; ft++) {
                 // merge the two half-waves (the other 16 mixture rows of the same frame); the
                 // reference's underflow behaviour (safe_log, gmm.cc:34-38) is in lse.hpp
                 const float ll = lse_close2(m[ft], ssum[ft], other_half(m[ft]), other_half(ssum[ft]), clamp);
+                double mine = 0.0;
+                bool hot = false;          // a frame in the band of the reference's partial-product flushes (lse.hpp)
                 if (valid[ft] && hh == 0) {
-                    mine += (double)ll;
+                    mine = (double)ll;
                     if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;
-                    hot |= ll < band_hi;
+                    hot = ll < band_hi;
                 }
                 m[ft] = NEG_BIG;
                 ssum[ft] = 0.0f;
+                mine = wave_sum_f64(mine);
+                if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
+                if (lane == 0 && has[ft]) partial[(int64_t)tile_id[ft] * n_models + s] = mine;
             }
-            mine = wave_sum_f64(mine);
-            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
-            if (lane == 0) close_slot[gen][wave] = mine;
-            pending_model = s;
-            pending_gen = gen;
-            gen ^= 1;
         }
         dma_publish_barrier();
     };
@@ -236,12 +226,12 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         do_chunk(lds_a, lds_b, c);
         if (c + 1 < chunk_end) do_chunk(lds_b, lds_a, c + 1);
     }
-    flush_pending();
 }
 
 template <typename SC, int KS, int FT>
 static void launch_split(const MfmaLaunch &a) {
-    dim3 grid((unsigned)((int64_t)a.n_groups * ((a.n_tiles + 7) / 8) * 8));
+    const int n_wg = (a.n_tiles + 4 * FT - 1) / (4 * FT);        // `a.tiles` = 32-frame tiles, 4 FT per workgroup
+    dim3 grid((unsigned)((int64_t)a.n_groups * ((n_wg + 7) / 8) * 8));
     hipLaunchKernelGGL((gmm_score_split_kernel<SC, KS, FT>), grid, dim3(256), 0, ctx().stream, a.X, a.tiles,
                        reinterpret_cast<const uint4 *>(a.params), a.chunks, a.group_chunk_begin, a.center,
                        a.scale, a.partial, a.frame_ll, a.oor_flag, a.n_frames, a.dim, a.n_models, a.clamp,

@@ -253,27 +253,30 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
     auto slab_flush = [&]() {
         wave_sync();
         const int j = lane >> 2, qq = lane & 3;            // 4 lanes per model, 8 frames each
-        double sum = 0.0;
+        // The additions are those of wave_sum_f64 over a wave whose lanes 0..31 hold the frames (wave_ops.hpp: pairs, pairs of
+        // pairs, ... within each row of 16, then the rows in order), so that this kernel and gmm_score_split_kernel leave the
+        // same double for a (32-frame tile, model): which of them a batch's size selects does not show in an utterance's sum.
+        float v[8];
         bool hot = false;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float v = slab[j * SLAB_STRIDE + qq * 8 + i];
-            sum += (double)v;
-            hot |= v < a.band_hi;
+            v[i] = slab[j * SLAB_STRIDE + qq * 8 + i];
+            hot |= v[i] < a.band_hi;
         }
-        if (hot) sum = SR_FLUSH_POISON;
-        // the four lanes of a model, in lane order (DPP quad broadcasts)
+        double sum = (((double)v[1] + (double)v[0]) + ((double)v[3] + (double)v[2])) + (((double)v[5] + (double)v[4]) + ((double)v[7] + (double)v[6]));
+        // the four lanes of a model (DPP quad broadcasts): rows of 16 frames, then the two rows
         union { double d; int i[2]; } s, b;
         s.d = sum;
-        double tot = 0.0;
+        const unsigned long long hot_mask = __builtin_amdgcn_ballot_w64(hot);
+        double x[4];
 #define SR_QUAD_BCAST(K)                                                              \
         b.i[0] = __builtin_amdgcn_update_dpp(0, s.i[0], (K) * 0x55, 0xf, 0xf, true);       \
-        b.i[1] = __builtin_amdgcn_update_dpp(0, s.i[1], (K) * 0x55, 0xf, 0xf, true);
-        SR_QUAD_BCAST(0) tot = b.d;
-        SR_QUAD_BCAST(1) tot += b.d;
-        SR_QUAD_BCAST(2) tot += b.d;
-        SR_QUAD_BCAST(3) tot += b.d;
+        b.i[1] = __builtin_amdgcn_update_dpp(0, s.i[1], (K) * 0x55, 0xf, 0xf, true);       \
+        x[K] = b.d;
+        SR_QUAD_BCAST(0) SR_QUAD_BCAST(1) SR_QUAD_BCAST(2) SR_QUAD_BCAST(3)
 #undef SR_QUAD_BCAST
+        double tot = ((0.0 + (x[1] + x[0])) + (x[3] + x[2]));
+        if ((hot_mask >> (lane & ~3)) & 0xfull) tot = SR_FLUSH_POISON;      // a frame of this model's tile in the band (lse.hpp)
         if (has && qq == 0 && j < slab_n) partial[(int64_t)tile_id * a.n_models + slab_first + j] = tot;
         wave_sync();
         slab_first += slab_n;

@@ -31,6 +31,10 @@
 using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
+std::atomic<int> &multi_pieces_option() {   // sr_set_option("multi_pieces", n): 0 = automatic (up to MULTI_CHUNKS), 1 .. MULTI_CHUNKS
+    static std::atomic<int> v{0};
+    return v;
+}
 
 struct SRMulti {
     // One piece of a slot's utterances: its PCM on the device, the feature stage's workspace and output, page-locked result
@@ -45,6 +49,11 @@ struct SRMulti {
         MfccScratch *scratch = nullptr;
         PinnedBuf<double> h_sums;
         PinnedBuf<int> h_argmax, h_flags;   // h_flags: {a frame saturated the fp16 engine, (tile, model) pairs in the partial-product band}
+        // the piece's list of (tile, model) pairs in the band, set aside on the device (the scoring workspace it was produced in
+        // belongs to the next piece by then): what gmm_flush.hip re-evaluates when it is not empty
+        DevBuf<int2> d_list;
+        const TileTable *tiles = nullptr;
+        int flush_cap = 0;
     };
     struct Slot {
         int device = 0;
@@ -140,14 +149,24 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // piece boundaries: whole utterances, about equal sample counts; pieces of at least ~2 MB of PCM (smaller ones are
         // all launch overhead and kernel tails)
         const int64_t total = s.offsets[U];
-        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(MULTI_CHUNKS, U), total / ((int64_t)1 << 20)));
+        const int want = multi_pieces_option().load() > 0 ? std::min(MULTI_CHUNKS, multi_pieces_option().load()) : MULTI_CHUNKS;
+        const int n_chunks_max = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, U), total / ((int64_t)1 << 20)));
+        // Copy and kernels take about the same time on this path (configs[1]: 5.8 and 5.4 ms), so the call ends at
+        // copy(everything) + kernels(LAST piece) or copy(FIRST piece) + kernels(everything), whichever is later: a small first and
+        // a small last piece, the bulk in between (equal pieces: 8.3 ms with 4, 8.9 with 8 -- more, equal pieces only add launches)
+        int n_chunks = n_chunks_max;
+        static const double cum6[7] = {0.0, 0.06, 0.22, 0.47, 0.75, 0.93, 1.0};
+        const bool shaped = multi_pieces_option().load() == 0 && n_chunks >= 6;
+        const int n_used = shaped ? 6 : n_chunks;
+        n_chunks = n_used;
         for (int c = 0; c < MULTI_CHUNKS; c++) {
             auto &ch = s.chunk[c];
             ch.u0 = ch.u1 = 0;
-            if (c >= n_chunks) continue;
-            const int64_t lo = total * c / n_chunks, hi = total * (c + 1) / n_chunks;
+            if (c >= n_used) continue;
+            const int64_t lo = shaped ? (int64_t)(total * cum6[c]) : total * c / n_used;
+            const int64_t hi = shaped ? (int64_t)(total * cum6[c + 1]) : total * (c + 1) / n_used;
             ch.u0 = c == 0 ? 0 : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), lo) - s.offsets.begin());
-            ch.u1 = c == n_chunks - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
+            ch.u1 = c == n_used - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
             ch.u0 = std::min(ch.u0, U);
             ch.u1 = std::max(ch.u0, std::min(ch.u1, U));
         }
@@ -207,7 +226,16 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
             mfcc_extract_with(*m->mfcc, b, nd, 1, ch.feat, ch.scratch);
             const ScoreResult r = score_device(*s.set, ch.feat, false, flags);
             if (r.d_oor) SR_HIP(hipMemcpyAsync(ch.h_flags.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-            if (r.d_flush_count) SR_HIP(hipMemcpyAsync(ch.h_flags.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            ch.tiles = r.tiles;
+            ch.flush_cap = 0;
+            if (r.d_flush_count) {
+                // frames in the band of the reference's partial-product flushes are the NORMAL case on some workloads (synthetic
+                // speech against random models: ~2 k pairs per 10 M frames): keep what resolving them needs, a few MB device to device
+                SR_HIP(hipMemcpyAsync(ch.h_flags.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+                ch.d_list.ensure((size_t)std::max(1, r.flush_cap));
+                ch.flush_cap = r.flush_cap;
+                SR_HIP(hipMemcpyAsync(ch.d_list.p, r.d_flush_list, (size_t)r.flush_cap * sizeof(int2), hipMemcpyDeviceToDevice, ctx().stream));
+            }
             SR_HIP(hipMemcpyAsync(ch.h_sums.p, r.d_sums, (size_t)nu * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
             SR_HIP(hipMemcpyAsync(ch.h_argmax.p, r.d_argmax, (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
             SR_HIP(hipEventRecord(ch.done, ctx().stream));
@@ -218,7 +246,16 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
             const int nu = ch.u1 - ch.u0;
             if (nu == 0) continue;
             SR_HIP(hipEventSynchronize(ch.done));
-            if (ch.h_flags.p[0] != 0 || ch.h_flags.p[1] != 0) {
+            if (ch.h_flags.p[0] == 0 && ch.h_flags.p[1] > 0 && ch.h_flags.p[1] <= ch.flush_cap) {
+                // pairs in the band, nothing else: re-evaluate exactly those with the reference's arithmetic and complete the
+                // piece's results where they are, in host memory -- on the device's SECOND stream (what it reads -- the piece's
+                // features, the models, the list -- is nobody else's), so that its one host wait does not wait for the later
+                // pieces' kernels
+                std::lock_guard<std::recursive_mutex> lock(api_mutex());
+                StreamScope side(ctx().aux);
+                flush_resolve_host(*s.set, ch.feat, *ch.tiles, ch.d_list.p, ch.h_flags.p[1], ch.h_sums.p, ch.h_argmax.p);
+            } else if (ch.h_flags.p[0] != 0 || ch.h_flags.p[1] != 0) {
+                // a frame saturated the fp16 engine, or the list overflowed: this piece again, synchronously, from its features
                 std::lock_guard<std::recursive_mutex> lock(api_mutex());
                 const int fl = flags | (ch.h_flags.p[0] != 0 ? SCORE_PRECISE : 0);
                 ScoreResult r = score_device(*s.set, ch.feat, false, fl);
@@ -308,6 +345,7 @@ void sr_multi_free(SRMulti *m) {
                 if (ch.scratch) mfcc_scratch_delete(ch.scratch);
                 ch.scratch = nullptr;
                 ch.feat = SRBatch();
+                ch.d_list.release();
             }
         } catch (...) {
         }

@@ -152,6 +152,9 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
 // adds the tiles' sums to `d_sums`, redoes the argmax of the utterances touched, overwrites the per-frame values
 void flush_resolve(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *d_sums,
                    int *d_argmax, float *d_frame_ll);
+// the same for results that already sit in host memory (sums[U][S], argmax[U] of the batch `feat`): patched on the host, one wait
+void flush_resolve_host(SRModelSet &set, SRBatch &feat, const TileTable &tt, const int2 *d_list, int count, double *h_sums,
+                        int *h_argmax);
 int &flush_order_option();     // 2 = partial products as the reference DSO's compiler forms them (default), 1 = source order
 void flush_stats(long *calls, long *pairs, long *frames);
 // PCM batch -> MFCC -> CMVN/deltas -> all models -> sums + argmax on the host (abi.cpp; pipelined over
