@@ -40,7 +40,9 @@
 namespace sr {
 
 __host__ __device__ constexpr int split_waves_per_eu(int parts, int ks, int ft) {
-    const int regs = ft * (ks * parts * 4 + 16) + 24 + 12 * parts;
+    // (the long contractions get headroom: at ks * parts >= 14 the 128-register bucket spilled 48 bytes per lane once every wave
+    // had a tile of its own, round 4; the short ones must stay at 5 waves per SIMD -- what hides this kernel's log-sum-exp)
+    const int regs = ft * (ks * parts * 4 + 16) + (ks * parts * ft >= 14 ? 32 : 16) + 12 * parts;
     return regs <= 96 ? 5 : regs <= 128 ? 4 : regs <= 168 ? 3 : regs <= 256 ? 2 : 1;
 }
 
@@ -99,7 +101,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
     frag breg[FT][KS][P];
     bool valid[FT], has[FT];
     int tile_id[FT];
-    int64_t row[FT];
+    int64_t tile_start[FT];                    // (wave-uniform: a lane's row = tile_start + col where it is needed)
     float zmax = 0.0f;
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) {
@@ -107,8 +109,8 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         has[ft] = tile_id[ft] < n_tiles;
         const TileDesc tile = tiles[has[ft] ? tile_id[ft] : n_tiles - 1];
         valid[ft] = has[ft] && col < tile.count;
-        row[ft] = tile.start + (valid[ft] ? col : 0);
-        const float *src = X + row[ft] * dim;
+        tile_start[ft] = tile.start;
+        const float *src = X + (tile.start + (valid[ft] ? col : 0)) * dim;
         float xs[8 * KS];
 #pragma unroll
         for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < dim ? d : dim - 1];
@@ -209,7 +211,7 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
                 bool hot = false;          // a frame in the band of the reference's partial-product flushes (lse.hpp)
                 if (valid[ft] && hh == 0) {
                     mine = (double)ll;
-                    if (frame_ll) frame_ll[(int64_t)s * n_frames + row[ft]] = ll;
+                    if (frame_ll) frame_ll[(int64_t)s * n_frames + tile_start[ft] + col] = ll;
                     hot = ll < band_hi;
                 }
                 m[ft] = NEG_BIG;

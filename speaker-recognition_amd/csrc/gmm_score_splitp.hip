@@ -191,10 +191,10 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
     const bool has = tile_id < a.n_tiles;
     const TileDesc tile = tiles[has ? tile_id : a.n_tiles - 1];
     const bool valid = has && col < tile.count;
-    const int64_t row = tile.start + (valid ? col : 0);
+    const int64_t tile_start = tile.start;             // (wave-uniform; a lane's row = tile_start + col where it is needed)
     frag breg[KS][P];
     {
-        const float *src = X + row * a.dim;
+        const float *src = X + (tile_start + (valid ? col : 0)) * a.dim;
         float xs[8 * KS];
 #pragma unroll
         for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < a.dim ? d : a.dim - 1];
@@ -289,7 +289,7 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
         }
         const float ll = lse_close2(st.m, st.ssum, other_half(st.m), other_half(st.ssum), a.clamp);
         if (hh == 0) {
-            if (valid && frame_ll) frame_ll[(int64_t)model_next * a.n_frames + row] = ll;
+            if (valid && frame_ll) frame_ll[(int64_t)model_next * a.n_frames + tile_start + col] = ll;
             slab[slab_n * SLAB_STRIDE + col] = valid ? ll : 0.0f;
         }
         st.m = NEG_BIG;
