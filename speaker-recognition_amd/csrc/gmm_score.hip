@@ -732,10 +732,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // 4-wave workgroups per CU below that (measured crossover on 201 models x 512 mixtures: 30-50 k frames;
         // at 250 k frames x 1001 models x 2048 mixtures the wide form is 25 % faster, 0.128 s against 0.169 s)
         const int64_t n32 = (feat.n_rows + 31) / 32 + feat.n_utt;     // upper bound of the 32-frame tiles
-        const int64_t wide_wgs = (n32 / h2s_tiles_per_wg(H2S_WIDE_SHAPE)) * (int64_t)set.h2s.blocks.size();
-        const bool wide = wide_wgs >= (int64_t)6 * ctx().n_cu;
-        // (round 3: the wide shape with its image loop pipelined inside the wave where it exists -- chains of 2..8 MFMAs, D <= 42 --
-        // 6.5-8.5 % faster than the plain 12-wave kernel, profiles/r03_h2p_parts.txt)
+        // Round 4 (scripts/ab_h2s_small.py, 201 x 512 x 39, utterances of 300 frames): the pipelined 12-wave shape wins from
+        // ~2000 frames up -- 8 utterances 0.177 against 0.196 ms, 64 utterances 0.76 against 0.95, 256 utterances 2.31 against
+        // 3.09 -- and loses below (4 utterances 0.173 against 0.159: a few workgroups, latency-bound); round 3's rule ("fills
+        // the chip six times over") kept the 4-wave shape up to 30-50 k frames.
+        const bool wide = n32 >= 64 + feat.n_utt;
         h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_PIPELINED_SHAPE : 0);
         if (h2s_shape == H2S_PIPELINED_SHAPE && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = H2S_WIDE_SHAPE;
     }

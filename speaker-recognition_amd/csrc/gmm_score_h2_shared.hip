@@ -165,8 +165,16 @@ __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBl
 // tiles -5 %; 8 waves with the two waves of a SIMD held in anti-phase by a workgroup barrier per phase (one
 // chains while the other runs its epilogue) -3 % with one image per phase, -5 % with two.
 __host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, int waves) {
-    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf > 16) ? 2 : 3;
+    // The 4-wave shape at three workgroups per CU (168 registers) kept its quadratic-half frame fragments in scratch from
+    // kqf + klf = 10 up (156 .. 364 bytes per lane, one reload inside the image loop = an s_waitcnt vmcnt(0) on the LDS-DMA
+    // stream).  Since round 4 it only serves batches below ~2000 frames (score_device: everything larger takes a 12-wave
+    // shape) -- a handful of workgroups, latency-bound, where a third workgroup per CU buys nothing: two per CU, 256 registers,
+    // nothing in scratch.
+    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf >= 9) ? 2 : 3;
 }
+// the quadratic-half frame fragments in LDS instead of registers: every 12-wave shape (round 3), and the 4-wave shape of the long
+// chains (round 4: with them in registers it spilled 76 bytes per lane even at 256 registers)
+__host__ __device__ constexpr bool h2s_bq_in_lds(int kqf, int klf, int waves) { return waves > 4 || kqf + klf >= 9; }
 __host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) {
     // 4-wave form: 2 images per stage (three workgroups per CU share the LDS); 12-wave form: 4 (measured on the
     // configs[2]-shaped 5 M-frame pass: 8 images 0.145 s, 4 images 0.137 s, 2 images 0.138 s)
@@ -182,7 +190,7 @@ template <int KQF, int KLF, int COLS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, h2s_waves_per_eu(KQF, KLF, COLS, WAVES))
 void gmm_score_h2s_kernel(const H2sArgs a) {
     constexpr int SB = SHARED_SB;
-    constexpr bool BQ_LDS = WAVES > 4;
+    constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
     constexpr int G = BQ_LDS ? 2 : h2s_stage_images(KQF, KLF, WAVES);      // (2 images per stage measured the same as 4)
     extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64] when BQ_LDS
     constexpr int TILES_WG = WAVES * COLS;                     // 32-frame tiles per workgroup
@@ -834,7 +842,7 @@ __host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 
 
 template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false>
 static int launch_h2s(const H2sLaunch &l) {
-    constexpr bool BQ_LDS = WAVES > 4;
+    constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
     H2sArgs a;
     a.X = l.X;
     a.tiles = l.tiles;

@@ -149,14 +149,20 @@ def test_no_hot_kernel_spills(built_lib):
     for name, r in _kernel_resources("gmm_score_mfma").items():
         assert r["scratch"] == 0, (name, r)
     h2s = _kernel_resources("gmm_score_h2_shared")
-    # the shared-sigma engine's frame-operand prologue spills (its image loop holds ONE scratch load: checked in the ISA,
-    # profiles/r02_h2s_stalls.txt); a bound, so that it cannot grow unnoticed.  configs[2] / [3]: <8,8,*>
+    # the shared-sigma engine: NOTHING in scratch in any workgroup shape at any chain length (round 4: the 4-wave shape of the long
+    # chains -- configs[2] / [3]'s <8,8,*> carried 364 bytes per lane through round 3, one reload of it inside the image loop --
+    # keeps its quadratic-half frame fragments in LDS like the 12-wave shapes)
+    n_main = 0
     for name, r in h2s.items():
-        m = re.search(r"gmm_score_h2s_kernelILi(\d+)ELi(\d+)E", name)
-        if m and (int(m.group(1)), int(m.group(2))) <= (8, 8):
-            assert r["scratch"] <= 400 and r["occupancy"] >= 3, (name, r)
-            if "Li12E" in name:                      # the 12-wave shape (configs[2] / [3]): operands in LDS, nothing in scratch (round 3)
-                assert r["scratch"] == 0, (name, r)
+        if re.search(r"gmm_score_h2s_kernelILi(\d+)ELi(\d+)E", name):
+            n_main += 1
+            assert r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
+    assert n_main >= 30
+    # (the single-wave exception pass: rare by construction; its two longest chains, dims 43..48, keep a bounded spill)
+    for name, r in h2s.items():
+        m = re.search(r"gmm_score_h2s_online_kernelILi(\d+)ELi(\d+)E", name)
+        if m:
+            assert r["scratch"] <= (200 if int(m.group(1)) >= 9 else 0), (name, r)
     # the pipelined 12-wave shape (the default for large batches since round 3): NOTHING in scratch -- a spill reload inside its
     # image loop waits with vmcnt(0), i.e. for the LDS-DMA stream in flight (it cost 8 % when two fragments spilled) -- and three
     # waves per SIMD
