@@ -381,11 +381,18 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     float *s_dct = s_melval + mr.pad_floats;                         // [16][DCT_LD], zero padded
     constexpr int DCT_LD = MFCC_DCT_LD;
     const int dct_pad = 16 * DCT_LD;
-    constexpr bool LDS_TW = WPB != 4;                                // twiddle constants in LDS, not registers
+    // Frames of more than 4 rows of samples (NZ1 > 4: windows longer than 512 samples) hold 4 NZ1 window taps, 3 NZ1 sample
+    // offsets and 3 NZ1 prefetched samples per lane on top of the transform's 32 registers: through round 3 those variants
+    // spilled 460-680 bytes per lane.  They keep the twiddle constants AND the window taps in LDS (one 16-byte read per row and
+    // frame), form the offsets where they are used, and come in the 4-wave shape only (whose LDS has the room).
+    constexpr bool LDS_WIN = NZ1 > 4;
+    static_assert(!LDS_WIN || WPB == 4, "long frames: the 4-wave workgroup shape only");
+    constexpr bool LDS_TW = WPB != 4 || LDS_WIN;                     // twiddle constants in LDS, not registers
     float2 *s_wk = reinterpret_cast<float2 *>(s_dct + dct_pad);      // [N1][64] W_NC^(lane*k1) (LDS_TW only)
+    float4 *s_win = reinterpret_cast<float4 *>(s_wk + (LDS_TW ? N1 * 64 : 0));     // [NZ1][64] {w0, wm, w1, w0p} (LDS_WIN only)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float2 *slab = s_wk + (LDS_TW ? N1 * 64 : 0) + (size_t)wave * WAVE_SLAB_C;
+    float2 *slab = reinterpret_cast<float2 *>(s_win + (LDS_WIN ? NZ1 * 64 : 0)) + (size_t)wave * WAVE_SLAB_C;
     float *pbuf = reinterpret_cast<float *>(slab);          // power spectrum, 1025 floats
     float *s_lm = pbuf + 1100;                              // log-mel energies, 64 floats
 
@@ -418,14 +425,24 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     }
     const int L = p.frame_len;
     // window taps of this lane's samples: y[i0] = w0 x[i0] - wm x[i0-1], y[i0+1] = w1 x[i0+1] - w0p x[i0]
-    float win_m[NZ1], win_0[NZ1], win_1[NZ1], win_0p[NZ1];
+    constexpr int NW = LDS_WIN ? 1 : NZ1;
+    float win_m[NW], win_0[NW], win_1[NW], win_0p[NW];
+    auto taps = [&](int i0, float &w0, float &wm, float &w1, float &w0p) {
+        w0 = i0 < L ? p.window[i0] : 0.f;
+        wm = (i0 > 0 && i0 < L) ? p.window[i0 - 1] * p.pre_emph : 0.f;
+        w1 = i0 + 1 < L ? p.window[i0 + 1] : 0.f;
+        w0p = i0 + 1 < L ? w0 * p.pre_emph : 0.f;
+    };
+    if constexpr (LDS_WIN) {
+        for (int i = threadIdx.x; i < NZ1 * 64; i += 64 * WPB) {
+            float w0, wm, w1, w0p;
+            taps(2 * i, w0, wm, w1, w0p);                   // (i = 64 n1 + lane)
+            s_win[i] = make_float4(w0, wm, w1, w0p);
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int n1 = 0; n1 < NZ1; n1++) {
-        const int i0 = 2 * (64 * n1 + lane);
-        win_0[n1] = i0 < L ? p.window[i0] : 0.f;
-        win_m[n1] = (i0 > 0 && i0 < L) ? p.window[i0 - 1] * p.pre_emph : 0.f;
-        win_1[n1] = i0 + 1 < L ? p.window[i0 + 1] : 0.f;
-        win_0p[n1] = i0 + 1 < L ? win_0[n1] * p.pre_emph : 0.f;
+        for (int n1 = 0; n1 < NZ1; n1++) taps(2 * (64 * n1 + lane), win_0[n1], win_m[n1], win_1[n1], win_0p[n1]);
     }
     // mel: 4 lanes per band, 16 bands per pass
     const int m_part = lane & 3, m_bl = lane >> 2;
@@ -457,13 +474,16 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
     // Sample fetch for one frame: three taps per row (previous, even, odd sample).  Addresses are
     // clamped into the frame, never predicated: out-of-frame taps carry a zero window weight, and
     // all loads of a frame are in flight together (a predicated load forces a wait each).
-    int off_m[NZ1], off_0[NZ1], off_1[NZ1];
-#pragma unroll
-    for (int n1 = 0; n1 < NZ1; n1++) {
+    int off_m[NW], off_0[NW], off_1[NW];
+    auto offsets = [&](int n1, int &o0, int &om, int &o1) {
         const int i0 = 2 * (64 * n1 + lane);
-        off_0[n1] = i0 < L ? i0 : L - 1;
-        off_m[n1] = i0 - 1 < 0 ? 0 : (i0 - 1 < L ? i0 - 1 : L - 1);
-        off_1[n1] = i0 + 1 < L ? i0 + 1 : L - 1;
+        o0 = i0 < L ? i0 : L - 1;
+        om = i0 - 1 < 0 ? 0 : (i0 - 1 < L ? i0 - 1 : L - 1);
+        o1 = i0 + 1 < L ? i0 + 1 : L - 1;
+    };
+    if constexpr (!LDS_WIN) {
+#pragma unroll
+        for (int n1 = 0; n1 < NZ1; n1++) offsets(n1, off_0[n1], off_m[n1], off_1[n1]);
     }
     // (held as float: a 32-bit register per tap, so the prefetched samples are not re-packed --
     // packing would put a wait right behind the loads instead of one iteration later)
@@ -471,25 +491,52 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
         const PcmT *fp = pcm + base;
 #pragma unroll
         for (int n1 = 0; n1 < NZ1; n1++) {
-            x0[n1] = (float)fp[off_0[n1]];
-            xm[n1] = (float)fp[off_m[n1]];
-            x1[n1] = (float)fp[off_1[n1]];
+            int o0, om, o1;
+            if constexpr (LDS_WIN) offsets(n1, o0, om, o1);
+            else {
+                o0 = off_0[n1];
+                om = off_m[n1];
+                o1 = off_1[n1];
+            }
+            x0[n1] = (float)fp[o0];
+            xm[n1] = (float)fp[om];
+            x1[n1] = (float)fp[o1];
         }
     };
     float cm[NZ1], c0[NZ1], c1[NZ1];
     fetch(utt_s0 + (f_begin - utt_f0) * p.frame_shift, cm, c0, c1);
 
     for (int64_t frame = f_begin; frame < f_end; frame++) {
+        if constexpr (LDS_WIN) {
+            // long frames: 3 x 16 prefetched samples live across the whole transform are what used to spill; they are
+            // fetched where they are consumed instead (the wave beside this one on the SIMD covers the latency)
+            if (frame != f_begin) {
+                while (frame >= utt_f1) {
+                    utt++;
+                    utt_f0 = utt_f1;
+                    utt_f1 = frame_off[utt + 1];
+                    utt_s0 = sample_off[utt];
+                }
+                fetch(utt_s0 + (frame - utt_f0) * p.frame_shift, cm, c0, c1);
+            }
+        }
         // ---- window + pre-emphasis on the windowed samples (MFCC.py:61-64), packed z = y[2n] + i y[2n+1] ----
         float2 v[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; n1++) v[n1] = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int n1 = 0; n1 < NZ1; n1++)
-            v[n1] = make_float2(win_0[n1] * (float)c0[n1] - win_m[n1] * (float)cm[n1],
-                                win_1[n1] * (float)c1[n1] - win_0p[n1] * (float)c0[n1]);
+        for (int n1 = 0; n1 < NZ1; n1++) {
+            float w0, wm, w1, w0p;
+            if constexpr (LDS_WIN) {
+                const float4 t = s_win[n1 * 64 + lane];
+                w0 = t.x; wm = t.y; w1 = t.z; w0p = t.w;
+            } else {
+                w0 = win_0[n1]; wm = win_m[n1]; w1 = win_1[n1]; w0p = win_0p[n1];
+            }
+            v[n1] = make_float2(w0 * (float)c0[n1] - wm * (float)cm[n1], w1 * (float)c1[n1] - w0p * (float)c0[n1]);
+        }
         // ---- prefetch the next frame's samples (in flight during the transform) ----
-        if (frame + 1 < f_end) {
+        if (!LDS_WIN && frame + 1 < f_end) {
             int64_t nf = frame + 1;
             while (nf >= utt_f1) {     // utterances with zero frames are skipped
                 utt++;
@@ -902,11 +949,15 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
                 mr.pass_base[ps] = tabs.pass_base[ps];
                 mr.pass_len[ps] = tabs.pass_len[ps];
             }
+            const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
+            const int nz_inst = nz1 <= 4 ? 4 : n1;          // the instantiated NZ1
+            const bool long_frames = nz_inst > 4;           // window taps + twiddles in LDS, 4-wave workgroups only (see the kernel)
             auto lds_for = [&](int w) {
                 return (size_t)(64 * n1) * sizeof(float2) + (size_t)(tabs.pad_floats + 16 * MFCC_DCT_LD) * sizeof(float) +
-                       (w == 4 ? 0 : (size_t)n1 * 64 * sizeof(float2)) + (size_t)w * WAVE_SLAB_C * sizeof(float2);
+                       ((w == 4 && !long_frames) ? 0 : (size_t)n1 * 64 * sizeof(float2)) +
+                       (long_frames ? (size_t)nz_inst * 64 * sizeof(float4) : 0) + (size_t)w * WAVE_SLAB_C * sizeof(float2);
             };
-            int wpb = mfcc_waves_per_block();
+            int wpb = long_frames ? 4 : mfcc_waves_per_block();
             if (wpb == 12 && lds_for(12) > (size_t)160 * 1024) wpb = 4;      // a very wide filterbank: tables too big for one 12-wave workgroup
             const size_t lds = lds_for(wpb);
             // one contiguous frame range per wave; enough waves to fill the chip a few times over
@@ -915,7 +966,6 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
             const int64_t frames_per_wave = std::max<int64_t>(8, (NF + max_waves - 1) / max_waves);
             const int64_t n_waves = (NF + frames_per_wave - 1) / frames_per_wave;
             const int grid = (int)((n_waves + wpb - 1) / wpb);
-            const int nz1 = (m.frame_len + 127) / 128;      // rows n1 with any nonzero sample
             int preset = 0;
             for (int pr = 1; pr <= 2 && !preset && n1 == 16; pr++) {
                 bool same = true;
@@ -930,7 +980,11 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
     } while (0)
 #define SR_LAUNCH_FAST_P(PT, NZ, MPV, N1V, PCMPTR)                                                  \
     do {                                                                                             \
-        if (wpb == 12) SR_LAUNCH_FAST_W(PT, NZ, MPV, 12, N1V, PCMPTR); else SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, N1V, PCMPTR); \
+        if constexpr ((NZ) <= 4) {                                                                   \
+            if (wpb == 12) SR_LAUNCH_FAST_W(PT, NZ, MPV, 12, N1V, PCMPTR); else SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, N1V, PCMPTR); \
+        } else {                                                                                     \
+            SR_LAUNCH_FAST_W(PT, NZ, MPV, 4, N1V, PCMPTR);                                           \
+        }                                                                                            \
     } while (0)
 #define SR_LAUNCH_FAST_W(PT, NZ, MPV, W, N1V, PCMPTR)                                               \
     do {                                                                                             \

@@ -64,7 +64,10 @@ def test_ragged_batch_vs_oracle(built_lib):
 
 
 @pytest.mark.parametrize("fs,win,shift,fft", [(16000, 25, 10, 512), (16000, 25, 10, 1024), (8000, 32, 16, 512), (16000, 32, 16, 1024),
-                                              (16000, 50, 20, 1024), (16000, 32, 16, 512), (16000, 25, 10, 4096), (8000, 25, 10, 256)])
+                                              (16000, 50, 20, 1024), (16000, 32, 16, 512), (16000, 25, 10, 4096), (8000, 25, 10, 256),
+                                              # frames longer than 512 samples under the default FFT_SIZE 2048 (window taps and twiddles
+                                              # in LDS, round 4: these variants spilled 460-680 bytes per lane before)
+                                              (16000, 64, 20, 2048), (44100, 25, 10, 2048)])
 def test_fft_sizes_vs_oracle(built_lib, fs, win, shift, fft):
     """FFT_SIZE other than the reference's default 2048: 1024 and 512 take the register-resident kernel too (8 / 4
     points per lane in pass 1, frames of up to FFT_SIZE samples), anything else the generic LDS-pass one; raw cepstra
