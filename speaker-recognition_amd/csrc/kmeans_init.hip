@@ -31,7 +31,8 @@
 
 #include "../../include/pygmm_hip.h"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>     // the device radix sort of the Lloyd step (rocPRIM: the native library; hipCUB wraps it in CUB's API)
 
 #include <algorithm>
 #include <atomic>
@@ -542,7 +543,7 @@ void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::ve
     w.bsum.ensure((size_t)n_blocks);
     w.segsum.ensure((size_t)n_keys * dim);
     size_t tmp_bytes = 0;
-    SR_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (int)n, 0, end_bit, ctx().stream));
+    SR_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (size_t)n, 0u, (unsigned)end_bit, ctx().stream));
     w.sort_tmp.ensure(tmp_bytes);
     std::vector<double> csum((size_t)K * dim), bsum((size_t)n_blocks);
     std::vector<int> csize((size_t)K);
@@ -553,8 +554,8 @@ void lloyd_full(const float *X, long n, int dim, int K, int concurrency, std::ve
                            w.bsum.p);
         hipLaunchKernelGGL(lloyd_keys_kernel, dim3(g256), dim3(256), 0, ctx().stream, w.belong.p, n, block, K, n_keys, w.key_in.p, w.idx_in.p);
         size_t tb = w.sort_tmp.n;
-        SR_HIP(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp.p, tb, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (int)n, 0, end_bit,
-                                                  ctx().stream));                            // stable: point order inside a key
+        SR_HIP(rocprim::radix_sort_pairs(w.sort_tmp.p, tb, w.key_in.p, w.key_out.p, w.idx_in.p, w.idx_out.p, (size_t)n, 0u, (unsigned)end_bit,
+                                         ctx().stream));                                     // stable: point order inside a key
         hipLaunchKernelGGL(lloyd_segments_kernel, dim3((n_keys + 1 + 255) / 256), dim3(256), 0, ctx().stream, w.key_out.p, n, n_keys, w.seg.p);
         const size_t n_seg_elems = (size_t)n_keys * dim;
         hipLaunchKernelGGL(lloyd_segment_sum_kernel, dim3((unsigned)((n_seg_elems + 255) / 256)), dim3(256), 0, ctx().stream, w.X.p, dim,
