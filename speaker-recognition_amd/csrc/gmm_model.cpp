@@ -503,8 +503,10 @@ PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme
     }
     size_t live = 0, padded = 0;
     pm.model_chunk_begin.push_back(0);
-    // slot (ks, hh, j): feature d = 8 ks + j; hh = 0 -> A2 (pairs with x'^2), hh = 1 -> A1 (pairs with
-    // x'); the last upper slot (d = 8 KS - 1 >= dim) carries C (pairs with the constant 1)
+    // slots (ks, hh, 0..7) of contraction step ks: features f0..f3 = 8 ks + 4 hh + 0..3 as  A2 f0, A2 f1, A1 f0, A1 f1, A2 f2,
+    // A2 f3, A1 f2, A1 f3  (A2 pairs with x'^2, A1 with x'): a lane of the frame side owns BOTH powers of four features, in the
+    // pairs its packed instructions produce (split_prologue.hpp).  The last slot (A1 of d = 8 KS - 1 >= dim) carries C (pairs
+    // with the constant 1).
     std::vector<float> sq((size_t)KS * 8), lin((size_t)KS * 8);
     for (size_t s = 0; s < models.size(); s++) {
         const GMM &g = *models[s];
@@ -551,14 +553,14 @@ PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme
                 }
                 lin[(size_t)KS * 8 - 1] = cst_f;
                 for (int d = 0; d < KS * 8; d++) {
-                    const int ks = d >> 3, j = d & 7;
-                    for (int hh = 0; hh < 2; hh++) {
+                    const int ks = d >> 3, hh = (d >> 2) & 1, jp = d & 3;
+                    for (int pw = 0; pw < 2; pw++) {                 // 0: A2 (against x'^2), 1: A1 (against x')
                         uint16_t parts[3];
                         if (scheme == SPLIT_F16X2)
-                            split_f16x2(hh ? lin[d] : sq[d], parts);
+                            split_f16x2(pw ? lin[d] : sq[d], parts);
                         else
-                            split_bf16x3(hh ? lin[d] : sq[d], parts);
-                        const int lane = i + 32 * hh;
+                            split_bf16x3(pw ? lin[d] : sq[d], parts);
+                        const int lane = i + 32 * hh, j = 4 * (jp >> 1) + 2 * pw + (jp & 1);
                         for (int p = 0; p < P; p++)
                             tile[(((size_t)ks * P + p) * 64 + lane) * 8 + j] = parts[p];
                     }
@@ -574,6 +576,9 @@ PackedSplit pack_models_split(const std::vector<const GMM *> &models, int scheme
         pm.model_chunk_begin.push_back((int)pm.chunks.size());
     }
     pm.pad_waste = 1.0 - (double)live / (double)padded;
+    // the kernels index both tables with compile-time slot numbers 0 .. 8 KS - 1 (split_prologue.hpp): slots past dim are padded
+    pm.center.resize((size_t)8 * KS, 0.0f);
+    pm.scale.resize((size_t)8 * KS, 0.0f);
     return pm;
 }
 

@@ -118,8 +118,8 @@ struct PackedSplit {
     std::vector<uint16_t> params;    // 16-byte granular (8 x 16 bit)
     std::vector<ChunkDesc> chunks;   // one mixture tile per chunk; offset in 16-byte units
     std::vector<int> model_chunk_begin;
-    std::vector<float> center;       // [dim]
-    std::vector<float> scale;        // [dim], powers of two (all 1 for bf16x3)
+    std::vector<float> center;       // [8 ks]: dim entries, zero-padded (the kernels index slots, split_prologue.hpp)
+    std::vector<float> scale;        // [8 ks]: dim powers of two (all 1 for bf16x3), zero-padded
     double amp = 0.0;
     double pad_waste = 0.0;
     double sigma_ratio = 1.0;        // max over dims of (max sigma / min sigma) across all mixtures

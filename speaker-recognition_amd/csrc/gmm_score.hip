@@ -788,6 +788,27 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                                    : splitp_w ? (tt.n_tiles + splitp_w - 1) / splitp_w
                                    : use_split ? (tt.n_tiles + 4 * FT - 1) / (4 * FT) : tt.n_tiles;
             G = (target + n_wg_tiles - 1) / n_wg_tiles;
+            if (use_h2s) {
+                // Round 4: when the grid is a handful of rounds, WHICH handful matters more than having many workgroups: a
+                // workgroup is a frame prologue (about three (block, mixture tile) steps' worth; scripts/debug/h2s_small_one.py
+                // with the H2S_EXP build: 0.12 of 0.78 ms at 64 utterances x 300 frames) plus its blocks, and the chip runs
+                // ceil(workgroups / resident) rounds of the longest one.  64 x 300 frames against 14 blocks: 14 groups = 700
+                // workgroups = 3 rounds of (prologue + 1 block); 5 groups = 250 workgroups = 1 round of (prologue + 3 blocks).
+                const int n_blocks = (int)set.h2s.blocks.size();
+                const int64_t resident = (int64_t)ctx().n_cu * h2s_resident_per_cu(set.h2s.kqf, set.h2s.klf, h2s_shape);
+                const double prologue = 3.0 / std::max(1, set.h2s.n_tiles);      // in units of one block
+                double best = 0.0;
+                int best_g = 1;
+                for (int g = 1; g <= std::min(G, n_blocks); g++) {
+                    const int64_t rounds = ((int64_t)n_wg_tiles * g + resident - 1) / resident;
+                    const double cost = (double)rounds * (prologue + (double)((n_blocks + g - 1) / g));
+                    if (g == 1 || cost < best * 0.999) {
+                        best = cost;
+                        best_g = g;
+                    }
+                }
+                G = best_g;
+            }
         }
         const int n_units = use_h2s ? (int)set.h2s.blocks.size()
                             : use_shared ? (int)set.shared.blocks.size() : S;     // what a group is a range of

@@ -30,8 +30,12 @@
 // online log-sum-exp (running maximum, rescaling), a wave runs the two one after the other, and what hides the one behind the
 // other is MORE waves per SIMD (five 4-wave workgroups = 5 per SIMD) -- worth more than the third of the L2 -> LDS stream the
 // wide shape saves.  (The shared-sigma kernel's epilogue is 32 instructions with no maximum: there the wide shape wins.)
+#ifndef SPLIT_EXP
+#define SPLIT_EXP 0        // measurement builds (scripts/debug/exp_lib.sh): 1 = leave after the frame prologue
+#endif
 #include "lse.hpp"
 #include "score.hpp"
+#include "split_prologue.hpp"
 #include "split_schemes.hpp"
 #include "wave_ops.hpp"
 
@@ -94,10 +98,9 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
     stage(lds_a, chunk_begin);
     int done_next = chunks[chunk_begin].model_done;   // fetched one chunk ahead of its use
 
-    // ---- resident B fragments.  Contraction slot (ks, hh, j) is feature d = 8 ks + j: its square in
-    //      the lower half-wave (hh = 0), the value itself in the upper one (hh = 1); the very last
-    //      upper slot carries the constant 1 that picks up C_k (8 KS > dim, so it is free).
-    //      breg[ft][ks][part] = the 16-bit parts of this lane's 8 slots of step ks. ----
+    // ---- resident B fragments (split_prologue.hpp): breg[ft][ks][part] = the 16-bit parts of this lane's 8 slots of step ks.
+    //      (Tried, round 4: the tile's rows as coalesced LDS-DMA into a stage buffer, one row per lane read back -- the row
+    //      fetch alone 18 % faster, the kernel 9 % slower: the wait for the rows is also a wait for the first chunk.) ----
     frag breg[FT][KS][P];
     bool valid[FT], has[FT];
     int tile_id[FT];
@@ -110,52 +113,29 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         const TileDesc tile = tiles[has[ft] ? tile_id[ft] : n_tiles - 1];
         valid[ft] = has[ft] && col < tile.count;
         tile_start[ft] = tile.start;
-        const float *src = X + (tile.start + (valid[ft] ? col : 0)) * dim;
-        float xs[8 * KS];
-#pragma unroll
-        for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < dim ? d : dim - 1];
-        // keep the loads unconditional and batched: without this the compiler sinks each one into
-        // its own `d < dim` branch with a full wait
-#pragma unroll
-        for (int d = 0; d < 8 * KS; d++) asm volatile("" : "+v"(xs[d]));
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            uint32_t w[P][4];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int d = ks * 8 + j;
-                const int dc = d < dim ? d : dim - 1;
-                float xc = xs[d] - center[dc];
-                if constexpr (SC::SCALED) {
-                    xc *= scale[dc];
-                    if (d < dim) zmax = fmaxf(zmax, fabsf(xc));
-                    xc = fminf(fmaxf(xc, -255.0f), 255.0f);    // x'^2 stays below fp16's 65504
-                }
-                float v = hh ? xc : xc * xc;
-                v = d < dim ? v : 0.0f;
-                if (d == 8 * KS - 1) v = hh ? 1.0f : v;
-                uint32_t p[P];
-                SC::split(v, p);
-#pragma unroll
-                for (int pi = 0; pi < P; pi++) {
-                    if (j & 1)
-                        w[pi][j >> 1] |= p[pi] << 16;
-                    else
-                        w[pi][j >> 1] = p[pi];
-                }
-            }
-#pragma unroll
-            for (int pi = 0; pi < P; pi++) {
-                const uint4 u = make_uint4(w[pi][0], w[pi][1], w[pi][2], w[pi][3]);
-                breg[ft][ks][pi] = __builtin_bit_cast(frag, u);
-            }
-        }
+        split_frame_fragments<SC, KS>(X + (tile.start + (valid[ft] ? col : 0)) * dim, dim, hh, center, scale, breg[ft], zmax);
     }
     if constexpr (SC::SCALED) {
         // NaN features compare false and fall through to the arithmetic, which propagates them
         if (zmax >= 255.0f) atomicOr(oor_flag, 1);
     }
 
+#if SPLIT_EXP & 1
+    {
+        uint32_t chk = 0;
+#pragma unroll
+        for (int ft = 0; ft < FT; ft++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                for (int pi = 0; pi < P; pi++) {
+                    const uint4 u = __builtin_bit_cast(uint4, breg[ft][ks][pi]);
+                    chk ^= u.x ^ u.y ^ u.z ^ u.w;
+                }
+        if (chk == 0x12345678u) partial[0] = 1.0;
+        return;
+    }
+#endif
     float m[FT], ssum[FT];
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) {

@@ -26,6 +26,7 @@
 // A (32-frame tile, model) with a frame in the band of the reference's partial-product flushes leaves +inf (lse.hpp).
 #include "lse.hpp"
 #include "score.hpp"
+#include "split_prologue.hpp"
 #include "split_schemes.hpp"
 #include "wave_ops.hpp"
 
@@ -59,7 +60,7 @@ __host__ __device__ constexpr bool splitp_fits(int ks, int parts, int waves) {
     return splitp_lds_bytes(ks, parts, waves) <= (160 * 1024 - 512) / (waves > 8 ? 1 : 2);
 }
 
-// Parts-off builds for profiles/r04_splitp_parts.txt (scripts/debug/splitp_parts.sh: -DSPLITP_OFF=mask; results are wrong by
+// Parts-off builds for profiles/r04_splitp_parts.txt (scripts/debug/exp_lib.sh gmm_score_splitp.hip SPLITP_OFF mask; results are wrong by
 // construction, only the time means something): 1 no log-sum-exp update, 2 no model close, 4 no LDS-DMA behind the prologue,
 // 8 no fragment reads in the loop, 16 no MFMA
 #ifndef SPLITP_OFF
@@ -194,40 +195,8 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
     const int64_t tile_start = tile.start;             // (wave-uniform; a lane's row = tile_start + col where it is needed)
     frag breg[KS][P];
     {
-        const float *src = X + (tile_start + (valid ? col : 0)) * a.dim;
-        float xs[8 * KS];
-#pragma unroll
-        for (int d = 0; d < 8 * KS; d++) xs[d] = src[d < a.dim ? d : a.dim - 1];
-#pragma unroll
-        for (int d = 0; d < 8 * KS; d++) asm volatile("" : "+v"(xs[d]));       // (loads unconditional and batched)
         float zmax = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            uint32_t w[P][4];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int d = ks * 8 + j;
-                const int dc = d < a.dim ? d : a.dim - 1;
-                float xc = xs[d] - center[dc];
-                if constexpr (SC::SCALED) {
-                    xc *= scale[dc];
-                    if (d < a.dim) zmax = fmaxf(zmax, fabsf(xc));
-                    xc = fminf(fmaxf(xc, -255.0f), 255.0f);    // x'^2 stays below fp16's 65504
-                }
-                float v = hh ? xc : xc * xc;
-                v = d < a.dim ? v : 0.0f;
-                if (d == 8 * KS - 1) v = hh ? 1.0f : v;
-                uint32_t p[P];
-                SC::split(v, p);
-#pragma unroll
-                for (int pi = 0; pi < P; pi++) {
-                    if (j & 1) w[pi][j >> 1] |= p[pi] << 16;
-                    else w[pi][j >> 1] = p[pi];
-                }
-            }
-#pragma unroll
-            for (int pi = 0; pi < P; pi++) breg[ks][pi] = __builtin_bit_cast(frag, make_uint4(w[pi][0], w[pi][1], w[pi][2], w[pi][3]));
-        }
+        split_frame_fragments<SC, KS>(X + (tile_start + (valid ? col : 0)) * a.dim, a.dim, hh, center, scale, breg, zmax);
         if constexpr (SC::SCALED) {
             if (zmax >= 255.0f) atomicOr(oor_flag, 1);       // saturated: the host re-scores on the fp32-grade engines
         }

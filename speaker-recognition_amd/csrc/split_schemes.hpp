@@ -11,6 +11,8 @@ namespace sr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 struct bf16x3 {
     static constexpr int PARTS = 3, NPROD = 6;
@@ -36,6 +38,14 @@ struct bf16x3 {
         p[1] = p1 >> 16;
         p[2] = rne(r2) >> 16;
     }
+    // the parts of a pair of values, packed (v.x in the low half of every word)
+    __device__ static __forceinline__ void split2(f32x2v v, uint32_t (&p)[3]) {
+        uint32_t a[3], b[3];
+        split(v.x, a);
+        split(v.y, b);
+#pragma unroll
+        for (int i = 0; i < 3; i++) p[i] = a[i] | (b[i] << 16);
+    }
 };
 
 struct f16x2 {
@@ -52,6 +62,14 @@ struct f16x2 {
         const _Float16 l = (_Float16)(v - (float)h);
         p[0] = (uint32_t)__builtin_bit_cast(unsigned short, h);
         p[1] = (uint32_t)__builtin_bit_cast(unsigned short, l);
+    }
+    // a pair at a time: v_cvt_pk_f16_f32 (gfx950; RNE like v_cvt_f16_f32) and one v_pk_add_f32 -- 5 instructions for 4 parts
+    __device__ static __forceinline__ void split2(f32x2v v, uint32_t (&p)[2]) {
+#pragma clang fp contract(off)
+        const f16x2v h = __builtin_convertvector(v, f16x2v);
+        const f16x2v l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2v), f16x2v);
+        p[0] = __builtin_bit_cast(uint32_t, h);
+        p[1] = __builtin_bit_cast(uint32_t, l);
     }
 };
 
