@@ -290,6 +290,9 @@ void sr_kmeans_fast_stats(long *passes, long *rechecked);
 int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz);
 /* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */
 const char *sr_last_score_kernel(void);
+/* Which statistics kernel the last EM / MAP iteration of this process ran: 0 none yet, 1 vector ALU, 2 fp64 matrix cores,
+ * 3 fp64 matrix cores with the responsibilities on the 16-bit matrix cores (round 4; csrc/em.hip).  Tests and benches. */
+int sr_last_em_stats_engine(void);
 /* The first `count` values of the random stream train_model / load draw from when no seed is given: glibc's rand()
  * from its default seed, restated inside the library (the reference draws its initialisation from libc rand():
  * src/gmm/src/random.hh:22-25, gmm.hh:44, kmeansII.cc:94,133; csrc/kmeans_init.hip).  For checks. */

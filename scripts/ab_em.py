@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """EM statistics engines side by side in one GPU-box call: `ab_em.py [K] [N] [D]` fits 1 and 5 iterations (random-frame
-start, same seed) with em_stats_engine = 1 (vector ALU, per-mixture centring) and = 0 (fp64 matrix cores), prints the
+start, same seed) with em_stats_engine = 1 (vector ALU, per-mixture centring), = 2 (fp64 matrix cores, responsibilities on the vector ALU) and = 0
+(automatic: fp64 matrix cores with the responsibilities on the 16-bit ones where the model allows), prints the
 per-iteration time, the statistics kernel's HIP-event time and the largest relative parameter difference between the
 two fits."""
 import os
@@ -22,7 +23,7 @@ cent = rng.normal(0, 3, (64, D)).astype(np.float32)
 X = (cent[rng.integers(0, 64, N)] + rng.normal(0, 1, (N, D))).astype(np.float32)
 _lib.profile_enable(True)
 fits = {}
-for eng in (1, 0, 1, 0):
+for eng in (2, 0, 1, 2, 0):
     _lib.set_option("em_stats_engine", eng)
     res, ev = [], []
     for it in (1, 5):

@@ -10,7 +10,7 @@ mkdir -p ../../build_dbg
 obj=$(basename "$src" .hip).o
 OBJS=$(ls ../build/*.o | grep -v "/$obj\$")
 for m in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -D$macro=$m -c "$src" -o ../../build_dbg/${macro}$m.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -D$macro=$m $EXP_EXTRA -c "$src" -o ../../build_dbg/${macro}$m.o &
 done
 wait
 for m in "$@"; do

@@ -28,7 +28,7 @@ EXT_SYMBOLS = [
     "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
     "sr_train_f32", "sr_profile_enable", "sr_profile_reset", "sr_profile_get", "sr_set_option",
-    "sr_last_score_kernel", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
+    "sr_last_score_kernel", "sr_last_em_stats_engine", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
     "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats", "sr_host_register", "sr_host_unregister",
     "sr_mfma_peak_probe", "sr_kmeans_fast_stats",
@@ -128,6 +128,7 @@ def lib():
         "sr_profile_get": (i32, [i32, dp, C.POINTER(C.c_long)]),
         "sr_set_option": (i32, [C.c_char_p, C.c_long]),
         "sr_last_score_kernel": (C.c_char_p, []),
+        "sr_last_em_stats_engine": (C.c_int, []),
         "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
         "sr_mfma_peak_probe": (i32, [C.c_double, dp, dp]),
         "sr_kmeans_fast_stats": (None, [C.POINTER(C.c_long)] * 2),
@@ -270,6 +271,11 @@ def mfma_peak_probe(ms_target: float = 50.0):
 
 def last_score_kernel() -> str:
     return lib().sr_last_score_kernel().decode()
+
+
+def last_em_stats_engine() -> int:
+    """1 vector ALU, 2 fp64 matrix cores, 3 the same with the responsibilities on the 16-bit matrix cores (0: no E-step yet)"""
+    return int(lib().sr_last_em_stats_engine())
 
 
 def profile_enable(on: bool = True) -> None:

@@ -23,6 +23,7 @@ void reference_rand_sample(int *out, int count);
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed);
 void set_em_stats_engine(int v);
+int last_em_stats_engine();
 void set_reference_side_effects(int v);
 void set_kmeans_assign_engine(int v);
 }
@@ -764,7 +765,8 @@ int sr_set_option(const char *key, long value) {
         if (value != 0 && value != 1) fail("reference_side_effects must be 0 or 1");
         set_reference_side_effects((int)value);
     } else if (k == "em_stats_engine") {
-        if (value != 0 && value != 1) fail("em_stats_engine must be 0 (automatic: fp64 matrix cores for dims <= 40) or 1 (vector ALU)");
+        if (value < 0 || value > 2)
+            fail("em_stats_engine must be 0 (automatic), 1 (vector ALU) or 2 (fp64 matrix cores, responsibilities on the vector ALU)");
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
@@ -785,6 +787,7 @@ int sr_set_option(const char *key, long value) {
 }
 
 const char *sr_last_score_kernel(void) { return last_score_kernel(); }
+int sr_last_em_stats_engine(void) { return sr::last_em_stats_engine(); }
 
 void sr_flush_stats(long *calls, long *pairs, long *frames) { flush_stats(calls, pairs, frames); }
 

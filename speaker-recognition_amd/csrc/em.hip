@@ -13,14 +13,18 @@
 // update does not cancel).  The M-step is O(K*D) and runs on the host in float64 with the
 // reference's formulas.
 #include "score.hpp"
+#include "split_prologue.hpp"
+#include "split_schemes.hpp"
 #include "wave_ops.hpp"
 
 #include "../../include/pygmm_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <memory>
 
 namespace sr {
 
@@ -323,11 +327,189 @@ static size_t emm_lds_bytes(int DP) {
            (size_t)EMM_WAVES * EMM_MB * EMM_GS * sizeof(float);
 }
 
+// ---- round 4: the responsibilities on the 16-bit matrix cores -------------------------------------------------------------------
+// em_stats_mfma_kernel's phase A is 2 D fused multiply-adds per (frame, mixture) on the vector ALU, and v_mfma_f64 shares that
+// ALU's rate (above): 11 k of the tile's 24 k cycles.  Here the log2 densities come from the scoring engine's own contraction
+// (gmm_score_split.hip, scheme bf16x3: three bf16 parts per operand, six part products, fp32-grade without range conditions)
+// against the set's split-bf16 layout -- the one the pass that produced frame_ll has just run on -- and only exp2(. - lse) stays on
+// the vector ALU.  One 8-wave workgroup owns 128 mixtures (four 32-mixture tiles, A fragments resident in LDS) and walks its
+// frame chunk in tiles of 128 frames:
+//   phase A': wave w takes the 32 frames (w & 3) of the tile and the mixture tiles 2 (w >> 2), + 1: builds the frames' B
+//             fragments from the transposed rows in LDS (split_prologue.hpp), 2 x 6 KS MFMAs, exp2, responsibilities -> LDS
+//             [mixture][frame];
+//   phase B : as em_stats_mfma_kernel -- wave w owns mixtures 16 w .. 16 w + 15 over all 128 frames, fp64 MFMAs from fp32-exact
+//             operands into accumulators that live in registers until the chunk is done.
+// Same slabs, same reduction; the statistics themselves are float64 as before.
+constexpr int EMS_WAVES = 8, EMS_WG_MIX = EMS_WAVES * EMM_MB;       // 128 mixtures = 4 tiles of the split layout
+__host__ __device__ constexpr int ems_lds_bytes(int ks) {
+    return 4 * ks * 3 * 64 * 16 + 8 * ks * EMM_XS * 4 + EMS_WG_MIX * EMM_GS * 4;
+}
+
+template <int DP, int KS>
+__global__ __launch_bounds__(EMS_WAVES * 64, 2)
+void em_stats_split_kernel(const float *__restrict__ X, int64_t n_frames, int dim, const uint4 *__restrict__ frags /* the model's split-bf16 tiles */,
+                           int n_mix_tiles, const float *__restrict__ center /* [8 KS], of that layout */,
+                           const float *__restrict__ frame_ll,
+                           double *__restrict__ slabs /* [gridDim.y][gridDim.x * 128][NCB * 16] */, int n_tiles) {
+    typedef bf16x3 SC;
+    constexpr int P = SC::PARTS, TILE_U4 = KS * P * 64;
+    constexpr int NFULL = DP / 16, REM = DP % 16, NCB = emm_ncb(DP);
+    extern __shared__ uint4 ems_lds[];
+    uint4 *afr = ems_lds;                                          // [4 tiles][KS * P][64]
+    float *xt = reinterpret_cast<float *>(afr + 4 * TILE_U4);      // raw rows of the tile, [slot feature][frame], stride EMM_XS
+    float *gs = xt + 8 * KS * EMM_XS;                              // responsibilities [mixture][frame], stride EMM_GS
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile0 = blockIdx.x * 4;                              // first mixture tile of this workgroup
+    // ---- this workgroup's A fragments -> LDS (tiles beyond the model stay unread: their responsibilities are forced to 0)
+    for (int i = tid; i < 4 * TILE_U4; i += EMS_WAVES * 64) {
+        const int t = tile0 + i / TILE_U4;
+        afr[i] = t < n_mix_tiles ? frags[(size_t)t * TILE_U4 + (i % TILE_U4)] : make_uint4(0, 0, 0, 0);
+    }
+    // rows of the slots beyond dim read as 0 (the DMA below never writes them)
+    for (int i = tid; i < 8 * KS * EMM_XS; i += EMS_WAVES * 64) xt[i] = 0.f;
+    const int tiles_per = (n_tiles + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_begin = (int)blockIdx.y * tiles_per, t_end = min(n_tiles, t_begin + tiles_per);
+    // The tile's rows are one contiguous run of (frames in the tile) x dim floats.  Thread t carries elements t, t + 512, ... of the
+    // NEXT tile in registers from the start of the current tile's phases (one workgroup per CU: a fetch between two tiles would
+    // be waited for by everybody) and scatters them into the transposed tile xt[feature][frame] when the tile begins.
+    constexpr int NPF = (EMM_FT * DP + EMS_WAVES * 64 - 1) / (EMS_WAVES * 64);
+    int pf_off[NPF];                                               // LDS offset of element tid + 512 i, -1 beyond the tile
+    {
+        int f = tid / dim, d = tid - f * dim;
+        const int qs = (EMS_WAVES * 64) / dim, rs = (EMS_WAVES * 64) - qs * dim;
+#pragma unroll
+        for (int i = 0; i < NPF; i++) {
+            pf_off[i] = f < EMM_FT ? d * EMM_XS + f : -1;
+            d += rs;
+            f += qs;
+            if (d >= dim) {
+                d -= dim;
+                f++;
+            }
+        }
+    }
+    float pf[NPF], pf_ll;
+    auto prefetch_tile = [&](int tile) {
+        const int64_t f0 = (int64_t)tile * EMM_FT;
+        const int nfl = (int)min((int64_t)EMM_FT, n_frames - f0) * dim;       // floats of the tile that exist
+        const float *src = X + f0 * dim;
+#pragma unroll
+        for (int i = 0; i < NPF; i++) {
+            const int e = tid + i * (EMS_WAVES * 64);
+            pf[i] = e < nfl ? src[e] : 0.f;                          // (frames beyond the data: zeros, and no responsibility)
+        }
+        const int64_t frame = f0 + 32 * (wave & 3) + (lane & 31);      // the frame this lane turns into a B fragment column
+        pf_ll = frame < n_frames ? frame_ll[frame] : -3.0e38f;
+    };
+    // phase A' roles
+    const int col = lane & 31, hh = lane >> 5;
+    const int ft = wave & 3, mp = wave >> 2;
+    float cs[KS][4], ss[KS][4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cs[ks][i] = center[8 * ks + 4 * hh + i];
+            ss[ks][i] = 1.0f;
+        }
+    const bool live0 = tile0 + 2 * mp < n_mix_tiles, live1 = tile0 + 2 * mp + 1 < n_mix_tiles;
+    // phase B roles (as em_stats_mfma_kernel)
+    const int j = lane & 15, fl = lane >> 4;
+    constexpr int NMIX = NCB - 2 * NFULL;
+    int boff[NFULL > 0 ? NFULL : 1], moff[NMIX];
+    double al[NMIX], be[NMIX], ga[NMIX];
+#pragma unroll
+    for (int cb = 0; cb < NFULL; cb++) boff[cb] = (16 * cb + j) * EMM_XS + fl;
+#pragma unroll
+    for (int mb = 0; mb < NMIX; mb++) {
+        const int q = 16 * mb + j;
+        int d = 0;
+        al[mb] = be[mb] = ga[mb] = 0.0;
+        if (q < REM) { d = 16 * NFULL + q; al[mb] = 1.0; }
+        else if (q < 2 * REM) { d = 16 * NFULL + q - REM; be[mb] = 1.0; }
+        else if (q == 2 * REM) ga[mb] = 1.0;
+        moff[mb] = d * EMM_XS + fl;
+    }
+    f64x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[cb] = (f64x4){0.0, 0.0, 0.0, 0.0};
+    const float *g = gs + (size_t)wave * EMM_MB * EMM_GS;
+
+    if (t_begin < t_end) prefetch_tile(t_begin);
+    for (int tile = t_begin; tile < t_end; tile++) {
+        __syncthreads();                       // every wave is done with the previous tile's rows and responsibilities
+#pragma unroll
+        for (int i = 0; i < NPF; i++)
+            if (pf_off[i] >= 0) xt[pf_off[i]] = pf[i];
+        // underflowed frames (and the lanes beyond the data) carry no responsibility (gmm.cc:482-498): their "log-likelihood"
+        // is +1e30, so every 2^(. - lse2) below is 0 without a select
+        const float lse2 = pf_ll >= EM_MINLOG ? pf_ll * LOG2E_F : 1.0e30f;
+        __syncthreads();                       // this tile's rows are in place for every wave (and `afr` is filled)
+        if (tile + 1 < t_end) prefetch_tile(tile + 1);
+        // ---- phase A'
+        {
+            float xs[KS][4];
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) xs[ks][i] = xt[(8 * ks + 4 * hh + i) * EMM_XS + 32 * ft + col];
+            typename SC::frag breg[KS][P];
+            float zmax = 0.0f;
+            split_fragments_from_values<SC, KS>(xs, cs, ss, dim, hh, breg, zmax);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint4 *at = afr + (2 * mp + t) * TILE_U4 + lane;
+                f32x16 c16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    typename SC::frag a[P];
+#pragma unroll
+                    for (int pi = 0; pi < P; pi++) a[pi] = __builtin_bit_cast(typename SC::frag, at[(ks * P + pi) * 64]);
+#pragma unroll
+                    for (int pr = 0; pr < SC::NPROD; pr++) c16 = SC::mfma(a[SC::AI[pr]], breg[ks][SC::BI[pr]], c16);
+                }
+                // accumulator r of lane (col, hh) is mixture row 8 (r / 4) + 4 hh + r % 4 of the tile, frame column col
+                const float off = (t ? live1 : live0) ? lse2 : 1.0e30f;      // (a tile beyond the model: no responsibilities)
+                float *grow = gs + (size_t)(32 * (2 * mp + t) + 4 * hh) * EMM_GS + 32 * ft + col;
+#pragma unroll
+                for (int r = 0; r < 16; r++) grow[(8 * (r >> 2) + (r & 3)) * EMM_GS] = __builtin_amdgcn_exp2f(c16[r] - off);
+            }
+        }
+        __syncthreads();                       // the responsibilities of all 128 mixtures x 128 frames are in LDS
+        // ---- phase B: EMM_FT / 4 frame groups x NCB column blocks on the fp64 matrix cores
+#pragma unroll 4
+        for (int fg = 0; fg < EMM_FT / 4; fg++) {
+            const double av = (double)g[j * EMM_GS + 4 * fg + fl];             // A[mixture j][frame 4 fg + fl]
+#pragma unroll
+            for (int cb = 0; cb < NFULL; cb++) {
+                const double v = (double)xt[boff[cb] + 4 * fg];
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v, acc[cb], 0, 0, 0);
+                acc[NFULL + cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, v * v, acc[NFULL + cb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < NMIX; mb++) {
+                const double v = (double)xt[moff[mb] + 4 * fg];
+                const double y = __builtin_fma(v, __builtin_fma(be[mb], v, al[mb]), ga[mb]);
+                acc[2 * NFULL + mb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y, acc[2 * NFULL + mb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- this workgroup's sums -> its slab: D[mixture (l >> 4) + 4 r][column l & 15]
+    double *slab = slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * EMS_WG_MIX * (NCB * 16);
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            slab[(size_t)(wave * EMM_MB + fl + 4 * r) * (NCB * 16) + 16 * cb + j] = acc[cb][r];
+}
+
 // sums the frame chunks' slabs in chunk order and unpacks the column blocks: out[k][2 DP + 1] = sum g x_d | sum g x_d^2 | sum g
 template <int DP>
 __global__ __launch_bounds__(256)
 void em_reduce64_kernel(const double *__restrict__ slabs, int n_chunks, int n_ranges, int k_pad /* the old layout's */,
-                        double *__restrict__ out) {
+                        double *__restrict__ out, int wg_mix /* mixtures per range: EMM_WG_MIX or EMS_WG_MIX */) {
     constexpr int REC = 2 * DP + 1, NFULL = DP / 16, REM = DP % 16, NC = emm_ncb(DP) * 16;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= k_pad * REC) return;
@@ -338,11 +520,11 @@ void em_reduce64_kernel(const double *__restrict__ slabs, int n_chunks, int n_ra
     if (kind == 2) col = 2 * NFULL * 16 + 2 * REM;
     else if (d < 16 * NFULL) col = (kind == 0 ? 0 : NFULL * 16) + d;
     else col = 2 * NFULL * 16 + (d - 16 * NFULL) + (kind == 0 ? 0 : REM);
-    const int range = k / EMM_WG_MIX, kk = k - range * EMM_WG_MIX;
+    const int range = k / wg_mix, kk = k - range * wg_mix;
     double acc = 0.0;
     if (range < n_ranges)
         for (int ch = 0; ch < n_chunks; ch++)
-            acc += slabs[(((size_t)ch * n_ranges + range) * EMM_WG_MIX + kk) * NC + col];
+            acc += slabs[(((size_t)ch * n_ranges + range) * wg_mix + kk) * NC + col];
     out[e] = acc;
 }
 
@@ -390,14 +572,45 @@ static void launch_stats_mfma(const float *X, int64_t n, int dim, const float4 *
                        n, dim, params, center, n_records, frame_ll, slabs, n_tiles64);
     const int n_elem = k_pad * (2 * DP + 1);
     hipLaunchKernelGGL((em_reduce64_kernel<DP>), dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, ctx().stream, slabs, n_chunks,
-                       n_ranges, k_pad, out);
+                       n_ranges, k_pad, out, EMM_WG_MIX);
+}
+
+template <int DP, int KS>
+static void launch_stats_split(const float *X, int64_t n, int dim, const uint4 *frags, int n_mix_tiles, const float *center,
+                               const float *frame_ll, double *slabs, int n_tiles128, int n_ranges, int n_chunks, int k_pad, double *out) {
+    static_assert(8 * KS >= DP, "the transposed tile has a row per slot feature");
+    static bool attr_set[MAX_DEVICES] = {};
+    if (!attr_set[ctx().device]) {
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&em_stats_split_kernel<DP, KS>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, ems_lds_bytes(KS)));
+        attr_set[ctx().device] = true;
+    }
+    hipLaunchKernelGGL((em_stats_split_kernel<DP, KS>), dim3(n_ranges, n_chunks), dim3(EMS_WAVES * 64), ems_lds_bytes(KS), ctx().stream, X,
+                       n, dim, frags, n_mix_tiles, center, frame_ll, slabs, n_tiles128);
+    const int n_elem = k_pad * (2 * DP + 1);
+    hipLaunchKernelGGL((em_reduce64_kernel<DP>), dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, ctx().stream, slabs, n_chunks,
+                       n_ranges, k_pad, out, EMS_WG_MIX);
+}
+
+// instantiated for the (padded dim, contraction steps) pairs whose LDS fits a CU (DP = 40 with dim = 40 has KS = 6: 164 KB)
+static bool stats_split_available(int DP, int dim) {
+    const int ks = (dim + 8) / 8;
+    return DP <= 40 && 8 * ks >= DP && ems_lds_bytes(ks) <= 160 * 1024;
+}
+static void dispatch_stats_split(int DP, int KS, const float *X, int64_t n, int dim, const uint4 *frags, int n_mix_tiles, const float *center,
+                                 const float *frame_ll, double *slabs, int n_tiles128, int n_ranges, int n_chunks, int k_pad, double *out) {
+#define SR_CASE(V, W) if (DP == V && KS == W) return launch_stats_split<V, W>(X, n, dim, frags, n_mix_tiles, center, frame_ll, slabs, n_tiles128, n_ranges, n_chunks, k_pad, out);
+    SR_CASE(8, 1) SR_CASE(8, 2) SR_CASE(13, 2) SR_CASE(16, 2) SR_CASE(16, 3) SR_CASE(24, 3) SR_CASE(24, 4) SR_CASE(26, 4)
+    SR_CASE(32, 4) SR_CASE(32, 5) SR_CASE(34, 5) SR_CASE(39, 5) SR_CASE(40, 5)
+#undef SR_CASE
+    fail("no split-responsibility EM kernel for padded dim %d with %d contraction steps", DP, KS);
 }
 
 // the fp64 matrix-core form is instantiated for padded dims <= 40 (its LDS -- 16 parameter records, a transposed 128-frame
 // tile, the responsibilities: 75 KiB at DP = 39 -- lets two workgroups share a CU); wider rows keep em_stats_kernel
 static bool stats_mfma_available(int DP) { return DP <= 40; }
-static size_t stats_mfma_slab_doubles(int DP, int n_ranges, int n_chunks) {
-    return (size_t)n_chunks * n_ranges * EMM_WG_MIX * (size_t)(emm_ncb(DP) * 16);
+static size_t stats_mfma_slab_doubles(int DP, int n_ranges, int n_chunks, int wg_mix = EMM_WG_MIX) {
+    return (size_t)n_chunks * n_ranges * wg_mix * (size_t)(emm_ncb(DP) * 16);
 }
 static void dispatch_stats_mfma(int DP, const float *X, int64_t n, int dim, const float4 *params, const float *center, int n_records,
                                 const float *frame_ll, double *slabs, int n_tiles64, int n_ranges, int n_chunks, int k_pad, double *out) {
@@ -413,15 +626,26 @@ static void dispatch_stats_mfma(int DP, const float *X, int64_t n, int dim, cons
 void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Parameter &param, long seed);
 void burn_reference_rand(int count);
 
+// The model of one EM / MAP iteration as a set: the vector-ALU layout (the statistics kernels' records) and -- round 4 -- the
+// split-bf16 one, so that the posteriors' denominators and the total log-likelihood of every second iteration run on the matrix
+// cores at the same fp32 grade (K = 2048 x 39, 400 k frames: 2.7 ms on the vector engine per pass); score_device falls back to
+// the vector engine by itself while the model is outside that layout's range (collapsed variances early in a fit).
+static void pack_em_set(SRModelSet &set, const GMM &gmm) {
+    set.host = pack_models({&gmm});
+    if (gmm.dim <= MAX_MATRIX_DIM && score_options().engine == 0) set.bx3 = pack_models_split({&gmm}, SPLIT_BF16X3);
+}
+
 struct EmWorkspace {
     DevBuf<float> slabs, mean_f32;
     DevBuf<double> stats, slabs64;
 };
 static int &em_stats_engine_option() {
-    static int v = 0;       // 0 = automatic (fp64 matrix cores where instantiated), 1 = the vector-ALU form always
+    static int v = 0;       // 0 = automatic (fp64 matrix cores where instantiated; responsibilities on the 16-bit ones where the model allows), 1 = the vector-ALU form always, 2 = fp64 matrix cores with the responsibilities on the vector ALU (round 3's)
     return v;
 }
 void set_em_stats_engine(int v) { em_stats_engine_option() = v; }
+static std::atomic<int> g_last_stats_engine{0};
+int last_em_stats_engine() { return g_last_stats_engine.load(); }
 // The reference's trainers leave traces a drop-in user may be relying on: the parameter block on stdout at every train_model*
 // call (pygmm.cc:31-41, :64, :88) and, after every second iteration, the model written to
 // ./gmm-training-intermediate-dump.model with two lines around it (gmm.cc:622-630, unconditional: `if (true || ...)`).
@@ -484,13 +708,21 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     int it = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool trace = param.verbosity >= 2;                 // phase times of every iteration on stdout
+    std::unique_ptr<SRModelSet> carried;
     for (; it < param.nr_iteration; it++) {
         // ---- E-step ----
         const double t0 = now();
-        SRModelSet set;
-        set.host = pack_models({&gmm});
+        // (the model as the previous iteration left it is already packed and resident when that iteration computed its total
+        // log-likelihood: every second one, gmm.cc:622-623)
+        std::unique_ptr<SRModelSet> set_owner = std::move(carried);
+        const bool fresh = !set_owner;
+        if (fresh) {
+            set_owner = std::make_unique<SRModelSet>();
+            pack_em_set(*set_owner, gmm);
+        }
+        SRModelSet &set = *set_owner;
         const double t1 = now();
-        upload_model_set(set);
+        if (fresh) upload_model_set(set);
         if (trace) sync_stream();
         const double t2 = now();
         const int DP = set.host.dp;
@@ -502,8 +734,23 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         const double t3 = now();
         const size_t n_elem = (size_t)K_pad * REC;
         w.stats.ensure(n_elem);
-        const bool use_mfma = stats_mfma_available(DP) && em_stats_engine_option() == 0;
-        if (use_mfma) {
+        const int stats_engine = em_stats_engine_option();
+        const bool use_mfma = stats_mfma_available(DP) && stats_engine != 1;
+        // round 4: responsibilities on the 16-bit matrix cores when the model is inside the split-bf16 layout's range -- the
+        // engine score_device has just taken for the denominators (em_stats_engine = 2 keeps them on the vector ALU)
+        const bool use_split = use_mfma && stats_engine == 0 && split_bf16_in_range(set) && stats_split_available(DP, dim);
+        g_last_stats_engine.store(use_split ? 3 : use_mfma ? 2 : 1);
+        if (use_split) {
+            ensure_bx3_layout(set);
+            const int n_mix_tiles = (int)set.bx3.chunks.size();
+            const int n_ranges = (n_mix_tiles + 3) / 4;
+            const int n_tiles128 = (int)((n + EMM_FT - 1) / EMM_FT);
+            const int n_chunks = std::max(1, std::min(n_tiles128, (4 * ctx().n_cu + n_ranges - 1) / n_ranges));
+            w.slabs64.ensure(stats_mfma_slab_doubles(DP, n_ranges, n_chunks, EMS_WG_MIX));
+            ScopedKernelTimer t(T_ESTEP);
+            dispatch_stats_split(DP, set.bx3.ks, feat.data.p, n, dim, reinterpret_cast<const uint4 *>(set.d_bx3_params.p), n_mix_tiles,
+                                 set.d_bx3_center.p, sres.d_frame_ll, w.slabs64.p, n_tiles128, n_ranges, n_chunks, K_pad, w.stats.p);
+        } else if (use_mfma) {
             // sums about the origin on the fp64 matrix cores (em_stats_mfma_kernel); re-centred below
             const int n_ranges = (n_records + EMM_WG_MIX / KB - 1) / (EMM_WG_MIX / KB);
             const int n_tiles64 = (int)((n + EMM_FT - 1) / EMM_FT);
@@ -640,8 +887,9 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
             printf("model dumped to %s ...\n", dump_file);
         }
         // total log-likelihood under the updated model (gmm.cc:631-641), reference clamp on
-        SRModelSet set2;
-        set2.host = pack_models({&gmm});
+        carried = std::make_unique<SRModelSet>();
+        SRModelSet &set2 = *carried;
+        pack_em_set(set2, gmm);
         upload_model_set(set2);
         double ll = 0.0;
         score_batch_set(set2, feat, &ll, nullptr, nullptr, SR_CLAMP_COMPAT | SCORE_PRECISE);

@@ -237,36 +237,61 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
 // reference's argmax -- first maximum wins (gmmset.py:62-64, `max(enumerate(scores), key=...)`).
 // A (tile, model) whose partial is SR_FLUSH_POISON holds a frame in the band where the reference's flushes of partial
 // products decide (lse.hpp): it is left out of the sum and noted for gmm_flush.hip, which adds the tile's sum later.
+//
+// The order (round 4): the utterance's tiles in segments of `seg` consecutive tiles -- 32, or more for utterances of more
+// than 32 k tiles, so that there are at most 1024 segments -- each summed front to back, then the segment sums front to back.
+// It depends on the utterance's own tile count only, never on the batch around it.  One thread per (segment, model): until
+// round 4 one thread per model walked ALL the tiles, which for the one long utterance of an E-step (400 k frames = 12 500
+// tiles, one model) was 1.7 ms of dependent loads behind a 0.6 ms scoring kernel.
+constexpr int FIN_LDS_DOUBLES = 4096;
 __global__ __launch_bounds__(256)
 void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n_models,
                          int per_tile, double *sums, int *argmax, int2 *flush_list, int *flush_count, int flush_cap) {
+    __shared__ double seg_sum[FIN_LDS_DOUBLES];
     const int u = blockIdx.x;
     const int tb = utt_tile_begin[u], te = utt_tile_begin[u + 1];
+    const int n_t = te - tb;
+    const int seg = max(32, (n_t + 1023) / 1024);
+    const int n_seg = (n_t + seg - 1) / seg;                   // <= 1024
+    const int mb = max(1, min(n_models, FIN_LDS_DOUBLES / max(1, n_seg)));      // models per pass
     double best = -INFINITY;
     int best_i = 0x7fffffff;
-    for (int s = threadIdx.x; s < n_models; s += 256) {
-        double acc = 0.0;
-        for (int t = tb; t < te; t++) {
-            // per_tile = 4: one double per wave of the tile's workgroup; 1: already combined
-            const double *p = partial + ((int64_t)t * n_models + s) * per_tile;
-            double tile_sum = 0.0;
-            bool poisoned = false;
-            for (int i = 0; i < per_tile; i++) {
-                poisoned |= flush_poisoned(p[i]);
-                tile_sum += p[i];
+    for (int s0 = 0; s0 < n_models; s0 += mb) {
+        const int m = min(mb, n_models - s0);
+        for (int item = threadIdx.x; item < n_seg * m; item += 256) {
+            const int sg = item / m, s = s0 + item - sg * m;   // (consecutive threads: consecutive models of one segment)
+            const int t0 = tb + sg * seg, t1 = min(te, t0 + seg);
+            double acc = 0.0;
+            for (int t = t0; t < t1; t++) {
+                // per_tile = 4: one double per wave of the tile's workgroup; 1: already combined
+                const double *p = partial + ((int64_t)t * n_models + s) * per_tile;
+                double tile_sum = 0.0;
+                bool poisoned = false;
+                for (int i = 0; i < per_tile; i++) {
+                    poisoned |= flush_poisoned(p[i]);
+                    tile_sum += p[i];
+                }
+                if (__builtin_expect(poisoned && flush_count != nullptr, 0)) {
+                    const int idx = atomicAdd(flush_count, 1);
+                    if (idx < flush_cap) flush_list[idx] = make_int2(t, s);
+                    continue;
+                }
+                acc += tile_sum;
             }
-            if (__builtin_expect(poisoned && flush_count != nullptr, 0)) {
-                const int idx = atomicAdd(flush_count, 1);
-                if (idx < flush_cap) flush_list[idx] = make_int2(t, s);
-                continue;
+            seg_sum[item] = acc;
+        }
+        __syncthreads();
+        for (int sl = threadIdx.x; sl < m; sl += 256) {
+            double acc = 0.0;
+            for (int sg = 0; sg < n_seg; sg++) acc += seg_sum[sg * m + sl];
+            const int s = s0 + sl;
+            sums[(int64_t)u * n_models + s] = acc;
+            if (acc > best) {                                  // (a thread meets its models in increasing order)
+                best = acc;
+                best_i = s;
             }
-            acc += tile_sum;
         }
-        sums[(int64_t)u * n_models + s] = acc;
-        if (acc > best) {
-            best = acc;
-            best_i = s;
-        }
+        __syncthreads();
     }
     __shared__ double sv[256];
     __shared__ int si[256];
@@ -634,7 +659,11 @@ static bool f16_ok(const PackedSplit &p) {
            p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
 }
 
-static void ensure_bx3_layout(SRModelSet &s) {
+bool split_bf16_in_range(const SRModelSet &s) {
+    return !s.bx3.params.empty() && s.bx3.amp <= MFMA_MAX_AMP && s.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
+}
+
+void ensure_bx3_layout(SRModelSet &s) {
     if (s.d_bx3_params.p) return;
     s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
     s.d_bx3_chunks.upload(s.bx3.chunks.data(), s.bx3.chunks.size());

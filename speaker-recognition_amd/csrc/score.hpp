@@ -165,6 +165,9 @@ namespace sr {
 void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out, int *argmax_out, int flags);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);
+// the split-bf16 layout of a set that carries one (s.bx3), on the device: lazily, as every matrix-core layout (em.hip reads it too)
+void ensure_bx3_layout(SRModelSet &s);
+bool split_bf16_in_range(const SRModelSet &s);       // what score_device asks before it takes that engine
 // Packs the layouts a set needs (all of them for small sets; for large ones the vector layout plus
 // the one the dispatcher will pick, or the one forced by score_engine at creation time).
 void pack_model_set(SRModelSet &s, const std::vector<const GMM *> &models);

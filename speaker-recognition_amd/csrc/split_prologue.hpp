@@ -20,30 +20,15 @@
 
 namespace sr {
 
-// `row` = this lane's frame; `center`, `scale` = the packer's tables, 8 KS entries (scale: SC::SCALED only).
-// zmax: running maximum of |x'| (SC::SCALED: what the caller compares with the fp16 range).
+// The arithmetic on values already in registers: xs[ks][i] = feature 8 ks + 4 hh + i of this lane's frame, cs / ss the table
+// entries of the same slots (ss: SC::SCALED only).  zmax: running maximum of |x'| (SC::SCALED: what the caller compares with
+// the fp16 range).
 template <typename SC, int KS>
-__device__ __forceinline__ void split_frame_fragments(const float *__restrict__ row, int dim, int hh,
-                                                      const float *__restrict__ center, const float *__restrict__ scale,
-                                                      typename SC::frag (&breg)[KS][SC::PARTS], float &zmax) {
+__device__ __forceinline__ void split_fragments_from_values(const float (&xs)[KS][4], const float (&cs)[KS][4], const float (&ss)[KS][4],
+                                                            int dim, int hh, typename SC::frag (&breg)[KS][SC::PARTS], float &zmax) {
 #pragma clang fp contract(off)        // (x'^2 - hi(x'^2) must not become an fma of x' with itself: the parts are those of the fp32 square)
     constexpr int P = SC::PARTS;
     typedef typename SC::frag frag;
-    float xs[KS][4], cs[KS][4], ss[KS][4];
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int d = 8 * ks + 4 * hh + i;
-            xs[ks][i] = row[(ks < KS - 1 || d < dim) ? d : dim - 1];
-            cs[ks][i] = center[d];
-            if constexpr (SC::SCALED) ss[ks][i] = scale[d];
-        }
-    // keep the loads unconditional and batched: without this the compiler sinks them into the branches of the last step
-#pragma unroll
-    for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(xs[ks][i]));
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
         uint32_t w[P][4];
@@ -77,6 +62,30 @@ __device__ __forceinline__ void split_frame_fragments(const float *__restrict__ 
 #pragma unroll
         for (int pi = 0; pi < P; pi++) breg[ks][pi] = __builtin_bit_cast(frag, make_uint4(w[pi][0], w[pi][1], w[pi][2], w[pi][3]));
     }
+}
+
+// `row` = this lane's frame in global memory; `center`, `scale` = the packer's tables, 8 KS entries (scale: SC::SCALED only).
+template <typename SC, int KS>
+__device__ __forceinline__ void split_frame_fragments(const float *__restrict__ row, int dim, int hh,
+                                                      const float *__restrict__ center, const float *__restrict__ scale,
+                                                      typename SC::frag (&breg)[KS][SC::PARTS], float &zmax) {
+    float xs[KS][4], cs[KS][4], ss[KS][4];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int d = 8 * ks + 4 * hh + i;
+            xs[ks][i] = row[(ks < KS - 1 || d < dim) ? d : dim - 1];
+            cs[ks][i] = center[d];
+            ss[ks][i] = 1.0f;
+            if constexpr (SC::SCALED) ss[ks][i] = scale[d];
+        }
+    // keep the loads unconditional and batched: without this the compiler sinks them into the branches of the last step
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) asm volatile("" : "+v"(xs[ks][i]));
+    split_fragments_from_values<SC, KS>(xs, cs, ss, dim, hh, breg, zmax);
 }
 
 }  // namespace sr

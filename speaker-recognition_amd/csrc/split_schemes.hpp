@@ -38,13 +38,19 @@ struct bf16x3 {
         p[1] = p1 >> 16;
         p[2] = rne(r2) >> 16;
     }
-    // the parts of a pair of values, packed (v.x in the low half of every word)
+    // the parts of a pair of values, packed (v.x in the low half of every word): v_cvt_pk_bf16_f32 (gfx950; RNE, as `split`)
+    // and a shift / a mask to widen the parts again -- 9 instructions for 6 parts
     __device__ static __forceinline__ void split2(f32x2v v, uint32_t (&p)[3]) {
-        uint32_t a[3], b[3];
-        split(v.x, a);
-        split(v.y, b);
-#pragma unroll
-        for (int i = 0; i < 3; i++) p[i] = a[i] | (b[i] << 16);
+#pragma clang fp contract(off)
+        typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+        const bf16x2v h = __builtin_convertvector(v, bf16x2v);
+        const f32x2v r1 = v - __builtin_convertvector(h, f32x2v);
+        const bf16x2v m = __builtin_convertvector(r1, bf16x2v);
+        const f32x2v r2 = r1 - __builtin_convertvector(m, f32x2v);
+        const bf16x2v l = __builtin_convertvector(r2, bf16x2v);
+        p[0] = __builtin_bit_cast(uint32_t, h);
+        p[1] = __builtin_bit_cast(uint32_t, m);
+        p[2] = __builtin_bit_cast(uint32_t, l);
     }
 };
 

@@ -286,6 +286,39 @@ def test_em_statistics_engines_vs_oracle(built_lib, oracle_built):
         _lib.set_option("em_stats_engine", 0)
 
 
+def test_em_responsibilities_on_the_matrix_cores_vs_oracle(built_lib, oracle_built):
+    """Round 4: em_stats_split_kernel -- log2 densities of the E-step from the scoring engine's split-bf16 contraction
+    (32-mixture tiles, 128 mixtures per workgroup), responsibilities through LDS into the fp64 statistics -- taken when the
+    model is inside that layout's range.  One EM iteration against the float64 oracle and against round 3's kernel
+    (responsibilities on the vector ALU) from the same start: models of 1, 2, 4 and 5 tiles (a last workgroup with one live
+    tile; padding mixtures inside a tile), dims with and without padding, a frame count that is no multiple of the tile."""
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    rng = np.random.default_rng(18)
+    try:
+        for n, K, D in ((9001, 160, 39), (5000, 56, 13), (7013, 128, 20), (3000, 32, 26)):
+            cent = 3.0 + rng.normal(0, 2, (K, D))
+            X = (cent[rng.integers(0, K, n)] + rng.normal(0, 0.7, (n, D))).astype(np.float32)
+            r6 = np.vectorize(lambda v: float("%g" % v))
+            start = go.GMMParams(np.full(K, 1.0 / K), r6(cent + 0.2 * rng.standard_normal(cent.shape)), np.full((K, D), 0.9))
+            want = go.em_iteration(start, X.astype(np.float64))
+            got = {}
+            for eng, ran in ((2, 2), (0, 3)):
+                _lib.set_option("em_stats_engine", eng)
+                g = GMM.from_arrays(start.weights, start.mean, start.sigma)
+                g.nr_iteration, g.init_with_kmeans = 1, -1            # -1: warm start (extension)
+                assert g.fit(X) == 1
+                assert _lib.last_em_stats_engine() == ran, (n, K, D, eng, _lib.last_em_stats_engine())
+                w, mu, sg = got[eng] = g.params()
+                err = (np.max(np.abs(w - want.weights)), np.max(np.abs(mu - want.mean)), np.max(np.abs(sg - want.sigma) / want.sigma))
+                assert err[0] < 1e-5 and err[1] < 1e-4 and err[2] < 1e-3, (n, K, D, eng, err)
+            # the two kernels differ in the rounding of the log densities only
+            assert np.max(np.abs(got[0][1] - got[2][1])) < 2e-5 and np.max(np.abs(got[0][2] - got[2][2]) / got[2][2]) < 2e-5, (n, K, D)
+    finally:
+        _lib.set_option("em_stats_engine", 0)
+
+
 def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, oracle_built):
     """Frames whose log-likelihood sits in the band where the reference's partial-product flushes decide on
     every path that scores from PCM: the fused serving step, its chunk-pipelined form (the band of ANY chunk sends the batch
