@@ -484,21 +484,25 @@ def block_multi_slot(_lib, ex, base):
     for pinned in (False, True):
         if pinned:
             _lib.host_register(cat)            # what a serving loop does once with its PCM ring: the copy engines read it in place
-        for slots in (1, 2):
+        for slots, merge in ((1, 1), (2, 1), (2, 0)):
+            # merge = 1 (the default): slots that share a device are one queue on it; 0: a thread and a share per slot
+            _lib.set_option("multi_merge_same_device", merge)
             mp_ = MultiPredictor(gm, FS, n_slots=slots, **MFCC_KW)
             f = lambda: mp_.predict_concat(cat, off, nd=ND)
             f(); f()
             el, (s2, a2) = timed(f, 0, 10)
-            out["slots_%d_%s" % (slots, "caller_memory_page_locked" if pinned else "pageable_caller_memory")] = {
+            out["slots_%d%s_%s" % (slots, "" if merge else "_a_thread_each", "caller_memory_page_locked" if pinned else "pageable_caller_memory")] = {
                 "ms_per_call": 1e3 * el / 10, "over_resident": (el / 10) / (el_res / 10), "argmax_equal": bool(np.array_equal(a2, arg)),
                 "sums_bit_identical": bool(np.array_equal(s2, sums)), "slot_seconds": [float(v) for v in mp_.slot_seconds]}
             del mp_
+        _lib.set_option("multi_merge_same_device", 1)
         if pinned:
             _lib.host_unregister(cat)
     out["pcie_floor_ms"] = cat.nbytes / 55e9 * 1e3
     out["note"] = ("every call moves the PCM host -> device; a slot uploads its utterances in up to 8 pieces on the copy stream and enqueues every "
                    "piece's kernels + result copies behind its upload event, one host wait at the end; pcie_floor_ms = the PCM at 55 GB/s; "
-                   "floor of the whole call ~ max(copy, kernels) + the first piece")
+                   "floor of the whole call ~ max(copy, kernels) + the first piece; slots that share a device (both of slots_2 on this one-GPU box) are "
+                   "one queue on it unless multi_merge_same_device = 0 (slots_2_a_thread_each_*)")
     return out
 
 

@@ -196,8 +196,9 @@ int sr_predict_pcm_batch(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, doubl
  * models -> sums + argmax, and the per-utterance rows are gathered on the host (the reference:
  * Threadpool inside the call, gmm.cc:533-560, and multiprocessing.Pool over utterances,
  * test-gmm.py:128-133).  n_slots = 0 means one slot per visible device; more slots than devices is
- * legal (the surplus share a device, serialised by its lock).  slot_seconds_out (optional,
- * [n_slots]) receives each slot's wall time for the pass. */
+ * legal: slots that share a device are one queue on it (the first of them takes their work and the others report 0
+ * seconds; sr_set_option("multi_merge_same_device", 0) gives every slot its own thread and share, serialised by the
+ * device's lock).  slot_seconds_out (optional, [n_slots]) receives each slot's wall time for the pass. */
 typedef struct SRMulti SRMulti;
 SRMulti *sr_multi_create(GMM *const *models, int n_models, double fs, double win_length_ms,
                          double win_shift_ms, int fft_size, int n_filters, int n_ceps,

@@ -29,6 +29,7 @@ void set_kmeans_assign_engine(int v);
 }
 std::atomic<int> &stream_debug_capture_delay_ms();      // stream.cpp
 std::atomic<int> &multi_pieces_option();                // multi.cpp
+std::atomic<int> &multi_merge_option();
 namespace sr {
 void kmeans_fast_stats(long *passes, long *rechecked);
 int reference_side_effects();
@@ -770,6 +771,8 @@ int sr_set_option(const char *key, long value) {
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
+    } else if (k == "multi_merge_same_device") {
+        multi_merge_option().store(value != 0);
     } else if (k == "multi_pieces") {
         if (value < 0 || value > 8) fail("multi_pieces must be 0 (automatic) .. 8");
         multi_pieces_option().store((int)value);

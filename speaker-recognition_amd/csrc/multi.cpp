@@ -31,6 +31,10 @@
 using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
+std::atomic<int> &multi_merge_option() {     // sr_set_option("multi_merge_same_device", 0 | 1)
+    static std::atomic<int> v{1};
+    return v;
+}
 std::atomic<int> &multi_pieces_option() {   // sr_set_option("multi_pieces", n): 0 = automatic (up to MULTI_CHUNKS), 1 .. MULTI_CHUNKS
     static std::atomic<int> v{0};
     return v;
@@ -78,9 +82,8 @@ namespace {
 // counts, in the caller's order -- a slot's PCM is then ONE run of the caller's buffer and travels as a few large copies (dealt
 // round-robin, 1000 equal utterances over 2 slots were 1000 copies of 320 KB: 15 ms of copy calls for 6 ms of PCIe time).
 // Few or very uneven utterances: longest-first greedy by sample count (what shard.partition_utterances does in Python).
-void partition(const int64_t *off, int n_utt, std::deque<SRMulti::Slot> &slots) {
-    for (auto &s : slots) s.utts.clear();
-    if (n_utt == 0) return;
+void partition(const int64_t *off, int n_utt, std::vector<SRMulti::Slot *> &slots) {
+    if (n_utt == 0 || slots.empty()) return;
     const int64_t total = off[n_utt];
     int64_t longest = 0;
     for (int u = 0; u < n_utt; u++) longest = std::max(longest, off[u + 1] - off[u]);
@@ -89,7 +92,7 @@ void partition(const int64_t *off, int n_utt, std::deque<SRMulti::Slot> &slots) 
         int u = 0;
         for (size_t k = 0; k < ns; k++) {
             const int64_t hi = total * (int64_t)(k + 1) / (int64_t)ns;
-            while (u < n_utt && (k + 1 == ns || off[u + 1] <= hi)) slots[k].utts.push_back(u++);
+            while (u < n_utt && (k + 1 == ns || off[u + 1] <= hi)) slots[k]->utts.push_back(u++);
         }
         return;
     }
@@ -99,10 +102,10 @@ void partition(const int64_t *off, int n_utt, std::deque<SRMulti::Slot> &slots) 
     std::vector<int64_t> load(ns, 0);
     for (int u : order) {
         const size_t k = std::min_element(load.begin(), load.end()) - load.begin();
-        slots[k].utts.push_back(u);
+        slots[k]->utts.push_back(u);
         load[k] += off[u + 1] - off[u];
     }
-    for (auto &s : slots) std::sort(s.utts.begin(), s.utts.end());
+    for (auto *s : slots) std::sort(s->utts.begin(), s->utts.end());
 }
 
 // true when [p, p + bytes) is page-locked host memory the copy engines can read directly (hipHostMalloc / hipHostRegister
@@ -394,14 +397,25 @@ int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_o
             if (sample_offsets[u + 1] < sample_offsets[u]) fail("sample_offsets must be non-decreasing");
         if (sample_offsets[n_utt] > 0 && !pcm) fail("null PCM pointer");
         if (gpu_runtime_lost()) fail_gpu_runtime_lost("sr_multi_predict_pcm");
-        partition(sample_offsets, n_utt, m->slots);
+        // Slots that share a device are ONE queue on it (round 4): the device's lock would serialise their pieces anyway, in
+        // an order nobody chose, with both slots' tails at the end.  The first slot of a device takes the work of all of them
+        // (sr_set_option("multi_merge_same_device", 0): every slot its own share and thread -- what the tests of the threaded
+        // path on a one-GPU box use).
+        std::vector<SRMulti::Slot *> active;
+        for (auto &s : m->slots) {
+            s.utts.clear();
+            s.seconds = 0.0;
+            bool first = true;
+            if (multi_merge_option().load())
+                for (auto *a : active) first = first && a->device != s.device;
+            if (first) active.push_back(&s);
+        }
+        partition(sample_offsets, n_utt, active);
         const bool pinned = sample_offsets[n_utt] > 0 && host_pinned(pcm) &&
                             host_pinned(pcm + sample_offsets[n_utt] - 1);
         std::vector<std::thread> th;
-        for (auto &s : m->slots) {
-            s.error.clear();
-            th.emplace_back(run_slot, m, std::ref(s), pcm, sample_offsets, nd, flags, pinned);
-        }
+        for (auto &s : m->slots) s.error.clear();
+        for (auto *s : active) th.emplace_back(run_slot, m, std::ref(*s), pcm, sample_offsets, nd, flags, pinned);
         for (auto &t : th) t.join();
         for (auto &s : m->slots)
             if (!s.error.empty()) fail("device %d: %s", s.device, s.error.c_str());

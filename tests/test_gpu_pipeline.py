@@ -460,13 +460,23 @@ def test_multi_slot_prediction_equals_single_device(built_lib):
     sigs = [synth.synth_speech(int(rng.integers(0, 30)), s, 16000, seed=100 + i) for i, s in enumerate(secs)]
     ex = MfccExtractor(16000, **kw)
     want_sums, want_arg = ex.predict_batch(ModelSet(models), Batch.from_pcm(sigs), nd=2)
-    for n_slots in (1, 2, 3):
-        mp = MultiPredictor(models, 16000, n_slots=n_slots, **kw)
-        assert mp.n_slots == n_slots and all(0 <= d < _lib.device_count() for d in mp.slot_devices())
-        sums, arg = mp.predict(sigs, nd=2)
-        assert np.array_equal(arg, want_arg), n_slots
-        assert np.array_equal(sums, want_sums), n_slots
-        assert mp.slot_seconds.shape == (n_slots,) and np.all(mp.slot_seconds > 0)
+    try:
+        for merge in (0, 1):
+            # 0: every slot its own thread and share, also when slots share a device (the threaded path on a one-GPU box);
+            # 1 (the default, round 4): the slots of one device are one queue -- its first slot takes their work
+            _lib.set_option("multi_merge_same_device", merge)
+            for n_slots in (1, 2, 3):
+                mp = MultiPredictor(models, 16000, n_slots=n_slots, **kw)
+                assert mp.n_slots == n_slots and all(0 <= d < _lib.device_count() for d in mp.slot_devices())
+                sums, arg = mp.predict(sigs, nd=2)
+                assert np.array_equal(arg, want_arg), (merge, n_slots)
+                assert np.array_equal(sums, want_sums), (merge, n_slots)
+                devs = mp.slot_devices()
+                working = [k for k in range(n_slots) if not merge or devs[k] not in devs[:k]]
+                assert mp.slot_seconds.shape == (n_slots,) and np.all(mp.slot_seconds[working] > 0), (merge, n_slots)
+                assert np.all(np.delete(mp.slot_seconds, working) == 0)
+    finally:
+        _lib.set_option("multi_merge_same_device", 1)
     # handles are bound to their device: a thread parked on another device index is refused
     if _lib.device_count() == 1:
         _lib.set_thread_device(1)
