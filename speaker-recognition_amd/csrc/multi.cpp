@@ -31,11 +31,12 @@
 using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
+constexpr int MULTI_DEFAULT_PIECES = 6; // ... and in this many unless sr_set_option("multi_pieces", n) says otherwise
 std::atomic<int> &multi_merge_option() {     // sr_set_option("multi_merge_same_device", 0 | 1)
     static std::atomic<int> v{1};
     return v;
 }
-std::atomic<int> &multi_pieces_option() {   // sr_set_option("multi_pieces", n): 0 = automatic (up to MULTI_CHUNKS), 1 .. MULTI_CHUNKS
+std::atomic<int> &multi_pieces_option() {   // sr_set_option("multi_pieces", n): 0 = MULTI_DEFAULT_PIECES, 1 .. MULTI_CHUNKS
     static std::atomic<int> v{0};
     return v;
 }
@@ -152,24 +153,19 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // piece boundaries: whole utterances, about equal sample counts; pieces of at least ~2 MB of PCM (smaller ones are
         // all launch overhead and kernel tails)
         const int64_t total = s.offsets[U];
-        const int want = multi_pieces_option().load() > 0 ? std::min(MULTI_CHUNKS, multi_pieces_option().load()) : MULTI_CHUNKS;
-        const int n_chunks_max = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, U), total / ((int64_t)1 << 20)));
-        // Copy and kernels take about the same time on this path (configs[1]: 5.8 and 5.4 ms), so the call ends at
-        // copy(everything) + kernels(LAST piece) or copy(FIRST piece) + kernels(everything), whichever is later: a small first and
-        // a small last piece, the bulk in between (equal pieces: 8.3 ms with 4, 8.9 with 8 -- more, equal pieces only add launches)
-        int n_chunks = n_chunks_max;
-        static const double cum6[7] = {0.0, 0.06, 0.22, 0.47, 0.75, 0.93, 1.0};
-        const bool shaped = multi_pieces_option().load() == 0 && n_chunks >= 6;
-        const int n_used = shaped ? 6 : n_chunks;
-        n_chunks = n_used;
+        const int want = multi_pieces_option().load() > 0 ? std::min(MULTI_CHUNKS, multi_pieces_option().load()) : MULTI_DEFAULT_PIECES;
+        // Copy and kernels take about the same time on this path (configs[1]: 5.6 and 5.3 ms), so the call ends at about
+        // copy(everything) + kernels(last piece): equal pieces, enough of them that the last one is short and few enough that
+        // the per-piece launches do not add up (scripts/debug/multi_pieces_sweep.py, page-locked PCM: 1 piece 11.3 ms, 2 8.7,
+        // 4 7.5, 6 7.2, 8 7.25; a small-first / small-last shape, round 4's first attempt, 7.7)
+        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, U), total / ((int64_t)1 << 20)));
         for (int c = 0; c < MULTI_CHUNKS; c++) {
             auto &ch = s.chunk[c];
             ch.u0 = ch.u1 = 0;
-            if (c >= n_used) continue;
-            const int64_t lo = shaped ? (int64_t)(total * cum6[c]) : total * c / n_used;
-            const int64_t hi = shaped ? (int64_t)(total * cum6[c + 1]) : total * (c + 1) / n_used;
+            if (c >= n_chunks) continue;
+            const int64_t lo = total * c / n_chunks, hi = total * (c + 1) / n_chunks;
             ch.u0 = c == 0 ? 0 : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), lo) - s.offsets.begin());
-            ch.u1 = c == n_used - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
+            ch.u1 = c == n_chunks - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
             ch.u0 = std::min(ch.u0, U);
             ch.u1 = std::max(ch.u0, std::min(ch.u1, U));
         }
