@@ -109,6 +109,27 @@ void partition(const int64_t *off, int n_utt, std::vector<SRMulti::Slot *> &slot
     for (auto *s : slots) std::sort(s->utts.begin(), s->utts.end());
 }
 
+// Pageable caller memory -> the page-locked staging buffer.  One thread's memcpy (~25 GB/s) is slower than the link it feeds
+// (55 GB/s): copies of more than a few MB are cut over MULTI_STAGING_THREADS short-lived threads (they inherit the slot
+// thread's placement next to its GPU).
+constexpr int MULTI_STAGING_THREADS = 4;
+void staging_copy(void *dst, const void *src, size_t bytes) {
+    constexpr size_t PART_MIN = (size_t)4 << 20;
+    const int parts = (int)std::min<size_t>(MULTI_STAGING_THREADS, bytes / PART_MIN);
+    if (parts <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int p = 1; p < parts; p++) {
+        const size_t lo = std::min(bytes, per * p), hi = p + 1 == parts ? bytes : std::min(bytes, per * (p + 1));
+        th.emplace_back([=] { std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(bytes, per));
+    for (auto &t : th) t.join();
+}
+
 // true when [p, p + bytes) is page-locked host memory the copy engines can read directly (hipHostMalloc / hipHostRegister
 // / sr_host_register): then the slots DMA straight out of the caller's buffer
 bool host_pinned(const void *p) {
@@ -210,7 +231,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                 if (n > 0) {
                     const int16_t *src = pcm + src0;
                     if (!pinned) {
-                        std::memcpy(ch.staging.p + dst0, src, sizeof(int16_t) * (size_t)n);
+                        staging_copy(ch.staging.p + dst0, src, sizeof(int16_t) * (size_t)n);
                         src = ch.staging.p + dst0;
                     }
                     SR_HIP(hipMemcpyAsync(b.pcm16.p + dst0, src, sizeof(int16_t) * (size_t)n, hipMemcpyHostToDevice, ctx().copy));
