@@ -131,6 +131,33 @@ def test_argmax_first_maximum_wins(built_lib):
     assert sums[0, 1] == sums[0, 2] == sums[0, 4] and sums[1, 0] == sums[1, 3]
 
 
+def test_utterance_sums_long_utterances_many_models(built_lib):
+    """gmm_finalize_kernel's order (round 4: an utterance's tiles in segments, a thread per (segment, model), the segment sums
+    in order; several passes over the models when segments x models exceed its LDS): one utterance of 50 001 frames (1563
+    32-frame tiles = 49 segments) beside short ones and an empty one, against 150 models (3 passes) and against 1 model --
+    each sum equals the float64 sum of the same call's per-frame values, the argmax is the first maximum, and the sums do
+    not depend on the batch around the utterance."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    base = [synth.synth_gmm(32, 13, 300 + s) for s in range(5)]
+    models = [base[s % 5] for s in range(150)]            # duplicates: ties for the argmax, first maximum wins
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    long_ = synth.draw_frames(base[3], 50001, 1)
+    utts = [synth.draw_frames(base[1], 70, 2), long_, np.zeros((0, 13), np.float32), synth.draw_frames(base[4], 3000, 3)]
+    sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+    off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
+    for u in range(len(utts)):
+        want = fll[:, off[u]:off[u + 1]].astype(np.float64).sum(axis=1)
+        assert np.allclose(sums[u], want, rtol=1e-12, atol=1e-9), u
+    assert arg.tolist() == [1, 3, -1, 4]
+    alone, arg1 = ms.score(Batch.from_features([long_]))
+    assert np.array_equal(alone[0], sums[1]) and arg1[0] == 3
+    one = ModelSet([GMM.from_arrays(*base[3])])
+    s1, a1, f1 = one.score(Batch.from_features([long_]), frame_ll=True)
+    assert np.allclose(s1[0, 0], f1[0].astype(np.float64).sum(), rtol=1e-12) and a1[0] == 0
+
+
 def test_deterministic_and_partition_invariant(built_lib):
     """Two runs are bit-identical; splitting an utterance changes nothing but the grouping of
     the (double) partial sums; per-frame values do not depend on the batch they sit in."""
