@@ -62,18 +62,23 @@ using namespace sr;
         return;                                                \
     }
 
-static SRModelSet &single_set(GMM *g) {
+namespace sr {
+// The handle's one-model set on the current device: packed (every layout a small set carries) and uploaded once, until training
+// changes the parameters.  The caller holds this device's lock.
+std::shared_ptr<SRModelSet> single_model_set(const GMM *g) {
     if (!g) fail("null GMM handle");
     if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
-    auto &slot = g->single[current_device()];          // one per device: the caller holds this device's lock
+    auto &slot = g->single[current_device()];          // one per device
     if (!slot || slot->device != ctx().device) {
         auto s = std::make_shared<SRModelSet>();
         pack_model_set(*s, {g});
         upload_model_set(*s);
         slot = s;
     }
-    return *slot;
+    return slot;
 }
+}  // namespace sr
+static SRModelSet &single_set(GMM *g) { return *sr::single_model_set(g); }
 
 static std::unique_ptr<SRBatch> feature_batch(const float *X, int64_t n, int dim,
                                               const int64_t *offsets, int n_utt) {

@@ -21,8 +21,9 @@ struct GMM {
     std::vector<double> mean;     // [K*D]
     std::vector<double> sigma;    // [K*D]
     // lazily packed one-model sets, one per device (threads on different GPUs may score the same handle concurrently:
-    // each holds its device's lock only); invalidated by training
-    std::shared_ptr<SRModelSet> single[sr::MAX_DEVICES];
+    // each holds its device's lock only); invalidated by training.  (mutable: a cache -- a UBM handed to the MAP trainer as
+    // `const` lends its packed set to every speaker's first E-step, em.hip)
+    mutable std::shared_ptr<SRModelSet> single[sr::MAX_DEVICES];
     void drop_single() {
         for (auto &s : single) s.reset();
     }

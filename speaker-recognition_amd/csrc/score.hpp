@@ -165,6 +165,8 @@ namespace sr {
 void predict_pcm(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd, double *sums_out, int *argmax_out, int flags);
 // Packs + uploads a model set on the current device.
 void upload_model_set(SRModelSet &s);
+// a GMM handle's own one-model set on the current device, packed and uploaded once (abi.cpp; invalidated by GMM::drop_single)
+std::shared_ptr<SRModelSet> single_model_set(const GMM *g);
 // the split-bf16 layout of a set that carries one (s.bx3), on the device: lazily, as every matrix-core layout (em.hip reads it too)
 void ensure_bx3_layout(SRModelSet &s);
 bool split_bf16_in_range(const SRModelSet &s);       // what score_device asks before it takes that engine
