@@ -315,6 +315,22 @@ def test_em_responsibilities_on_the_matrix_cores_vs_oracle(built_lib, oracle_bui
                 assert err[0] < 1e-5 and err[1] < 1e-4 and err[2] < 1e-3, (n, K, D, eng, err)
             # the two kernels differ in the rounding of the log densities only
             assert np.max(np.abs(got[0][1] - got[2][1])) < 2e-5 and np.max(np.abs(got[0][2] - got[2][2]) / got[2][2]) < 2e-5, (n, K, D)
+        # frames whose likelihood underflows carry no responsibility (gmm.cc:482-498), and fewer frames than one 128-frame tile:
+        # a means-only MAP enrolment (gmmubm.cc:29-81) of 70 frames, five of them 1000 units away, from a 64-mixture UBM
+        K, D = 64, 39
+        cent = rng.normal(0, 2, (K, D))
+        start = go.GMMParams(np.full(K, 1.0 / K), np.vectorize(lambda v: float("%g" % v))(cent), np.full((K, D), 0.9))
+        X = (cent[rng.integers(0, K, 70)] + rng.normal(0, 0.7, (70, D))).astype(np.float32)
+        X[::14] += 1000.0
+        want = go.em_iteration(start, X.astype(np.float64), map_relevance=16.0, ubm=start)
+        ubm = GMM.from_arrays(start.weights, start.mean, start.sigma)
+        for eng, ran in ((2, 2), (0, 3)):
+            _lib.set_option("em_stats_engine", eng)
+            spk = GMM(K, nr_iteration=1)
+            assert spk.fit(X, ubm=ubm) == 1 and _lib.last_em_stats_engine() == ran
+            w, mu, sg = spk.params()
+            assert np.array_equal(w, start.weights) and np.array_equal(sg, start.sigma)
+            assert np.max(np.abs(mu - want.mean)) < 1e-4, (eng, np.max(np.abs(mu - want.mean)))
     finally:
         _lib.set_option("em_stats_engine", 0)
 
