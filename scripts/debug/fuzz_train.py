@@ -21,6 +21,8 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 fails = 0
 for c in range(cases):
     K, D = int(rng.integers(1, 40)), int(rng.choice([1, 5, 13, 26, 39, 48, 64, 70, 84, 128]))
+    if c % 3 == 2:          # (round 4) whole 32-mixture tiles: the models the E-step's matrix-core responsibilities take (em_stats_split_kernel)
+        K, D = int(rng.choice([32, 61, 64, 96, 125, 160, 256])), int(rng.choice([5, 13, 20, 26, 33, 39]))
     n = int(rng.choice([50, 300, 2000, 9000]))
     shift, scale = float(rng.choice([0.0, 0.0, -20.0])), float(rng.choice([1.0, 1.0, 0.1]))
     w, mu, sg = synth.synth_gmm(K, D, int(rng.integers(1 << 30)))
@@ -46,6 +48,6 @@ for c in range(cases):
     e_leg = float(np.max(np.abs(ll - fused)))
     ok = e_w < 2e-5 and e_mu < 3e-4 and e_sg < 2e-3 and e_map < 3e-4 and e_leg == 0.0
     fails += not ok
-    print("case %2d K %2d D %3d n %4d shift %5g scale %4g: weights %.1e means %.1e sigmas %.1e MAP means %.1e legacy-vs-fused %.1e %s" % (
-        c, K, D, n, shift, scale, e_w, e_mu, e_sg, e_map, e_leg, "ok" if ok else "!!"))
+    print("case %2d K %2d D %3d n %4d shift %5g scale %4g: weights %.1e means %.1e sigmas %.1e MAP means %.1e legacy-vs-fused %.1e engine %d %s" % (
+        c, K, D, n, shift, scale, e_w, e_mu, e_sg, e_map, e_leg, _lib.last_em_stats_engine(), "ok" if ok else "!!"))
 print("cases with findings:", fails)
