@@ -963,7 +963,13 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
             // one contiguous frame range per wave; enough waves to fill the chip a few times over
             const int blocks_per_cu = std::max<int>(1, std::min<int>(3, (int)(160 * 1024 / lds)));
             const int64_t max_waves = (int64_t)ctx().n_cu * blocks_per_cu * wpb * 4;
-            const int64_t frames_per_wave = std::max<int64_t>(8, (NF + max_waves - 1) / max_waves);
+            // A wave walks its frames one after the other.  Large batches: enough waves to fill the chip four times over, at least 8
+            // frames each (the per-workgroup table setup amortised).  Small ones -- one serving utterance, a streaming window --
+            // spread over ONE round of waves instead, down to a frame per wave (through round 3 the minimum of 8 made 300 frames
+            // 38 waves on 4 CUs: 57 us of a 270 us decision; now 17 us).
+            const int64_t one_round = (int64_t)ctx().n_cu * blocks_per_cu * wpb;
+            int64_t frames_per_wave = std::max<int64_t>(1, (NF + one_round - 1) / one_round);
+            if (frames_per_wave > 8) frames_per_wave = std::max<int64_t>(8, (NF + max_waves - 1) / max_waves);
             const int64_t n_waves = (NF + frames_per_wave - 1) / frames_per_wave;
             const int grid = (int)((n_waves + wpb - 1) / wpb);
             int preset = 0;
