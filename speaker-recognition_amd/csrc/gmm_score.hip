@@ -367,16 +367,23 @@ ScoreOptions &score_options() {
 
 struct ScoreWorkspace {
     DevBuf<double> partial;
-    DevBuf<double> sums;
-    DevBuf<int> argmax;
+    // Results of a pass: [U x S] sums with the U argmax values right behind them, and the pass's three counters side by side --
+    // one host-bound copy and one clear each instead of two and three (a copy or a fill is ~4.5 us on the stream: 18 us of a
+    // 240 us single-utterance decision, round 4).
+    DevBuf<double> results;
+    DevBuf<int> counters;                // [0] saturation flag of the fp16 engines, [1] pairs in the partial-product band, [2] exception list length
+    double *sums_p(size_t n_sums) { (void)n_sums; return results.p; }
+    int *argmax_p(size_t n_sums) { return reinterpret_cast<int *>(results.p + n_sums); }
+    void ensure_results(size_t n_utt, size_t n_models) { results.ensure(n_utt * n_models + (n_utt + 1) / 2 + 1); }
+    int *oor_p() { return counters.p; }
+    int *flush_count_p() { return counters.p + 1; }
+    int *exc_count_p() { return counters.p + 2; }
     DevBuf<float> frame_ll;
-    DevBuf<int> oor;                     // saturation flag of the fp16 engines
     DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
     DevBuf<double> ref_partial;
-    DevBuf<int> exc_list, exc_count;     // ... and its (tile, block) exception list
+    DevBuf<int> exc_list;                // ... and its (tile, block) exception list
     DevBuf<float> hy_a, hy_b;            // hybrid sets: per-frame LL of the two sub-sets
     DevBuf<int2> flush_list;             // (tile, model) pairs in the partial-product band (lse.hpp, gmm_flush.hip)
-    DevBuf<int> flush_count;
     size_t flush_min_cap = 0;            // set after an overflow: the next pass gets a list of that length
 };
 static ScoreWorkspace &ws() { return per_device<ScoreWorkspace>(); }   // one per device, leaked on purpose
@@ -398,10 +405,8 @@ static FlushPass prepare_flush(const SRModelSet &set, int n_tiles, int flags) {
     if (score_options().flush_list_cap > 0) cap = (size_t)score_options().flush_list_cap;     // (testing the overflow path)
     cap = std::min<size_t>(std::max(cap, w.flush_min_cap), 0x7fffffff);
     w.flush_list.ensure(cap);
-    w.flush_count.ensure(1);
-    SR_HIP(hipMemsetAsync(w.flush_count.p, 0, sizeof(int), ctx().stream));
     fp.list = w.flush_list.p;
-    fp.count = w.flush_count.p;
+    fp.count = w.flush_count_p();          // (cleared with the pass's other counters by score_device)
     fp.cap = (int)std::min<size_t>(score_options().flush_list_cap > 0 ? cap : w.flush_list.n, 0x7fffffff);
     fp.band_hi = (float)(-708.396418532264 + set.host.flush_band);
     return fp;
@@ -796,12 +801,14 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 
     auto &w = ws();
     bool used_oor = false;
+    w.counters.ensure(4);
+    SR_HIP(hipMemsetAsync(w.counters.p, 0, 4 * sizeof(int), ctx().stream));     // the pass's counters, all at once
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
     // 0 off, 1 the reference's clamp, 2 the same with "all terms underflowed" reported as -inf (a half of a hybrid set)
     const int clamp_mode = (flags & 1) ? ((flags & SCORE_NO_FLUSH) ? 2 : 1) : 0;
     if (frame_ll_dst) want_frame_ll = true;
-    w.sums.ensure((size_t)std::max(1, U) * S);
-    w.argmax.ensure((size_t)std::max(1, U));
+    w.ensure_results((size_t)std::max(1, U), (size_t)S);
+    const size_t n_sums = (size_t)std::max(1, U) * S;
     if (tt.n_tiles > 0) {
         // model groups: enough workgroups to fill the chip several times over
         int G = opt.model_groups;
@@ -880,8 +887,6 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         if (use_h2s) {
             ensure_h2s_layout(set);
             const PackedH2Shared &h = set.h2s;
-            w.oor.ensure(1);
-            SR_HIP(hipMemsetAsync(w.oor.p, 0, sizeof(int), ctx().stream));
             used_oor = true;
             // pre-pass: the reference model's per-frame LL (natural log, no clamp) = the offset
             w.ref_ll.ensure((size_t)std::max<int64_t>(1, feat.n_rows));
@@ -898,7 +903,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 r.scale = set.d_h2s_ref_scale.p;
                 r.partial = w.ref_partial.p;
                 r.frame_ll = w.ref_ll.p;
-                r.oor_flag = w.oor.p;
+                r.oor_flag = w.oor_p();
                 r.n_frames = feat.n_rows;
                 r.dim = feat.dim;
                 r.n_models = 1;
@@ -912,8 +917,6 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             const int n_blocks = (int)h.blocks.size();
             const size_t cap = (size_t)tt.n_tiles * n_blocks;
             w.exc_list.ensure(2 * cap);
-            w.exc_count.ensure(1);
-            SR_HIP(hipMemsetAsync(w.exc_count.p, 0, sizeof(int), ctx().stream));
             H2sLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
@@ -927,9 +930,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.ref_ll = w.ref_ll.p;
             a.partial = w.partial.p;
             a.frame_ll = fll;
-            a.oor_flag = w.oor.p;
+            a.oor_flag = w.oor_p();
             a.exc_list = w.exc_list.p;
-            a.exc_count = w.exc_count.p;
+            a.exc_count = w.exc_count_p();
             a.exc_cap = (int)std::min<size_t>(cap, 0x7fffffff);
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
@@ -987,10 +990,8 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.group_chunk_begin = d_gcb;
             a.center = use_h2 ? set.d_h2_center.p : use_bx3 ? set.d_bx3_center.p : set.d_center.p;
             if (use_h2) {
-                w.oor.ensure(1);
-                SR_HIP(hipMemsetAsync(w.oor.p, 0, sizeof(int), ctx().stream));
                 a.scale = set.d_h2_scale.p;
-                a.oor_flag = w.oor.p;
+                a.oor_flag = w.oor_p();
                 used_oor = true;
             }
             a.partial = w.partial.p;
@@ -1047,15 +1048,15 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
-                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums.p, w.argmax.p,
+                           w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums_p(n_sums), w.argmax_p(n_sums),
                            fp.list, fp.count, fp.cap);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;
-    r.d_sums = w.sums.p;
-    r.d_argmax = w.argmax.p;
+    r.d_sums = w.sums_p(n_sums);
+    r.d_argmax = w.argmax_p(n_sums);
     r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? (frame_ll_dst ? frame_ll_dst : w.frame_ll.p) : nullptr;
-    r.d_oor = used_oor ? w.oor.p : nullptr;
+    r.d_oor = used_oor ? w.oor_p() : nullptr;
     r.d_flush_count = fp.count;
     r.d_flush_list = fp.list;
     r.flush_cap = fp.cap;
@@ -1080,8 +1081,8 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
     snprintf(good_name, sizeof(good_name), "%s", g_last_kernel);
     TileTable &tt = feat.tiles_for(256);
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
-    w.sums.ensure((size_t)std::max(1, U) * S);
-    w.argmax.ensure((size_t)std::max(1, U));
+    w.ensure_results((size_t)std::max(1, U), (size_t)S);
+    const size_t n_sums = (size_t)std::max(1, U) * S;
     float *out = nullptr;
     if (want_frame_ll || frame_ll_dst) {
         if (!frame_ll_dst) w.frame_ll.ensure(n);
@@ -1097,13 +1098,13 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream, w.partial.p,
-                           tt.d_utt_tile_begin.p, S, 1, w.sums.p, w.argmax.p, fp.list, fp.count, fp.cap);
+                           tt.d_utt_tile_begin.p, S, 1, w.sums_p(n_sums), w.argmax_p(n_sums), fp.list, fp.count, fp.cap);
         SR_HIP(hipGetLastError());
     }
     snprintf(g_last_kernel, sizeof(LastKernel::name), "hybrid: %d ill-conditioned mixtures on the vector ALU + %.150s", set.hy_bad_mixtures, good_name);
     ScoreResult r;
-    r.d_sums = w.sums.p;
-    r.d_argmax = w.argmax.p;
+    r.d_sums = w.sums_p(n_sums);
+    r.d_argmax = w.argmax_p(n_sums);
     r.d_frame_ll = (out && tt.n_tiles > 0) ? out : nullptr;
     r.d_oor = good.d_oor;
     r.d_flush_count = fp.count;
@@ -1133,17 +1134,32 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
     st.oor.ensure(2);
     const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
     const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
+    const int *h_argmax = nullptr;            // where the staged argmax values are (behind the sums when they came in one copy)
     for (;;) {
         st.oor.p[0] = st.oor.p[1] = 0;
-        if (r.d_oor) SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-        if (r.d_flush_count) SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-        if (sums_out && U) {
-            st.sums.ensure(U * S);
-            SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+        // (the workspace keeps the two counters, and the argmax values behind the sums, side by side: one copy each)
+        if (r.d_oor && r.d_flush_count == r.d_oor + 1) {
+            SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        } else {
+            if (r.d_oor) SR_HIP(hipMemcpyAsync(st.oor.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            if (r.d_flush_count) SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
         }
-        if (argmax_out && U) {
-            st.argmax.ensure(U);
-            SR_HIP(hipMemcpyAsync(st.argmax.p, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+        const bool together = sums_out && argmax_out && U && (const void *)r.d_argmax == (const void *)(r.d_sums + U * S);
+        h_argmax = nullptr;
+        if (together) {
+            st.sums.ensure(U * S + (U + 1) / 2);
+            SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double) + U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            h_argmax = reinterpret_cast<const int *>(st.sums.p + U * S);
+        } else {
+            if (sums_out && U) {
+                st.sums.ensure(U * S);
+                SR_HIP(hipMemcpyAsync(st.sums.p, r.d_sums, U * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+            }
+            if (argmax_out && U) {
+                st.argmax.ensure(U);
+                SR_HIP(hipMemcpyAsync(st.argmax.p, r.d_argmax, U * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+                h_argmax = st.argmax.p;
+            }
         }
         if (fll_n) {
             if (stage_fll) {
@@ -1175,7 +1191,7 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
         r.d_flush_count = nullptr;          // resolved: copy the patched results out
     }
     if (sums_out && U) std::memcpy(sums_out, st.sums.p, U * S * sizeof(double));
-    if (argmax_out && U) std::memcpy(argmax_out, st.argmax.p, U * sizeof(int));
+    if (argmax_out && U) std::memcpy(argmax_out, h_argmax, U * sizeof(int));
     if (stage_fll) std::memcpy(frame_ll_out, st.frame_ll.p, fll_n * sizeof(float));
     return true;
 }
