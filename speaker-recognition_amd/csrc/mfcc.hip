@@ -673,7 +673,9 @@ void mfcc_frames_fft2048_kernel(const PcmT *__restrict__ pcm, const int64_t *__r
 
 // Per-utterance CMVN (mean, population std, no epsilon -- MFCC.py:74-77) and causal
 // first-difference deltas AFTER the normalisation (utils.py:24-31).  Statistics in float64.
-__global__ __launch_bounds__(256)
+constexpr int CMVN_THREADS = 1024;    // frames of an utterance go round-robin to CMVN_THREADS / 16 stripes (13 coefficients): one short utterance
+                                      // -- a serving decision -- is 5 frames per thread instead of 19 with 256 (16 -> 6 us)
+__global__ __launch_bounds__(CMVN_THREADS)
 void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict__ raw_off,
                        const int64_t *__restrict__ out_off, int n_ceps, int nd, int cmvn,
                        float *__restrict__ out, int out_stride) {
@@ -682,12 +684,12 @@ void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict_
     const int64_t T = raw_off[u + 1] - r0;
     const int64_t o0 = out_off[u];
     const int64_t To = out_off[u + 1] - o0;
-    __shared__ double red[256];
+    __shared__ double red[CMVN_THREADS];
     __shared__ double s_mean[64], s_inv[64];
     const int tid = threadIdx.x;
     // thread = (stripe of frames, coefficient): consecutive threads read consecutive floats
     const int cp = n_ceps <= 16 ? 16 : n_ceps <= 32 ? 32 : 64;
-    const int n_stripes = 256 / cp;
+    const int n_stripes = CMVN_THREADS / cp;
     const int c = tid & (cp - 1);
     const int stripe = tid / cp;
     const bool live = c < n_ceps;
@@ -1036,7 +1038,7 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
     }
     if (U > 0 && out.n_rows > 0) {
         ScopedKernelTimer t(T_CMVN);
-        hipLaunchKernelGGL(cmvn_delta_kernel, dim3(U), dim3(256), 0, ctx().stream, w.raw.p,
+        hipLaunchKernelGGL(cmvn_delta_kernel, dim3(U), dim3(CMVN_THREADS), 0, ctx().stream, w.raw.p,
                            w.raw_off.p, out.d_offsets.p, m.n_ceps, nd, cmvn, out.data.p, out.dim);
         SR_HIP(hipGetLastError());
     }
