@@ -14,7 +14,7 @@ _lib.profile_enable(True)
 for U in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     feats = Batch.from_features([synth.draw_frames(ubm, 300, 10 + u) for u in range(U)])
     out = []
-    for shape in (1, 2, 3):
+    for shape in (1, 2, 3, 4):
         _lib.set_option("score_h2s_shape", shape)
         ts = []
         for r in range(7):

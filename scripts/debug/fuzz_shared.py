@@ -42,7 +42,7 @@ for c in range(cases):
     want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     bad = False
-    for shape, force in ((1, 0), (2, 0), (3, 0), (0, 1), (2, 1), (3, 1)):
+    for shape, force in ((1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (2, 1), (3, 1), (4, 1)):
         _lib.set_option("score_h2s_shape", shape)
         _lib.set_option("score_h2s_force_exc", force)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)

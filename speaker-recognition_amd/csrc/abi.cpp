@@ -745,7 +745,9 @@ int sr_set_option(const char *key, long value) {
         if (value != 0 && value != 1) fail("score_h2s_exact_offset must be 0 or 1");
         score_options().h2s_exact_offset = (int)value;
     } else if (k == "score_h2s_shape") {
-        if (value < 0 || value > 3) fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups) or 3 (12 waves, image loop pipelined inside the wave)");
+        if (value < 0 || value > 4)
+            fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups), 3 (12 waves, image loop pipelined inside the wave) "
+                 "or 4 (4 waves on one tile, the block's models split between them)");
         score_options().h2s_shape = (int)value;
     } else if (k == "flush_list_cap") {
         if (value < 0) fail("flush_list_cap must be >= 0");

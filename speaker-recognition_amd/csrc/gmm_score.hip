@@ -771,7 +771,13 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // 3.09 -- and loses below (4 utterances 0.173 against 0.159: a few workgroups, latency-bound); round 3's rule ("fills
         // the chip six times over") kept the 4-wave shape up to 30-50 k frames.
         const bool wide = n32 >= 64 + feat.n_utt;
-        h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (wide ? H2S_PIPELINED_SHAPE : 0);
+        // ... and the smallest ones -- one serving utterance: ten tiles -- take the model-split shape: a workgroup per (tile, block)
+        // with the block's models dealt to its four waves (gmm_score_h2_shared.hip).  Every such workgroup streams its block's
+        // images for ONE tile, so beyond one workgroup per CU the stream (L2 / fabric, 6 TB/s measured) bounds it: 300 frames
+        // 0.094 against 0.115 ms, 600 frames 0.123 against 0.114, 1200 frames 0.197 against 0.115 (scripts/ab_h2s_small.py)
+        const int64_t ms_wgs = n32 * (int64_t)set.h2s.blocks.size();
+        const bool tiny = ms_wgs <= (int64_t)ctx().n_cu;
+        h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (tiny ? H2S_MSPLIT_SHAPE : wide ? H2S_PIPELINED_SHAPE : 0);
         if (h2s_shape == H2S_PIPELINED_SHAPE && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = H2S_WIDE_SHAPE;
     }
     // the generic split-fp16 engine as ONE wide workgroup per CU (gmm_score_splitp.hip) once the batch fills the chip: the 4-wave
@@ -949,7 +955,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "%s<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
                      "3 products as one contraction; reference-offset log-sum-exp)", h2s_shape == 2 ? "gmm_score_h2p_kernel" : "gmm_score_h2s_kernel",
-                     h.kqf, h.klf, h2s_shape == 2 ? "waves=12, pipelined in the wave" : h2s_shape == 1 ? "waves=12" : "waves=4", SHARED_SB);
+                     h.kqf, h.klf, h2s_shape == 2 ? "waves=12, pipelined in the wave" : h2s_shape == 1 ? "waves=12" : h2s_shape == 3 ? "waves=4 on one tile, models split" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
             const int n_launches = launch_score_h2_shared(a, h.kqf, h.klf);
             const size_t len = strlen(g_last_kernel);

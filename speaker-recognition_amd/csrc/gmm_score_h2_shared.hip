@@ -127,21 +127,34 @@ struct H2sArgs {
 // exponent range and well above the reference's underflow boundary; a tile with a frame outside goes to the exception list
 // (decided per tile of ONE utterance, so an utterance's results do not depend on the batch around it), the others leave one
 // partial per model: a fixed-order float64 sum over the wave's lanes.
+// MS (round 4, the model-split shape of small batches): the workgroup's four waves hold the SAME tile and every fourth model of
+// the block each; the tile's fate is decided by all of them together (through `s_bad` in LDS), wave 0 reports it.
+template <bool MS = false>
 __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBlock &sb, int blk, const float (&ssum)[SHARED_SB], float off,
-                                                bool valid, bool has, int tile_id, int64_t row, int lane, int hh, float safe_ll2) {
+                                                bool valid, bool has, int tile_id, int64_t row, int lane, int hh, float safe_ll2,
+                                                int wave = 0, int *s_bad = nullptr) {
     constexpr int SB = SHARED_SB;
     bool bad = false;
     float ll_keep[SB];
 #pragma unroll
     for (int si = 0; si < SB; si++) {
+        if (MS && (si & 3) != wave) continue;
         const float tot = ssum[si] + other_half(ssum[si]);
         const float ll2 = off + log2f(tot);
         ll_keep[si] = LSE_LN2 * ll2;
         const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
         bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
     }
-    if (__builtin_amdgcn_ballot_w64(bad) != 0) {      // wave-uniform
-        if (lane == 0 && has) {
+    bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;      // wave-uniform
+    if constexpr (MS) {
+        if (any_bad && lane == 0) atomicOr(s_bad, 1);
+        __syncthreads();
+        any_bad = *reinterpret_cast<volatile int *>(s_bad) != 0;
+        __syncthreads();                               // everybody has read it
+        if (threadIdx.x == 0) *s_bad = 0;              // (for the next block: published by the barrier at its top)
+    }
+    if (any_bad) {
+        if (lane == 0 && has && (!MS || wave == 0)) {
             const int idx = atomicAdd(a.exc_count, 1);
             if (idx < a.exc_cap) a.exc_list[idx] = make_int2(tile_id, blk);
         }
@@ -149,6 +162,7 @@ __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBl
     }
 #pragma unroll
     for (int si = 0; si < SB; si++) {
+        if (MS && (si & 3) != wave) continue;
         double mine = 0.0;
         if (valid && hh == 0 && si < sb.n_models) {
             mine = (double)ll_keep[si];
@@ -168,13 +182,14 @@ __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBl
 // two column tiles per wave (COLS = 2: half the LDS fragment reads, 2 waves per SIMD) -4 %; 8 waves x 2 column
 // tiles -5 %; 8 waves with the two waves of a SIMD held in anti-phase by a workgroup barrier per phase (one
 // chains while the other runs its epilogue) -3 % with one image per phase, -5 % with two.
-__host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, int waves) {
+__host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, int waves, bool ms = false) {
     // The 4-wave shape at three workgroups per CU (168 registers) kept its quadratic-half frame fragments in scratch from
     // kqf + klf = 10 up (156 .. 364 bytes per lane, one reload inside the image loop = an s_waitcnt vmcnt(0) on the LDS-DMA
     // stream).  Since round 4 it only serves batches below ~2000 frames (score_device: everything larger takes a 12-wave
     // shape) -- a handful of workgroups, latency-bound, where a third workgroup per CU buys nothing: two per CU, 256 registers,
     // nothing in scratch.
-    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf >= 9) ? 2 : 3;
+    // (the model-split shape carries a few registers more: at three workgroups per CU its 3 + 3 and 4 + 4 forms spilled 24 / 52 bytes)
+    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf >= (ms ? 6 : 9)) ? 2 : 3;
 }
 // the quadratic-half frame fragments in LDS instead of registers: every 12-wave shape (round 3), and the 4-wave shape of the long
 // chains (round 4: with them in registers it spilled 76 bytes per lane even at 256 registers)
@@ -190,14 +205,20 @@ __host__ __device__ constexpr int h2s_stage_images(int kqf, int klf, int waves) 
 // (344 bytes per lane with the prologue's temporaries: 7 GB of scratch writes per configs[2] pass, profiles/r02b_pmc.txt).
 // Taken for the 12-wave shape (one workgroup per CU: the LDS is there); the 4-wave shape shares a CU's LDS three ways.
 // Same speed as the scratch form to 0.5 % (profiles/r03_scoring_experiments.txt), bit-identical results, 142 VGPRs, no scratch.
-template <int KQF, int KLF, int COLS, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, h2s_waves_per_eu(KQF, KLF, COLS, WAVES))
+// MS (round 4): the 4-wave shape for the smallest batches -- one serving utterance is ten 32-frame tiles: 42 workgroups of the
+// plain shape, each wave alone with a chain of 2048 MFMAs (93 us).  Here a workgroup holds ONE tile and its four waves split the
+// block's models (wave w: models w, w + 4, ...; every wave forms the quadratic half itself: 19 images' worth of MFMAs per
+// mixture tile instead of 16): four times the workgroups, chains a third as long, same results bit for bit (a (frame, model)
+// sum is formed by one lane in the same order either way).
+template <int KQF, int KLF, int COLS, int WAVES, bool MS = false>
+__global__ __launch_bounds__(WAVES * 64, h2s_waves_per_eu(KQF, KLF, COLS, WAVES, MS))
 void gmm_score_h2s_kernel(const H2sArgs a) {
+    static_assert(!MS || (WAVES == 4 && COLS == 1), "the model-split shape: four waves, one tile");
     constexpr int SB = SHARED_SB;
     constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
     constexpr int G = BQ_LDS ? 2 : h2s_stage_images(KQF, KLF, WAVES);      // (2 images per stage measured the same as 4)
     extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64] when BQ_LDS
-    constexpr int TILES_WG = WAVES * COLS;                     // 32-frame tiles per workgroup
+    constexpr int TILES_WG = MS ? 1 : WAVES * COLS;            // 32-frame tiles per workgroup
     constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
     constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;          // every image padded to the larger of the two
     constexpr int STRIDE_U4 = (1 + SB) * IMG_U4;               // one mixture tile of one block
@@ -205,12 +226,14 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     static_assert((1 + SB) % G == 0 && (N_STAGES % 2) == 0, "stages must tile the 16 images and alternate buffers");
     __shared__ uint4 lds_a[G * IMG_U4];
     __shared__ uint4 lds_b[G * IMG_U4];
+    __shared__ int s_bad;                                      // (MS) a wave's models sent the tile to the exception list
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31;
     const int hh = lane >> 5;
+    if (MS && tid == 0) s_bad = 0;                             // (published by the barrier at the top of the first block)
 
     // a stage is N_PIECES wave-instructions of 1 KiB; wave w issues pieces w, w + WAVES, ... (a scalar test)
     constexpr int N_PIECES = G * IMG_U4 / 64;
@@ -255,7 +278,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     float zmax = 0.0f;
 #pragma unroll
     for (int c = 0; c < COLS; c++) {
-        tile_id[c] = tile0 + wave * COLS + c;
+        tile_id[c] = tile0 + (MS ? 0 : wave * COLS + c);
         has[c] = tile_id[c] < a.n_tiles;
         const TileDesc tile = a.tiles[has[c] ? tile_id[c] : a.n_tiles - 1];
         valid[c] = has[c] && col < tile.count;
@@ -336,7 +359,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                         } else {
                             h2s_chain_regs<KQF, KM, COLS>(qacc, zero16, fr, bq);
                         }
-                    } else
+                    } else if (!MS || ((img - 1) & 3) == wave)
                         h2s_chain_regs<KLF, KM, COLS>(acc, qacc, fr, bl);
                     __builtin_amdgcn_sched_barrier(0);
                     if (gi == G - 1) {
@@ -358,7 +381,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
                         for (int c = 0; c < COLS; c++)
 #pragma unroll
                             for (int r = 0; r < 16; r++) qacc[c][r] -= off[c];
-                    } else {
+                    } else if (!MS || ((img - 1) & 3) == wave) {
 #pragma unroll
                         for (int c = 0; c < COLS; c++) {
                             // (Tried in round 3 and lost, profiles/r03_h2s_experiments.txt: skipping the 16 exponentials of a
@@ -383,7 +406,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         // ---- close the block's models: per 32-frame tile, so an utterance's fate does not depend on its neighbours ----
 #pragma unroll
         for (int c = 0; c < COLS; c++)
-            h2s_close_block(a, sb, blk, ssum[c], off[c], valid[c], has[c], tile_id[c], row[c], lane, hh, safe_ll2);
+            h2s_close_block<MS>(a, sb, blk, ssum[c], off[c], valid[c], has[c], tile_id[c], row[c], lane, hh, safe_ll2, wave, &s_bad);
     }
 }
 
@@ -850,7 +873,7 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 // LDS the pipelined kernel takes: its ring of two stages of four images plus the 12 waves' quadratic-half fragments
 __host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (2 * 4 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
 
-template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false>
+template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false, bool MS = false>
 static int launch_h2s(const H2sLaunch &l) {
     constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
     H2sArgs a;
@@ -881,8 +904,8 @@ static int launch_h2s(const H2sLaunch &l) {
     a.force_exc = l.force_exc;
     a.band_hi = l.band_hi;
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
-    constexpr int TILES_WG = WAVES * COLS;
-    const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES));
+    constexpr int TILES_WG = MS ? 1 : WAVES * COLS;
+    const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES, MS));
     const int n_wg = (l.n_tiles + TILES_WG - 1) / TILES_WG;
     // (the 12-wave form has one workgroup per CU sweeping the stream: nothing drifts apart, 1 / 3 / 5 / 9 / 18 launches
     // per configs[2] pass all take 0.281-0.283 s -- one launch)
@@ -903,7 +926,7 @@ static int launch_h2s(const H2sLaunch &l) {
                     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2p_kernel<KQF, KLF>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
                 else
-                    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>),
+                    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES, MS>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
                 attr_set[ctx().device] = true;
             }
@@ -911,7 +934,7 @@ static int launch_h2s(const H2sLaunch &l) {
         if constexpr (PIN)
             hipLaunchKernelGGL((gmm_score_h2p_kernel<KQF, KLF>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
         else
-            hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
+            hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES, MS>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
     }
     a.tile_base = 0;
     // the exception pass: persistent single-wave workgroups over the (tile, block) list the main pass left
@@ -920,9 +943,10 @@ static int launch_h2s(const H2sLaunch &l) {
     return n_launches;
 }
 
-// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves; 2: 12 waves, pipelined)
-int h2s_resident_per_cu(int kqf, int klf, int shape) { return shape == 0 ? h2s_waves_per_eu(kqf, klf, 1, 4) : 1; }
-int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : 12; }
+// workgroups resident per CU, and 32-frame tiles per workgroup, of shape `shape` (0: 4 waves; 1: 12 waves; 2: 12 waves, pipelined;
+// 3: 4 waves on one tile, the block's models split between them)
+int h2s_resident_per_cu(int kqf, int klf, int shape) { return (shape == 0 || shape == 3) ? h2s_waves_per_eu(kqf, klf, 1, 4, shape == 3) : 1; }
+int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : shape == 3 ? 1 : 12; }
 bool h2s_pipelined_available(int kqf, int klf) { return h2p_fits(kqf, klf); }
 
 // returns the number of launches of the main kernel the pass was cut into
@@ -931,6 +955,7 @@ int launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {
     if (KQF == Q && KLF == L) {                                 \
         if constexpr (h2p_fits(Q, L))                           \
             if (l.shape == 2) return launch_h2s<Q, L, 1, 12, true>(l); \
+        if (l.shape == 3) return launch_h2s<Q, L, 1, 4, false, true>(l); \
         if (l.shape >= 1) return launch_h2s<Q, L, 1, 12>(l);    \
         return launch_h2s<Q, L, 1, 4>(l);                       \
     }

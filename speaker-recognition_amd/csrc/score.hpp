@@ -110,6 +110,7 @@ bool h2s_pipelined_available(int kqf, int klf);         // shape 2 (12 waves, im
 // mostly phantom models).
 constexpr int SHARED_MIN_MODELS = 12;
 constexpr int H2S_WIDE_SHAPE = 1;       // the one-workgroup-per-CU shape
+constexpr int H2S_MSPLIT_SHAPE = 3;     // four waves on ONE tile, the block's models split between them: the smallest batches (round 4)
 constexpr int H2S_PIPELINED_SHAPE = 2;  // the same with the image loop pipelined inside each wave: what the dispatcher takes for large batches
 void launch_score_split(const MfmaLaunch &a, int scheme, int KS, int FT);   // a.params = the split image
 int split_max_ft(int ks);
