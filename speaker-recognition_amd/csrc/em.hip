@@ -601,7 +601,7 @@ static void dispatch_stats_split(int DP, int KS, const float *X, int64_t n, int 
                                  const float *frame_ll, double *slabs, int n_tiles128, int n_ranges, int n_chunks, int k_pad, double *out) {
 #define SR_CASE(V, W) if (DP == V && KS == W) return launch_stats_split<V, W>(X, n, dim, frags, n_mix_tiles, center, frame_ll, slabs, n_tiles128, n_ranges, n_chunks, k_pad, out);
     SR_CASE(8, 1) SR_CASE(8, 2) SR_CASE(13, 2) SR_CASE(16, 2) SR_CASE(16, 3) SR_CASE(24, 3) SR_CASE(24, 4) SR_CASE(26, 4)
-    SR_CASE(32, 4) SR_CASE(32, 5) SR_CASE(34, 5) SR_CASE(39, 5) SR_CASE(40, 5)
+    SR_CASE(32, 4) SR_CASE(32, 5) SR_CASE(34, 5) SR_CASE(39, 5)         // (DP = 40 is dim = 40: six steps, 164 KB of LDS -- not available)
 #undef SR_CASE
     fail("no split-responsibility EM kernel for padded dim %d with %d contraction steps", DP, KS);
 }

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <deque>
 #include <numeric>
+#include <system_error>
 #include <thread>
 
 using namespace sr;
@@ -121,13 +122,24 @@ void staging_copy(void *dst, const void *src, size_t bytes) {
         return;
     }
     const size_t per = ((bytes / parts) + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
+    struct Joiner {                          // (a thread that could not be started leaves its part to this one)
+        std::vector<std::thread> th;
+        ~Joiner() {
+            for (auto &t : th) t.join();
+        }
+    } helpers;
+    size_t mine_hi = std::min(bytes, per);   // this thread copies [0, mine_hi) and whatever nobody else took
+    std::vector<std::pair<size_t, size_t>> left;
     for (int p = 1; p < parts; p++) {
         const size_t lo = std::min(bytes, per * p), hi = p + 1 == parts ? bytes : std::min(bytes, per * (p + 1));
-        th.emplace_back([=] { std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+        try {
+            helpers.th.emplace_back([=] { std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+        } catch (const std::system_error &) {
+            left.emplace_back(lo, hi);
+        }
     }
-    std::memcpy(dst, src, std::min(bytes, per));
-    for (auto &t : th) t.join();
+    std::memcpy(dst, src, mine_hi);
+    for (const auto &r : left) std::memcpy((char *)dst + r.first, (const char *)src + r.first, r.second - r.first);
 }
 
 // true when [p, p + bytes) is page-locked host memory the copy engines can read directly (hipHostMalloc / hipHostRegister
