@@ -15,6 +15,8 @@ ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + [synth.synth_map_speaker(ubm
 _lib.profile_enable(True)
 _lib.set_option("score_h2s_shape", shape)
 _lib.set_option("score_model_groups", groups)
+if os.environ.get("SR_GM") is not None:
+    _lib.set_option("score_h2s_group_major", int(os.environ["SR_GM"]))          # launch order of the model groups (1 = group-major)
 for U in Us:
     feats = Batch.from_features([synth.draw_frames(ubm, 300, 10 + u) for u in range(U)])
     ts, tr = [], []
@@ -24,4 +26,4 @@ for U in Us:
         if r > 1:
             ts.append(_lib.profile_get(_lib.T_SCORE)[0])
             tr.append(_lib.profile_get(_lib.T_SCORE_REF)[0])
-    print("groups %d shape %d U = %3d: scoring %.4f ms  pre-pass %.4f ms  %s" % (groups, shape, U, float(np.median(ts)), float(np.median(tr)), _lib.last_score_kernel().split(" ")[0]), flush=True)
+    print("gm %s groups %d shape %d U = %3d: scoring %.4f ms  pre-pass %.4f ms  %s" % (os.environ.get("SR_GM", "-"), groups, shape, U, float(np.median(ts)), float(np.median(tr)), _lib.last_score_kernel().split(" ")[0]), flush=True)

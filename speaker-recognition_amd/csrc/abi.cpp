@@ -31,6 +31,9 @@ std::atomic<int> &stream_debug_capture_delay_ms();      // stream.cpp
 std::atomic<int> &multi_pieces_option();                // multi.cpp
 std::atomic<int> &multi_merge_option();
 namespace sr {
+int &h2s_group_major_option();                          // gmm_score_h2_shared.hip
+}
+namespace sr {
 void kmeans_fast_stats(long *passes, long *rechecked);
 int reference_side_effects();
 }  // namespace sr
@@ -778,6 +781,8 @@ int sr_set_option(const char *key, long value) {
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
+    } else if (k == "score_h2s_group_major") {
+        sr::h2s_group_major_option() = value != 0;
     } else if (k == "multi_merge_same_device") {
         multi_merge_option().store(value != 0);
     } else if (k == "multi_pieces") {

@@ -118,6 +118,8 @@ struct H2sArgs {
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
     int tile_base;                // first frame tile of this launch (long grids are cut into several launches)
+    int rows8;                    // rows of 8 workgroups (one per XCD) this launch has per model group
+    int group_major;              // 1: a group's workgroups are consecutive in launch order (small batches, see launch_h2s)
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
@@ -263,8 +265,8 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 
     const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
     const int q = blockIdx.x >> 3;
-    const int g = q % a.n_groups;
-    const int tile0 = a.tile_base + ((q / a.n_groups) * 8 + wg_lo) * TILES_WG;     // first 32-frame tile of this workgroup
+    const int g = a.group_major ? q / a.rows8 : q % a.n_groups;
+    const int tile0 = a.tile_base + ((a.group_major ? q % a.rows8 : q / a.n_groups) * 8 + wg_lo) * TILES_WG;     // first 32-frame tile of this workgroup
     if (tile0 >= a.n_tiles) return;
     const int blk_begin = a.group_block_begin[g];
     const int blk_end = a.group_block_begin[g + 1];
@@ -576,8 +578,8 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
 
     const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
     const int q = blockIdx.x >> 3;
-    const int g = q % a.n_groups;
-    const int tile0 = a.tile_base + ((q / a.n_groups) * 8 + wg_lo) * WAVES;
+    const int g = a.group_major ? q / a.rows8 : q % a.n_groups;
+    const int tile0 = a.tile_base + ((a.group_major ? q % a.rows8 : q / a.n_groups) * 8 + wg_lo) * WAVES;
     if (tile0 >= a.n_tiles) return;
     const int blk_begin = a.group_block_begin[g];
     const int blk_end = a.group_block_begin[g + 1];
@@ -873,6 +875,11 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 // LDS the pipelined kernel takes: its ring of two stages of four images plus the 12 waves' quadratic-half fragments
 __host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (2 * 4 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
 
+int &h2s_group_major_option() {
+    static int v = 1;       // sr_set_option("score_h2s_group_major", 0 | 1): A/B of the launch order (below)
+    return v;
+}
+
 template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false, bool MS = false>
 static int launch_h2s(const H2sLaunch &l) {
     constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
@@ -918,6 +925,13 @@ static int launch_h2s(const H2sLaunch &l) {
         a.tile_base = base * TILES_WG;
         const int n = std::min(wg_per_launch, n_wg - base);
         dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
+        // Launch order.  With ONE group every workgroup sweeps all blocks from block 0 on, in phase with its XCD's others (see the
+        // kernel).  With several, workgroups of different groups stream different blocks: group-fastest order (rounds 2-3) put one
+        // workgroup of EVERY block on each XCD at a time -- no reuse in its L2, every stage a trip to HBM, the loop bound by that
+        // latency (64 utterances x 300 frames: ~780 cycles per image against 381 in a full-chip pass).  Group-major order runs a
+        // block's workgroups side by side.
+        a.rows8 = (n + 7) / 8;
+        a.group_major = l.n_groups > 1 && h2s_group_major_option();
         constexpr size_t dyn = BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0;
         if constexpr (BQ_LDS) {
             static bool attr_set[MAX_DEVICES] = {};
