@@ -218,24 +218,29 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     static_assert(!MS || (WAVES == 4 && COLS == 1), "the model-split shape: four waves, one tile");
     constexpr int SB = SHARED_SB;
     constexpr bool BQ_LDS = h2s_bq_in_lds(KQF, KLF, WAVES);
-    constexpr int G = BQ_LDS ? 2 : h2s_stage_images(KQF, KLF, WAVES);      // (2 images per stage measured the same as 4)
-    extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64] when BQ_LDS
-    constexpr int TILES_WG = MS ? 1 : WAVES * COLS;            // 32-frame tiles per workgroup
     constexpr int Q_U4 = KQF * 64, L_U4 = KLF * 64;
     constexpr int IMG_U4 = Q_U4 > L_U4 ? Q_U4 : L_U4;          // every image padded to the larger of the two
+    // images per LDS stage.  (2 measured the same as 4 for the 12-wave shape.)  The 4-wave shapes serve small batches only (round 4:
+    // below ~2000 frames, at most a workgroup per CU): their few workgroups stream COLD images -- no neighbour on the XCD has
+    // fetched them -- and wait out a trip to HBM per stage: four images per stage where two such buffers fit the 64 KiB of
+    // static LDS (300 frames, model-split shape: 0.094 -> 0.081 ms).
+    constexpr int G = WAVES == 4 ? (2 * 4 * IMG_U4 * (int)sizeof(uint4) <= 65536 ? 4 : 2) : BQ_LDS ? 2 : h2s_stage_images(KQF, KLF, WAVES);
+    extern __shared__ uint4 h2s_bq_lds[];                                  // [WAVES][KQF][64] when BQ_LDS; (MS) one more for s_bad
+    constexpr int TILES_WG = MS ? 1 : WAVES * COLS;            // 32-frame tiles per workgroup
     constexpr int STRIDE_U4 = (1 + SB) * IMG_U4;               // one mixture tile of one block
     constexpr int N_STAGES = (1 + SB) / G;
     static_assert((1 + SB) % G == 0 && (N_STAGES % 2) == 0, "stages must tile the 16 images and alternate buffers");
     __shared__ uint4 lds_a[G * IMG_U4];
     __shared__ uint4 lds_b[G * IMG_U4];
-    __shared__ int s_bad;                                      // (MS) a wave's models sent the tile to the exception list
+    // (MS) "a wave's models sent the tile to the exception list": behind the dynamic region (the static one may be full)
+    int *const s_bad = reinterpret_cast<int *>(h2s_bq_lds + (BQ_LDS ? WAVES * KQF * 64 : 0));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31;
     const int hh = lane >> 5;
-    if (MS && tid == 0) s_bad = 0;                             // (published by the barrier at the top of the first block)
+    if (MS && tid == 0) *s_bad = 0;                            // (published by the barrier at the top of the first block)
 
     // a stage is N_PIECES wave-instructions of 1 KiB; wave w issues pieces w, w + WAVES, ... (a scalar test)
     constexpr int N_PIECES = G * IMG_U4 / 64;
@@ -408,7 +413,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         // ---- close the block's models: per 32-frame tile, so an utterance's fate does not depend on its neighbours ----
 #pragma unroll
         for (int c = 0; c < COLS; c++)
-            h2s_close_block<MS>(a, sb, blk, ssum[c], off[c], valid[c], has[c], tile_id[c], row[c], lane, hh, safe_ll2, wave, &s_bad);
+            h2s_close_block<MS>(a, sb, blk, ssum[c], off[c], valid[c], has[c], tile_id[c], row[c], lane, hh, safe_ll2, wave, s_bad);
     }
 }
 
@@ -932,8 +937,8 @@ static int launch_h2s(const H2sLaunch &l) {
         // block's workgroups side by side.
         a.rows8 = (n + 7) / 8;
         a.group_major = l.n_groups > 1 && h2s_group_major_option();
-        constexpr size_t dyn = BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0;
-        if constexpr (BQ_LDS) {
+        constexpr size_t dyn = (BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0) + (MS ? sizeof(uint4) : 0);
+        if constexpr (dyn > 0) {
             static bool attr_set[MAX_DEVICES] = {};
             if (!attr_set[ctx().device]) {
                 if constexpr (PIN)
