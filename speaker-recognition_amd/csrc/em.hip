@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <memory>
 
 namespace sr {
@@ -631,8 +632,14 @@ void burn_reference_rand(int count);
 // cores at the same fp32 grade (K = 2048 x 39, 400 k frames: 2.7 ms on the vector engine per pass); score_device falls back to
 // the vector engine by itself while the model is outside that layout's range (collapsed variances early in a fit).
 static void pack_em_set(SRModelSet &set, const GMM &gmm) {
-    set.host = pack_models({&gmm});
-    if (gmm.dim <= MAX_MATRIX_DIM && score_options().engine == 0) set.bx3 = pack_models_split({&gmm}, SPLIT_BF16X3);
+    if (gmm.dim <= MAX_MATRIX_DIM && score_options().engine == 0) {
+        // (the two layouts are independent functions of the model: side by side on two host threads, 1.35 -> 0.9 ms at K = 2048 x 39)
+        auto split = std::async(std::launch::async, [&gmm] { return pack_models_split({&gmm}, SPLIT_BF16X3); });
+        set.host = pack_models({&gmm});
+        set.bx3 = split.get();
+    } else {
+        set.host = pack_models({&gmm});
+    }
 }
 
 struct EmWorkspace {
