@@ -119,11 +119,32 @@ struct H2sArgs {
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
     int tile_base;                // first frame tile of this launch (long grids are cut into several launches)
     int rows8;                    // rows of 8 workgroups (one per XCD) this launch has per model group
-    int group_major;              // 1: a group's workgroups are consecutive in launch order (small batches, see launch_h2s)
+    int group_major;              // launch order of the model groups' workgroups (h2s_wg_assignment): 0 group-fastest, 1 group-major
+    int n_wg;                     // workgroups (of TILES_WG tiles) per group in this launch
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
+
+// Which (model group, frame tiles) a workgroup of the main kernels takes.  Consecutive blockIdx go to consecutive XCDs (8 of
+// them, each with its own L2), and workgroups of different groups stream different blocks' images:
+//   0  group-fastest (rounds 2-3): one workgroup of every group on each XCD in turn;
+//   1  group-major (round 4): a group's workgroups consecutive in launch order, spread over the 8 XCDs.
+// (Tried: XCD-major -- every XCD a contiguous run of (group, tile) pairs, whole groups where there are enough tiles, so that a
+// block's images come into ONE L2 only.  No better than 0: 64 utterances x 300 frames 0.755 ms against 0.652 for group-major.)
+__device__ __forceinline__ bool h2s_wg_assignment(const H2sArgs &a, int tiles_wg, int &g, int &tile0) {
+    const int wg_lo = blockIdx.x & 7, q = blockIdx.x >> 3;
+    int t;
+    if (a.group_major) {
+        g = q / a.rows8;
+        t = (q - g * a.rows8) * 8 + wg_lo;
+    } else {
+        g = q % a.n_groups;
+        t = (q / a.n_groups) * 8 + wg_lo;
+    }
+    tile0 = a.tile_base + t * tiles_wg;
+    return tile0 < a.n_tiles && t < a.n_wg;
+}
 
 // Close of one block's models for one 32-frame tile (both main kernels): the offset form is only trusted well inside fp32's
 // exponent range and well above the reference's underflow boundary; a tile with a frame outside goes to the exception list
@@ -268,11 +289,8 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
         __syncthreads();
     };
 
-    const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
-    const int q = blockIdx.x >> 3;
-    const int g = a.group_major ? q / a.rows8 : q % a.n_groups;
-    const int tile0 = a.tile_base + ((a.group_major ? q % a.rows8 : q / a.n_groups) * 8 + wg_lo) * TILES_WG;     // first 32-frame tile of this workgroup
-    if (tile0 >= a.n_tiles) return;
+    int g, tile0;                                  // this workgroup's model group and first 32-frame tile
+    if (!h2s_wg_assignment(a, TILES_WG, g, tile0)) return;
     const int blk_begin = a.group_block_begin[g];
     const int blk_end = a.group_block_begin[g + 1];
 
@@ -581,11 +599,8 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
     };
     auto barrier = [&]() { asm volatile("s_barrier" ::: "memory"); };
 
-    const int wg_lo = blockIdx.x & 7;              // XCD-aware order, as gmm_score_kernel
-    const int q = blockIdx.x >> 3;
-    const int g = a.group_major ? q / a.rows8 : q % a.n_groups;
-    const int tile0 = a.tile_base + ((a.group_major ? q % a.rows8 : q / a.n_groups) * 8 + wg_lo) * WAVES;
-    if (tile0 >= a.n_tiles) return;
+    int g, tile0;                                  // this workgroup's model group and first 32-frame tile
+    if (!h2s_wg_assignment(a, WAVES, g, tile0)) return;
     const int blk_begin = a.group_block_begin[g];
     const int blk_end = a.group_block_begin[g + 1];
 
@@ -881,7 +896,7 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 __host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (2 * 4 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
 
 int &h2s_group_major_option() {
-    static int v = 1;       // sr_set_option("score_h2s_group_major", 0 | 1): A/B of the launch order (below)
+    static int v = 1;       // sr_set_option("score_h2s_group_major", 0 | 1): A/B of the launch order (h2s_wg_assignment)
     return v;
 }
 
@@ -936,6 +951,7 @@ static int launch_h2s(const H2sLaunch &l) {
         // latency (64 utterances x 300 frames: ~780 cycles per image against 381 in a full-chip pass).  Group-major order runs a
         // block's workgroups side by side.
         a.rows8 = (n + 7) / 8;
+        a.n_wg = n;
         a.group_major = l.n_groups > 1 && h2s_group_major_option();
         constexpr size_t dyn = (BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0) + (MS ? sizeof(uint4) : 0);
         if constexpr (dyn > 0) {
