@@ -2,7 +2,7 @@
 """Workgroup shapes of the generic split-fp16 engine side by side inside ONE GPU-box call:
     ab_split_shape.py WORKLOAD [SHAPE ...]        (shapes: 1 = 4-wave kernel, 8 / 12 / 16 = waves of gmm_score_splitp_kernel; default all)
     ab_split_shape.py WORKLOAD --groups G ...     (force the number of model groups)
-WORKLOAD as scripts/ab_option.py: point256 (1 x 256 x 39, 2 M frames) | cfg1 (100 x 64 x 39, 1 M frames) | small13 | ubm512 | serve (201 x 64 x 39, 8 x 300 frames)
+WORKLOAD as scripts/ab_option.py: point256 (1 x 256 x 39, 2 M frames) | cfg1 (100 x 64 x 39, 1 M frames) | small13 | ubm512 | serve (201 x 64 x 39, 8 x 300 frames) | stream1024 (20 x 256 x 13, 1024 x 61 frames)
 Prints the scoring kernel's HIP-event time per shape (alternating, median of 5), G frames/s, TB/s of feature reads, the algorithmic
 TFLOP/s (S K (4 D + 6) per frame) and the largest relative difference of the sums against the first shape."""
 import os
@@ -17,7 +17,8 @@ from speaker_recognition_amd.core import Batch, ModelSet  # noqa: E402
 from speaker_recognition_amd.pygmm import GMM  # noqa: E402
 
 SHAPES = {"point256": (1, 256, 39, 2000, 1000), "cfg1": (100, 64, 39, 1000, 1000), "small13": (10, 32, 13, 1000, 1000), "ubm512": (1, 512, 39, 1000, 1000),
-          "serve": (201, 64, 39, 8, 300), "cfg1_k256": (100, 256, 39, 250, 1000)}
+          "serve": (201, 64, 39, 8, 300), "cfg1_k256": (100, 256, 39, 250, 1000),
+          "stream1024": (20, 256, 13, 1024, 61), "cfg1_d26": (100, 64, 26, 1000, 1000), "cfg1_d20": (100, 64, 20, 1000, 1000), "cfg1_d13": (100, 64, 13, 1000, 1000)}     # configs[4]: 1024 one-second windows per tick
 
 
 def main():

@@ -797,7 +797,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             // the short streams (one 256-mixture model: 0.33 against 0.38 ms) and the small batches
             const int want = opt.split_shape ? opt.split_shape : 8;
             const int w = splitp_waves(SPLIT_F16X2, split.ks, want);
-            if (w > 0 && (opt.split_shape || ((int64_t)S * split_cpm >= 32 &&
+            // ... and the long contractions only: with fewer than 5 steps (D < 32) a chunk is 6-12 MFMAs against the same ~60-instruction
+            // update and the 4-wave kernel wins or ties (100 x 64 mixtures, 1 M frames: D = 26 2.40 against 2.45 ms, D = 20 2.02 / 2.17,
+            // D = 13 1.74 / 1.82; configs[4]'s tick of 1024 windows, 20 x 256 x 13: 0.090 against 0.143 -- scripts/ab_split_shape.py)
+            if (w > 0 && (opt.split_shape || (split.ks >= 5 && (int64_t)S * split_cpm >= 32 &&
                                               (n32 / w) * (int64_t)std::min(S, 16) >= (int64_t)6 * ctx().n_cu * splitp_resident_per_cu(w))))
                 splitp_w = w;
         }
