@@ -820,7 +820,6 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
     constexpr int N_IMG = 1 + SB;
     constexpr int KM = KQF > KLF ? KQF : KLF;
     static_assert(N_IMG % 2 == 0, "the two fragment sets alternate by image parity");
-    __shared__ uint4 bq_lds[KQF * 64];
     const int lane = threadIdx.x;
     const int col = lane & 31;
     const int hh = lane >> 5;
@@ -832,18 +831,9 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
         const TileDesc tile = a.tiles[e.x];
         const bool valid = col < tile.count;
         const int64_t row = tile.start + (valid ? col : 0);
-        f16x8 bl[1][KLF];
+        f16x8 bq[1][KQF], bl[1][KLF];
         float zmax = 0.0f;
-        {
-            // the quadratic-half fragments are needed once per 16 images: parked in LDS (this wave's own 8 KiB), their registers
-            // go to the fragment ring below
-            f16x8 bq[KQF];
-            h2s_build_b<KQF>(bq, a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
-            wave_sync();                                   // (the previous pair's reads of bq_lds are done: same wave, in order)
-#pragma unroll
-            for (int ks = 0; ks < KQF; ks++) bq_lds[ks * 64 + lane] = __builtin_bit_cast(uint4, bq[ks]);
-            wave_sync();
-        }
+        h2s_build_b<KQF>(bq[0], a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
         h2s_build_b<KLF>(bl[0], a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
         if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
         const SharedBlock sb = a.blocks[e.y];
@@ -854,37 +844,30 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
             m[si] = NEG_BIG;
             ssum[si] = 0.0f;
         }
-        // A ring of NR fragment sets: image i's fragments are requested NR - 1 images ahead (through round 4's first half one
-        // image ahead -- a lone wave streaming cold images waited out most of a trip to L2 / HBM per image: 1.0 s of the
-        // configs[3] shard's 6.9 s went into this pass at its 0.1 % outlier frames).
-        constexpr int NR = KM <= 8 ? 4 : 2;        // (the 9- and 10-step chains have no registers for more than two sets)
-        static_assert(N_IMG % NR == 0, "the fragment sets rotate by image index");
-        uint4 fr[NR][KM];
-        auto fetch = [&](uint4 (&f)[KM], const uint4 *at, int kn) {
+        uint4 fa[KM], fb[KM];
+        auto fetch = [&](uint4 (&fr)[KM], const uint4 *at, int kn) {
 #pragma unroll
             for (int ks = 0; ks < KM; ks++)
-                if (ks < kn) f[ks] = at[ks * 64];
+                if (ks < kn) fr[ks] = at[ks * 64];
         };
+        fetch(fa, stream, KQF);
         const int n_img_total = a.n_mix_tiles * N_IMG;
-#pragma unroll
-        for (int i = 0; i < NR - 1; i++)
-            if (i < n_img_total) fetch(fr[i], stream + (size_t)i * IMG_U4, i == 0 ? KQF : KLF);
         for (int t = 0; t < a.n_mix_tiles; t++) {
             f32x16 qacc[1];
 #pragma unroll
             for (int img = 0; img < N_IMG; img++) {
                 const int flat = t * N_IMG + img;
-                constexpr int AHEAD = NR - 1;
-                const int nimg = (img + AHEAD) % N_IMG;                  // (compile-time after unrolling)
-                if (flat + AHEAD < n_img_total) fetch(fr[(img + AHEAD) % NR], stream + (size_t)(flat + AHEAD) * IMG_U4, nimg == 0 ? KQF : KLF);
+                const uint4 *next = stream + (size_t)(flat + 1) * IMG_U4;
+                const int next_kn = (img + 1 == N_IMG) ? KQF : KLF;
                 f32x16 acc[1];
-                if (img == 0) {
-                    f16x8 bqt[1][KQF];
-#pragma unroll
-                    for (int ks = 0; ks < KQF; ks++) bqt[0][ks] = __builtin_bit_cast(f16x8, bq_lds[ks * 64 + lane]);
-                    h2s_chain_regs<KQF, KM, 1>(qacc, {zero1}, fr[img % NR], bqt);
-                } else
-                    h2s_chain_regs<KLF, KM, 1>(acc, qacc, fr[img % NR], bl);
+                if ((img & 1) == 0) {
+                    if (flat + 1 < n_img_total) fetch(fb, next, next_kn);
+                    if (img == 0) h2s_chain_regs<KQF, KM, 1>(qacc, {zero1}, fa, bq);
+                    else h2s_chain_regs<KLF, KM, 1>(acc, qacc, fa, bl);
+                } else {
+                    if (flat + 1 < n_img_total) fetch(fa, next, next_kn);
+                    h2s_chain_regs<KLF, KM, 1>(acc, qacc, fb, bl);
+                }
                 if (img > 0) {
                     lse_update16(acc[0], m[img - 1], ssum[img - 1], near_thr);
                     asm volatile("" : "+v"(m[img - 1]), "+v"(ssum[img - 1]));
