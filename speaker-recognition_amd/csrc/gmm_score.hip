@@ -371,13 +371,14 @@ struct ScoreWorkspace {
     // one host-bound copy and one clear each instead of two and three (a copy or a fill is ~4.5 us on the stream: 18 us of a
     // 240 us single-utterance decision, round 4).
     DevBuf<double> results;
-    DevBuf<int> counters;                // [0] saturation flag of the fp16 engines, [1] pairs in the partial-product band, [2] exception list length
+    DevBuf<int> counters;                // [0] saturation flag of the fp16 engines, [1] pairs in the partial-product band, [4 ...] the shared-sigma
+                                         // engine's exception tiles per model block
     double *sums_p(size_t n_sums) { (void)n_sums; return results.p; }
     int *argmax_p(size_t n_sums) { return reinterpret_cast<int *>(results.p + n_sums); }
     void ensure_results(size_t n_utt, size_t n_models) { results.ensure(n_utt * n_models + (n_utt + 1) / 2 + 1); }
     int *oor_p() { return counters.p; }
     int *flush_count_p() { return counters.p + 1; }
-    int *exc_count_p() { return counters.p + 2; }
+    int *exc_count_p() { return counters.p + 4; }
     DevBuf<float> frame_ll;
     DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
     DevBuf<double> ref_partial;
@@ -810,8 +811,9 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 
     auto &w = ws();
     bool used_oor = false;
-    w.counters.ensure(4);
-    SR_HIP(hipMemsetAsync(w.counters.p, 0, 4 * sizeof(int), ctx().stream));     // the pass's counters, all at once
+    const size_t n_counters = 4 + set.h2s.blocks.size();
+    w.counters.ensure(n_counters);
+    SR_HIP(hipMemsetAsync(w.counters.p, 0, n_counters * sizeof(int), ctx().stream));     // the pass's counters, all at once
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
     // 0 off, 1 the reference's clamp, 2 the same with "all terms underflowed" reported as -inf (a half of a hybrid set)
     const int clamp_mode = (flags & 1) ? ((flags & SCORE_NO_FLUSH) ? 2 : 1) : 0;
@@ -924,8 +926,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 launch_score_split(r, opt.h2s_exact_offset ? SPLIT_F16X2 : SPLIT_F16X1, h.ref.ks, 1);
             }
             const int n_blocks = (int)h.blocks.size();
-            const size_t cap = (size_t)tt.n_tiles * n_blocks;
-            w.exc_list.ensure(2 * cap);
+            w.exc_list.ensure((size_t)std::max(1, tt.n_tiles) * n_blocks);
             H2sLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
@@ -942,7 +943,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.oor_flag = w.oor_p();
             a.exc_list = w.exc_list.p;
             a.exc_count = w.exc_count_p();
-            a.exc_cap = (int)std::min<size_t>(cap, 0x7fffffff);
+            a.n_blocks = n_blocks;
             a.n_frames = feat.n_rows;
             a.dim = feat.dim;
             a.n_models = S;

@@ -91,9 +91,9 @@ struct H2sLaunch {
     double *partial;
     float *frame_ll;
     int *oor_flag;
-    int *exc_list;      // int2 pairs
-    int *exc_count;
-    int exc_cap;
+    int *exc_list;      // [n_blocks][n_tiles] tile ids
+    int *exc_count;     // [n_blocks]
+    int n_blocks;
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
     float log2_k;
