@@ -212,7 +212,11 @@ __host__ __device__ constexpr int h2s_waves_per_eu(int kqf, int klf, int cols, i
     // shape) -- a handful of workgroups, latency-bound, where a third workgroup per CU buys nothing: two per CU, 256 registers,
     // nothing in scratch.
     // (the model-split shape carries a few registers more: at three workgroups per CU its 3 + 3 and 4 + 4 forms spilled 24 / 52 bytes)
-    return waves > 4 ? waves / 4 : (cols > 1 || kqf + klf >= (ms ? 6 : 9)) ? 2 : 3;
+    // (since the 4-wave shapes stream four images per stage their LDS admits two workgroups per CU at most, and their batches --
+    // below ~2000 frames -- never need more: two per CU for every chain length; the third one's 168-register budget was
+    // what spilled, last in <4,4> once the exception lists became per block)
+    (void)kqf; (void)klf; (void)cols; (void)ms;
+    return waves > 4 ? waves / 4 : 2;
 }
 // the quadratic-half frame fragments in LDS instead of registers: every 12-wave shape (round 3), and the 4-wave shape of the long
 // chains (round 4: with them in registers it spilled 76 bytes per lane even at 256 registers)
