@@ -30,7 +30,8 @@ configs[1], a stated sub-sample of one rank's configs[3] shard, configs[4] laten
 oracle/ is never imported by this process: the CPU baseline (oracle/cpu_baseline.py) and the parity
 samples (oracle/parity_check.py) run as subprocesses, outside every timed region, as checkers.
 
-Prints ONE JSON line on rank 0.
+Prints ONE compact JSON line (<= 1500 characters: headline + roofline + cpu_baseline + parity figures) as the LAST line of
+stdout on rank 0; the full record with every secondary block goes to bench_blocks.json (--blocks-out) and to stderr.
 """
 import argparse
 import json
@@ -696,6 +697,79 @@ def cpu_baseline_leg(spec):
     return json.loads(line), None
 
 
+# ------------------------------------------------------------------ the line the driver parses
+COMPACT_LIMIT = 1500           # characters; the driver keeps a 2000-character tail of stdout
+
+
+def _r(v, sig=5):
+    """numbers at `sig` significant digits (the full-precision values are in the blocks file)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    try:
+        return float("%.*g" % (sig, float(v)))
+    except (TypeError, ValueError):
+        return None
+
+
+def compact(result, blocks_file=None):
+    """The headline as ONE short JSON object: BASELINE.json's metric with `roofline` and `cpu_baseline`, numbers only --
+    every prose note, per-rank list and secondary block stays in the blocks file.  Never longer than COMPACT_LIMIT."""
+    rf = result.get("roofline") or {}
+    cb = result.get("cpu_baseline") or {}
+    par = result.get("parity") or {}
+    cfg = result.get("config") or {}
+    e2e = par.get("end_to_end_cpu_pool_sample") or {}
+    pf = par.get("per_frame_ll_from_pcm") or {}
+    mf = par.get("mfcc_configs[2]_audio") or par.get("mfcc_configs[1]_audio") or {}
+    line = {
+        "metric": result.get("metric"), "value": _r(result.get("value"), 7), "unit": result.get("unit"),
+        "n_gpus": result.get("n_gpus"), "steps": result.get("steps"), "warmup": result.get("warmup"),
+        "ms_per_step": _r(result.get("ms_per_step"), 6), "higher_is_better": True, "scaling": result.get("scaling"),
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: 16 kHz PCM -> 39-dim MFCC+d+dd, 512-mix UBM + 200 MAP speakers, 10 M frames/GPU",
+                   "frames_per_gpu": cfg.get("frames_per_gpu"), "models": cfg.get("models"), "mixtures": cfg.get("mixtures"),
+                   "dim": cfg.get("dim"), "sharding": "utterances, no collective"},
+        "roofline": {"kernel": str(rf.get("kernel", ""))[:48], "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")),
+                     "peak": rf.get("peak"), "unit": rf.get("unit"), "frac": _r(rf.get("frac"), 4),
+                     "frac_executed_mfma": _r(rf.get("frac_executed_mfma"), 4), "avg_launch_ms": _r(rf.get("avg_launch_ms")),
+                     "launches_per_pass": rf.get("launches_per_pass"), "traffic": _r(rf.get("traffic")),
+                     "algorithmic_bytes": _r(rf.get("algorithmic_bytes")),
+                     "hbm_GBps": _r((rf.get("hbm") or {}).get("achieved_GBps"), 4)},
+        "cpu_baseline": ({"error": str(cb.get("error"))[:80]} if "error" in cb else
+                         {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                          "sample": ("%s utt x 10.04 s, all %s models: reference C++ score_batch on Pool(%s) + f64 MFCC.py restatement"
+                                     % (e2e.get("utterances"), e2e.get("models"), cb.get("cores"))) if cb else None}),
+        "parity": {"argmax_mismatches": e2e.get("argmax_mismatches"), "utt_sum_max_rel": _r(e2e.get("max_rel_sum_diff"), 3),
+                   "frame_ll_from_pcm_max_rel": _r(pf.get("max_rel"), 3), "frame_ll_from_pcm_frames": pf.get("frames"),
+                   "mfcc_max_abs": _r(mf.get("max_abs_diff_vs_oracle"), 3), "mfcc_mean_abs": _r(mf.get("mean_abs_diff_vs_oracle"), 3),
+                   "steps_bit_identical": par.get("last_two_steps_bit_identical")},
+        "from_host_pcm_ms_per_step": _r(result.get("from_host_pcm_ms_per_step")),
+        "mfcc_ms_per_step": _r((result.get("kernel_ms_per_step") or {}).get("mfcc_frames")),
+        "blocks_file": os.path.basename(blocks_file) if blocks_file else None,
+    }
+    if (result.get("n_gpus") or 1) > 1:
+        line["scaling_efficiency_vs_rank0_alone"] = _r(result.get("scaling_efficiency_vs_rank0_alone"), 4)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:                          # cannot happen with the fields above; never let it break the driver
+        for k in ("parity", "from_host_pcm_ms_per_step", "mfcc_ms_per_step", "blocks_file"):
+            line.pop(k, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(result, blocks_file):
+    """full record -> blocks file (+ stderr); compact headline -> the LAST line of stdout"""
+    full = json.dumps(result)
+    try:
+        with open(blocks_file, "w") as fh:
+            fh.write(full + "\n")
+    except OSError as e:
+        print("bench.py: could not write %s: %s" % (blocks_file, e), file=sys.stderr)
+        blocks_file = None
+    print(full, file=sys.stderr, flush=True)
+    print(compact(result, blocks_file), flush=True)
+
+
 # ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -714,6 +788,9 @@ def main():
                          "0 = 64 when the container may use >= 64 cores, else 32 (a bounded ~20 s of CPU work either way)")
     ap.add_argument("--rendezvous", choices=("socket", "gloo"), default=os.environ.get("SR_RENDEZVOUS", "socket"),
                     help="how the N ranks meet on the host: the package's Unix-domain socket (no torch) or torch.distributed over gloo")
+    ap.add_argument("--blocks-out", default=os.path.join(ROOT, "bench_blocks.json"),
+                    help="file the FULL record (headline + every secondary block, rooflines, parity samples) is written to; stdout "
+                         "carries the compact headline line only")
     ap.add_argument("--device-override", type=int, default=-1,
                     help="testing only: put every rank on this device (N>1 code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -1030,7 +1107,7 @@ def main():
         except Exception as e:
             blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
         result["configs"] = blocks
-    print(json.dumps(result), flush=True)
+    emit(result, args.blocks_out)
     if grp is not None:
         grp.barrier()
 
