@@ -11,6 +11,7 @@
 // float64 tables built on the host exactly as the reference builds them.
 #include "batch.hpp"
 #include "mfcc.hpp"
+#include "mfcc_dev.hpp"
 #include "wave_ops.hpp"
 
 #include <algorithm>
@@ -85,18 +86,6 @@ SRMfcc::SRMfcc(double fs_, double win_length_ms, double win_shift_ms, int fft_si
 }
 
 namespace sr {
-
-struct MfccDev {
-    const float *window;      // [L]
-    const float2 *twiddle;    // [NFFT/2]  W_NFFT^k
-    const int *mel_row;       // [n_filters+1]
-    const int *mel_col;       // [nnz]
-    const float *mel_val;     // [nnz]
-    const float *mel_floor;   // [n_filters]  ln(1e-100 * row sum): the reference's floored silence
-    const float *dct;         // [n_ceps][n_filters]
-    int frame_len, frame_shift, fft_size, n_filters, n_ceps;
-    float pre_emph;
-};
 
 bool mfcc_force_generic();
 int mfcc_waves_per_block();
@@ -331,36 +320,10 @@ __device__ __forceinline__ void dft_n1(float2 (&v)[16]) {
     }
 }
 
-// Mel rows are contiguous column runs; for the fast kernel they are re-laid as 4 passes x 16 bands,
-// every run of a pass zero-padded to the same multiple of 16 columns, so that 4 lanes sweep a band
-// with plain (unclamped) reads; element i of band b sits at pass_base[pass] + (i/4)*64 + (b%16)*4 + i%4,
-// i.e. one sweep step of all 64 lanes reads 64 consecutive floats (bank-conflict free).
-struct MelRuns {
-    const int *col0;        // [64] first column of the band's run (0 for absent bands)
-    const float *pad_val;   // padded weights
-    int pad_floats;         // total floats in pad_val
-    int pass_base[4];       // float offset of each pass
-    int pass_len[4];        // padded run length of the pass (multiple of 16)
-};
-
-constexpr int MFCC_DCT_LD = 80;     // row stride of the zero-padded DCT table in LDS: 320 B = 64 B mod 256, so the 4 rows x 4
-                                    // parts of a 16-lane ds_read_b128 phase cover 16 distinct 16-byte windows (64 floats would put
-                                    // all 16 rows on the same banks)
-constexpr int WAVE_SLAB_C = 1088;   // complex slots per wave: max(16*68, 64*17, 1024)
-
 // One wave = one contiguous range of frames (binary search for the utterance once, then walk);
 // per-lane constants (window taps, pass-1/2 twiddles) live in registers, the untangle twiddles
 // and the mel / DCT tables in LDS; the next frame's samples are prefetched while the current
 // frame is transformed.
-// Mel sweep lengths (16-bin steps per pass of 16 bands) of the two common filterbanks, known at
-// compile time so that the sweep unrolls completely and its LDS reads are issued ahead of their use;
-// preset 0 takes the lengths from MelRuns at run time (any other fs / n_filters).
-__host__ __device__ constexpr int mel_preset_steps(int preset, int pass) {
-    return preset == 1 ? (pass == 0 ? 2 : pass == 1 ? 3 : pass == 2 ? 6 : 7)      // fs 16 kHz, 50 filters, FFT 2048
-         : preset == 2 ? (pass == 0 ? 2 : pass == 1 ? 4 : 6)                       // fs  8 kHz, 50 filters, FFT 2048
-                       : 0;
-}
-
 // WPB = waves per workgroup: 4 (per-lane twiddle constants in registers, 2 waves/SIMD) or 12 (the
 // pass-1 and untangle twiddles read from LDS instead: <= 168 VGPRs, 3 waves/SIMD; one workgroup per
 // CU, its tables shared by 12 waves).
@@ -748,18 +711,7 @@ void cmvn_delta_kernel(const float *__restrict__ raw, const int64_t *__restrict_
 
 // ---------------- host: device tables + launch ----------------
 
-struct MfccDeviceTables {
-    DevBuf<float> window, mel_val, mel_floor, dct;
-    DevBuf<float2> twiddle;
-    DevBuf<int> mel_row, mel_col, mel_col0, mel_cnt;
-    DevBuf<float> mel_pad;
-    int device = -1;
-    int nnz = 0, max_cnt = 0;
-    int pass_base[4] = {0, 0, 0, 0}, pass_len[4] = {0, 0, 0, 0}, pad_floats = 0;
-    bool runs_contiguous = true;
-};
-
-static MfccDev upload_tables(SRMfcc &m) {
+MfccDev upload_tables(SRMfcc &m) {
     std::shared_ptr<void> &slot = m.dev[current_device()];
     if (!slot) {
         auto t = std::make_shared<MfccDeviceTables>();
@@ -799,6 +751,38 @@ static MfccDev upload_tables(SRMfcc &m) {
         t->mel_col.upload(col.data(), col.size());
         t->mel_val.upload(val.data(), val.size());
         t->mel_floor.upload(floor_ln.data(), floor_ln.size());
+        {   // float64 copies for the float64-spectrum kernels (mfcc_f64.hip)
+            std::vector<double2> twd64(nc);
+            for (int k = 0; k < nc; k++) {
+                const double ang = -2.0 * M_PI * k / NF;
+                twd64[k] = make_double2(std::cos(ang), std::sin(ang));
+            }
+            std::vector<double> val64, floor64(64, 0.0), dpad((size_t)4 * 64 * 4, 0.0);
+            for (int b = 0; b < B; b++) {
+                double rs = 0.0;
+                for (int c = 0; c <= nc; c++) {
+                    const double v = m.melbank[(size_t)b * (nc + 1) + c];
+                    if (v != 0.0) {
+                        val64.push_back(v);
+                        rs += v;
+                    }
+                }
+                floor64[b] = std::log(1e-100 * rs);
+            }
+            if (C <= 16)
+                for (int it = 0; it < 4; it++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int q = 0; q < 4; q++) {
+                            const int ci = lane >> 2, band = 16 * it + 4 * (lane & 3) + q;
+                            if (ci < C && band < B) dpad[((size_t)it * 64 + lane) * 4 + q] = m.dct[(size_t)ci * B + band];
+                        }
+            t->window64.upload(m.window.data(), m.window.size());
+            t->twiddle64.upload(twd64.data(), twd64.size());
+            t->mel_val64.upload(val64.data(), val64.size());
+            t->mel_floor64.upload(floor64.data(), floor64.size());
+            t->dct64.upload(m.dct.data(), m.dct.size());
+            t->dct_pad64.upload(dpad.data(), dpad.size());
+        }
         // Padded re-layout for the fast kernel: pass ps holds bands 16ps..16ps+15.  Four lanes sweep a
         // band, 8 bands share a 32-lane LDS group; a band's sweep start is moved down to a multiple of
         // 4 columns whose 4-bank window (start/4 mod 8) no other band of its group uses, with leading
@@ -858,6 +842,19 @@ static MfccDev upload_tables(SRMfcc &m) {
     d.n_filters = m.n_filters;
     d.n_ceps = m.n_ceps;
     d.pre_emph = (float)m.pre_emph;
+    return d;
+}
+
+MfccDev64 device_tables_f64(SRMfcc &m) {
+    auto &t = device_tables(m);
+    MfccDev64 d;
+    d.window = t.window64.p;
+    d.twiddle = t.twiddle64.p;
+    d.mel_val = t.mel_val64.p;
+    d.mel_floor = t.mel_floor64.p;
+    d.dct = t.dct64.p;
+    d.dct_pad = t.dct_pad64.p;
+    d.pre_emph = m.pre_emph;
     return d;
 }
 
@@ -942,7 +939,11 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
         const bool fast = (m.fft_size == 2048 || m.fft_size == 1024 || m.fft_size == 512) && m.frame_len <= m.fft_size &&
                           tabs.runs_contiguous && m.n_ceps <= 16 && !mfcc_force_generic();
         ScopedKernelTimer t(T_MFCC);
-        if (fast) {
+        if (mfcc_precision() == 2) {
+            // float64 spectrum for every frame (MFCC.py:59-70 computes in float64): mfcc_f64.hip
+            mfcc_launch_f64(m, dev, pcm.kind, pcm.kind == SRBatch::PCM16 ? (const void *)pcm.pcm16.p : (const void *)pcm.data.p, d_pcm_off,
+                            w.raw_off.p, U, NF, w.raw.p);
+        } else if (fast) {
             MelRuns mr;
             mr.col0 = tabs.mel_col0.p;
             mr.pad_val = tabs.mel_pad.p;
