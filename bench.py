@@ -305,6 +305,12 @@ def block_cfg1(_lib, ex, base, hbm, preq):
     preq["configs[1]"] = {"models": raw, "X": X200, "offsets": fb.offsets(), "device_sums": sums[:n200], "device_frame_ll": f200}
     preq["mfcc_configs[1]_audio"] = {"kind": "mfcc", "pcm": cat[:off[n200]], "sample_offsets": off[:n200 + 1], "fs": FS, "mfcc_kw": MFCC_KW,
                                      "nd": ND, "device_feats": X200, "offsets": fb.offsets()}
+    # END TO END (north_star's criterion): the first 64 utterances' per-frame log-likelihoods computed from PCM by the device against the
+    # float64 feature oracle -> the reference's arithmetic, all 100 models
+    n64 = min(64, n200)
+    fo = fb.offsets()
+    preq["configs[1]_from_pcm"] = {"kind": "pcm_ll", "pcm": cat[:off[n64]], "sample_offsets": off[:n64 + 1], "fs": FS, "mfcc_kw": MFCC_KW, "nd": ND,
+                                   "models": raw, "device_frame_ll": f200[:, :fo[n64]], "offsets": fo[:n64 + 1], "device_sums": s200[:n64]}
     small_vs_timed = float(np.max(np.abs(s200 - sums[:n200]) / np.maximum(1.0, np.abs(s200))))
     return {"workload": "BASELINE.json configs[1]: 39-dim MFCC+delta+delta-delta, 100 speaker GMMs x 64 mixtures, %d utterances x %d frames" % (CFG1_UTTS, FRAMES_PER_UTT),
             "frames_per_s": n_frames * 10 / el, "ms_per_step": 1e3 * el / 10,
@@ -1068,6 +1074,14 @@ def main():
             preq["configs[2]_headline"] = {"models_recipe": {"kind": "cfg2", "K": CFG2_MIX, "dim": DIM, "S": CFG2_SPEAKERS, "ubm_seed": 99, "spk_seed": 500},
                                            "X": fb.download(), "offsets": fb.offsets(), "device_sums": sums[:n200], "device_frame_ll": f200}
             result["parity"]["small_batch_sums_vs_timed_pass_max_rel"] = float(np.max(np.abs(s200 - sums[:n200]) / np.maximum(1.0, np.abs(s200))))
+            # END TO END (north_star's criterion): 64 utterances from PCM, the UBM + 24 speakers (bounded CPU work for the checker)
+            n64, fo, idx = min(64, n200), fb.offsets(), list(range(25))
+            preq["configs[2]_from_pcm"] = {"kind": "pcm_ll", "pcm": cat[:off[n64]], "sample_offsets": off[:n64 + 1], "fs": FS, "mfcc_kw": MFCC_KW, "nd": ND,
+                                           "models_recipe": {"kind": "cfg2", "K": CFG2_MIX, "dim": DIM, "S": CFG2_SPEAKERS, "ubm_seed": 99, "spk_seed": 500},
+                                           "model_index": idx, "device_frame_ll": f200[idx][:, :fo[n64]], "offsets": fo[:n64 + 1],
+                                           "device_sums": s200[:n64][:, idx]}
+            preq["mfcc_configs[2]_audio"] = {"kind": "mfcc", "pcm": cat[:off[n200]], "sample_offsets": off[:n200 + 1], "fs": FS, "mfcc_kw": MFCC_KW,
+                                             "nd": ND, "device_feats": preq["configs[2]_headline"]["X"], "offsets": fo}
             del fb, f200
         except Exception as e:
             result["parity"]["headline_sample_error"] = "%s: %s" % (type(e).__name__, e)
@@ -1102,8 +1116,19 @@ def main():
                     result["parity"]["headline_200_utterances_x_all_models"] = v
                 elif name.startswith("mfcc_"):
                     result["parity"][name] = v
+                elif name.endswith("_from_pcm"):
+                    result["parity"].setdefault("per_frame_ll_from_pcm", {"configs": {}})["configs"][name[:-len("_from_pcm")]] = v
                 elif name == "_checker":
                     result["parity"]["checker"] = v
+            pf = result["parity"].get("per_frame_ll_from_pcm")
+            if pf:
+                vs = list(pf["configs"].values())
+                pf.update({"max_rel": max(v["max_rel_frame_ll_diff_vs_oracle"] for v in vs), "frames": sum(v["frames"] for v in vs),
+                           "frame_model_pairs": sum(v["frames"] * v["models"] for v in vs),
+                           "clamp_mismatches": sum(v["frames_with_different_clamp_decision"] for v in vs),
+                           "argmax_mismatches": sum(v.get("argmax_mismatches", 0) for v in vs),
+                           "gate": "north_star: |d| <= 1e-4 max(1, |LL|) per frame; device PCM -> LL against float64 MFCC.py restatement -> "
+                                   "the reference's scoring arithmetic (oracle/parity_check.py, kind pcm_ll)"})
         except Exception as e:
             blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
         result["configs"] = blocks

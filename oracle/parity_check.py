@@ -18,6 +18,12 @@ or, for the FEATURE stage (spec key "kind": "mfcc"),
 runs the float64 numpy restatement of the reference's MFCC.py / utils.py (oracle/mfcc_oracle.py) on every utterance -- Pool over
 utterances, as src/test/test-gmm.py:207-212 -- and reports max / mean |device - oracle| (SURVEY.md 8d gates: 1e-3 / 1e-5).
 
+END TO END FROM PCM (spec key "kind": "pcm_ll"): "pcm" / "sample_offsets" / "fs" / "mfcc_kw" / "nd" as above, the models (optionally
+"model_index": the subset that was scored), and the device's per-frame log-likelihoods "device_frame_ll" float32[S', n] computed from the
+PCM by its own feature stage.  The checker builds the features with the float64 oracle (never rounded to float32), scores them with the
+reference's arithmetic, and compares per frame: north_star's criterion, |d| <= 1e-4 max(1, |LL|) on identical INPUTS (MFCC.py:49-79 ->
+utils.py:24-31 -> gmm.cc:237-244), clamp decisions, per-utterance sums and argmax.
+
 The GMM specs: scores every frame under every model with the C restatement of the reference's arithmetic (oracle/gmm_oracle.c mode 3 =
 mode 0, what the reference's C ABI computes, to remez5's 1.2e-6: score_batch_fast) on ALL host cores --
 multiprocessing.Pool over (model, frame range) tasks, the shape of the reference's own test driver
@@ -119,6 +125,15 @@ def _mfcc_task(t):
     return name, float(d.max()) if d.size else 0.0, float(d.sum()), int(d.size), float(np.abs(f32 - ref).max()), dyn_db
 
 
+def _feat_task(t):
+    """(name, utterance) -> float64 features of the oracle chain (MFCC -> CMVN -> deltas), never rounded to float32"""
+    from oracle import mfcc_oracle as mo
+    name, u = t
+    r = _REQ[name]
+    so = r["sample_offsets"]
+    return name, u, mo.extract(r["fs"], r["pcm"][so[u]:so[u + 1]], diff=r["nd"] > 0, nd=max(1, r["nd"]), **r["mfcc_kw"])
+
+
 def main():
     from oracle import gmm_oracle as go
     if not os.path.exists(go.ORACLE_SO):
@@ -134,10 +149,36 @@ def main():
         r["device_feats"] = np.asarray(r["device_feats"], dtype=np.float32)
         _REQ[name] = r
         mfcc_tasks += [(name, u) for u in range(len(r["sample_offsets"]) - 1)]
+    cores = hostinfo.effective_cores()
+    # end-to-end specs: their frames come from the float64 feature oracle, one utterance per task
+    pcm_ll = [k for k, v in req.items() if v.get("kind") == "pcm_ll"]
+    feat_tasks = []
+    for name in pcm_ll:
+        r = req[name]
+        r["pcm"] = np.asarray(r["pcm"])
+        r["sample_offsets"] = np.asarray(r["sample_offsets"], dtype=np.int64)
+        _REQ[name] = r
+        feat_tasks += [(name, u) for u in range(len(r["sample_offsets"]) - 1)]
+    if feat_tasks:
+        if cores > 1:
+            with mp.get_context("fork").Pool(min(cores, len(feat_tasks))) as pool:
+                feats = pool.map(_feat_task, feat_tasks, chunksize=1)
+        else:
+            feats = [_feat_task(t) for t in feat_tasks]
+        for name in pcm_ll:
+            mine = sorted((x for x in feats if x[0] == name), key=lambda x: x[1])
+            r = req[name]
+            r["X"] = np.concatenate([x[2] for x in mine], axis=0)
+            own_off = np.concatenate([[0], np.cumsum([len(x[2]) for x in mine])])
+            if not np.array_equal(own_off, np.asarray(r["offsets"], dtype=np.int64)):
+                raise SystemExit("pcm_ll spec %s: the device's frame offsets differ from the oracle's" % name)
+            del r["pcm"]
     tasks = []
     for name, r in req.items():
         if "models" not in r:
             r["models"] = _models_from_recipe(r["models_recipe"])
+        if r.get("model_index") is not None:
+            r["models"] = [r["models"][i] for i in r["model_index"]]
         r["X"] = np.ascontiguousarray(r["X"], dtype=np.float64)
         r["offsets"] = np.asarray(r["offsets"], dtype=np.int64)
         if r.get("device_frame_ll") is not None:
@@ -147,7 +188,6 @@ def main():
             for f0 in range(0, n, FRAME_CHUNK):
                 tasks.append((name, s, f0, min(n, f0 + FRAME_CHUNK)))
         _REQ[name] = r
-    cores = hostinfo.effective_cores()
     procs = max(1, min(cores, len(tasks) + len(mfcc_tasks)))
     t0 = time.perf_counter()
     mfcc_results = []
@@ -189,7 +229,7 @@ def main():
             clamp_bad += cb
             for u, v in parts:
                 want[u, s] += v
-        o = {"utterances": U, "models": S, "frames": int(len(r["X"])),
+        o = {"utterances": U, "models": S, "frames": int(len(r["X"])), "features": "float64 oracle from PCM" if r.get("kind") == "pcm_ll" else "the device's own",
              "mixture_evaluations": int(len(r["X"])) * int(sum(len(m[0]) for m in r["models"]))}
         if r.get("device_frame_ll") is not None:
             o["max_rel_frame_ll_diff_vs_oracle"] = worst

@@ -24,7 +24,7 @@ for st in "$@"; do
             else timeout $T python -m pytest tests -x -q -m gpu < /dev/null 2>&1 | tail -15; fi ;;
     smoke)  timeout 120 python -c "import __graft_entry__ as g; g.smoke()" < /dev/null 2>&1 | tail -3 ;;
     device) (rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4; nproc; rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|mclk|Power" | head -6) > $O/${TAG}_device.txt < /dev/null; cat $O/${TAG}_device.txt ;;
-    bench)  timeout $T python bench.py $arg > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err < /dev/null; tail -3 $O/${TAG}_bench.err; cut -c1-1500 $O/${TAG}_bench.json ;;
+    bench)  timeout $T python bench.py $arg > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err < /dev/null; grep -v '^{' $O/${TAG}_bench.err | tail -5 | cut -c1-300; [ -f bench_blocks.json ] && cp bench_blocks.json $O/${TAG}_blocks.json; tail -1 $O/${TAG}_bench.json | cut -c1-1600 ;;
     prof)   CMD="python $R/bench.py ${arg:-$DEF_ARGS}"
             (cd /tmp && timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -o $TAG -- $CMD > $O/${TAG}_rocprof_run.log 2>&1 < /dev/null)
             f=$(find $O/${TAG}_prof -name "*kernel_stats*.csv" < /dev/null | head -1)

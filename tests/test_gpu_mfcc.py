@@ -1,19 +1,41 @@
 """GPU parity for the MFCC chain: HIP kernels vs the vectors recorded from the reference's own
 MFCC.py (tests/golden/mfcc_golden.npz) and vs the float64 oracle on fresh seeded audio.
-Gate: after CMVN max |d| <= 1e-3 (fp32 chain vs float64 reference), mean <= 1e-5."""
+Gate: after CMVN max |d| <= 1e-3, mean <= 1e-5.  The default chain (float64 spectrum, ln and DCT:
+csrc/mfcc_f64.hip) sits three orders under it; `mfcc_precision` 0 (fp32 throughout) is tested at the gate itself."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _default_mfcc_options(built_lib):
+    """every test starts (and leaves) with the defaults: float64 spectrum, register-resident kernel where it applies"""
+    from speaker_recognition_amd import _lib
+    _lib.set_option("mfcc_precision", 2)
+    _lib.set_option("mfcc_generic", 0)
+    yield
+    _lib.set_option("mfcc_precision", 2)
+    _lib.set_option("mfcc_generic", 0)
+
+
+# (precision, raw rel, feature max, feature mean, delta max, delta-delta max)
+# precision 2 = float64 spectrum / ln / DCT (the default; what is left is the fp32 rounding of the outputs and of the mel sums),
+# precision 0 = fp32 throughout (rounds 1-4: 5.8e-6 .. 9.3e-6 mean, 1.2e-4 max over the golden cases)
+TOL = {2: (2e-6, 1e-5, 1e-6, 2e-5, 4e-5), 0: (2e-4, 1e-3, 1e-5, 1e-3, 2e-3)}
+
+
+@pytest.mark.parametrize("precision", [2, 0])
 @pytest.mark.parametrize("generic", [0, 1])
-def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden, generic):
-    """generic=0: register-resident FFT-2048 kernel where it applies; generic=1: LDS-pass kernel."""
+def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden, generic, precision):
+    """generic=0: register-resident FFT-2048 kernel where it applies; generic=1: LDS-pass kernel; both in both precisions,
+    against the vectors recorded from the reference's own MFCC.py."""
     from speaker_recognition_amd import _lib
     from speaker_recognition_amd.core import Batch, MfccExtractor
     from speaker_recognition_amd.feature import MFCC
     _lib.set_option("mfcc_generic", generic)
+    _lib.set_option("mfcc_precision", precision)
+    t_raw, t_max, t_mean, t_d1, t_d2 = TOL[precision]
     m = mfcc_golden
     for c in m["cases"]:
         kw = eval(str(m[c + "_kw"]))
@@ -22,19 +44,43 @@ def test_golden_raw_cmvn_and_deltas(built_lib, mfcc_golden, generic):
         raw = ex.extract(pcm, cmvn=False)
         ref_raw = m[c + "_raw"]
         assert raw.shape == ref_raw.shape, c
-        # raw cepstra span +-25; fp32 FFT + log: relative 1e-5 is generous enough to be robust
-        assert np.max(np.abs(raw - ref_raw)) < 2e-4 * max(1.0, np.abs(ref_raw).max()), (c, np.max(np.abs(raw - ref_raw)))
+        assert np.max(np.abs(raw - ref_raw)) < t_raw * max(1.0, np.abs(ref_raw).max()), (c, np.max(np.abs(raw - ref_raw)))
         feat = MFCC.extract(fs, pcm, **kw)
-        assert np.max(np.abs(feat - m[c + "_feat"])) < 1e-3, (c, np.max(np.abs(feat - m[c + "_feat"])))
-        # SURVEY.md 8d's gate on the mean: 1e-5.  Measured (scripts/debug/mfcc_error.py, round 3): 5.8e-6 .. 9.3e-6 over the five
-        # golden cases and both FFT kernels (max 1.2e-4); with both deltas appended (39 dims, the bench audio) 1.1e-5 .. 1.4e-5 --
-        # a second difference carries up to four times the error of its three terms
-        assert np.mean(np.abs(feat - m[c + "_feat"])) < 1e-5, (c, np.mean(np.abs(feat - m[c + "_feat"])))
+        assert np.max(np.abs(feat - m[c + "_feat"])) < t_max, (c, np.max(np.abs(feat - m[c + "_feat"])))
+        assert np.mean(np.abs(feat - m[c + "_feat"])) < t_mean, (c, np.mean(np.abs(feat - m[c + "_feat"])))     # 1e-5
         d1 = MFCC.extract((fs, pcm), diff=True, **kw)                 # tuple form, MFCC.py:125-127
         d2 = MFCC.extract(fs, pcm, diff=True, nd=2, **kw)
         assert d1.shape == m[c + "_d1"].shape and d2.shape == m[c + "_d2"].shape
-        assert np.max(np.abs(d1 - m[c + "_d1"])) < 1e-3 and np.max(np.abs(d2 - m[c + "_d2"])) < 2e-3
+        assert np.max(np.abs(d1 - m[c + "_d1"])) < t_d1 and np.max(np.abs(d2 - m[c + "_d2"])) < t_d2
+
+
+@pytest.mark.parametrize("speaker", [0, 50, 99])
+def test_survey_8d_speakers_within_gate(built_lib, speaker):
+    """SURVEY.md 8d's gate -- after CMVN max |d| <= 1e-3, mean <= 1e-5 against the float64 chain (MFCC.py:59-70) -- on the
+    audio the benchmark configs are quoted on: synth_speech(s, seed 2000 + s), 25/10 ms, 39 dims.  Speaker 50's mel bands lie
+    up to 100 dB apart in a frame (80 Hz formants over a noise source): fp32 throughout gives 1.3e-3 / 3.8e-5 there and
+    misses both; the float64 spectrum gives ~1e-6 / 2.5e-7 on the 13 statics, ~4e-6 / 4e-7 over the 39 dims with both deltas
+    (a second difference carries up to four times the error of its terms)."""
+    import bench
+    from oracle import mfcc_oracle as mo
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor
+    pcm = synth.synth_speech(speaker, 10.04, bench.FS, seed=bench.AUDIO_SEED + speaker)
+    ref = mo.extract(bench.FS, pcm, diff=True, nd=2, **bench.MFCC_KW)
+    got = {}
+    for generic in (0, 1):
+        _lib.set_option("mfcc_generic", generic)
+        got[generic] = MfccExtractor(bench.FS, **bench.MFCC_KW).extract_batch(Batch.from_pcm([pcm]), nd=2).download()
+        d = np.abs(got[generic] - ref)
+        assert d[:, :13].max() <= 1e-3 and d[:, :13].mean() <= 1e-5                     # the gate
+        assert d[:, :13].max() <= 1e-5 and d[:, :13].mean() <= 1e-6, (generic, d[:, :13].max(), d[:, :13].mean())   # what float64 gives
+        assert d.max() <= 2e-5 and d.mean() <= 2e-6, (generic, d.max(), d.mean())       # deltas included
     _lib.set_option("mfcc_generic", 0)
+    _lib.set_option("mfcc_precision", 0)
+    d = np.abs(MfccExtractor(bench.FS, **bench.MFCC_KW).extract_batch(Batch.from_pcm([pcm]), nd=2).download() - ref)
+    assert d.max() < 1e-2                                                               # fp32 mode: usable, not within the gate
+    if speaker == 50:
+        assert d[:, :13].mean() > 1e-5                                                  # (why float64 is the default)
 
 
 def test_ragged_batch_vs_oracle(built_lib):
@@ -60,7 +106,7 @@ def test_ragged_batch_vs_oracle(built_lib):
             ref = mo.extract(fs, np.asarray(s, dtype=np.float64), diff=True, nd=2, **kw)
             got = X[off[i]:off[i + 1]]
             assert got.shape == ref.shape
-            assert np.max(np.abs(got - ref)) < 2e-3, (i, as_float, np.max(np.abs(got - ref)))
+            assert np.max(np.abs(got - ref)) < 4e-5, (i, as_float, np.max(np.abs(got - ref)))
 
 
 @pytest.mark.parametrize("fs,win,shift,fft", [(16000, 25, 10, 512), (16000, 25, 10, 1024), (8000, 32, 16, 512), (16000, 32, 16, 1024),
@@ -86,18 +132,17 @@ def test_fft_sizes_vs_oracle(built_lib, fs, win, shift, fft):
         for i, p in enumerate(pcm):
             raw = ex.extract(p, cmvn=False)
             assert raw.shape == ref_raw[i].shape
-            assert np.max(np.abs(raw - ref_raw[i])) < 2e-4 * max(1.0, np.abs(ref_raw[i]).max()), (generic, i, np.max(np.abs(raw - ref_raw[i])))
+            assert np.max(np.abs(raw - ref_raw[i])) < 2e-6 * max(1.0, np.abs(ref_raw[i]).max()), (generic, i, np.max(np.abs(raw - ref_raw[i])))
         out = ex.extract_batch(Batch.from_pcm(pcm), nd=2)
         X, off = out.download(), out.offsets()
         for i in range(len(pcm)):
             d = np.abs(X[off[i]:off[i + 1]] - ref[i])
-            # SURVEY 8d's 1e-3 on the normalised cepstra holds on the reference's default shapes (the golden test); across this
-            # sweep the worst case is 1.01e-3 (8 kHz, 32 ms, FFT 512: bands 60 dB below the peak sit at fp32's FFT noise
-            # floor, and the log turns that into absolute error) -- 2e-3 here, and the differences of up to 4 cepstra behind it
-            assert d[:, :13].max() < 2e-3 and d[:, 13:].max() < 4e-3, (generic, i, d[:, :13].max(), d[:, 13:].max())
+            # float64 spectrum (the default): what remains is the fp32 rounding of the outputs (rounds 1-4, fp32 throughout: 1.01e-3 on
+            # the 8 kHz / 32 ms / FFT 512 shape, whose bands sit 60 dB under the peak)
+            assert d[:, :13].max() < 1e-5 and d[:, 13:].max() < 4e-5, (generic, i, d[:, :13].max(), d[:, 13:].max())
         got[generic] = X
     _lib.set_option("mfcc_generic", 0)
-    assert np.max(np.abs(got[0] - got[1])) < 4e-3
+    assert np.max(np.abs(got[0] - got[1])) < 4e-5
 
 
 def test_silence_floor_matches_reference(built_lib):
@@ -113,7 +158,7 @@ def test_silence_floor_matches_reference(built_lib):
     raw = ex.extract(pcm, cmvn=False)
     ref = mo.get_mfcc_extractor(fs).raw_cepstra(pcm.astype(float))
     assert np.all(np.isfinite(raw))
-    assert np.max(np.abs(raw - ref)) < 5e-3, np.max(np.abs(raw - ref))
+    assert np.max(np.abs(raw - ref)) < 2e-4, np.max(np.abs(raw - ref))
 
 
 def test_lpc_and_mix_feature_vs_oracle(built_lib):
@@ -175,4 +220,4 @@ def test_full_size_cfg1_feature_properties(built_lib):
     assert np.max(np.abs(a - b)) < 2e-3              # ln(gain^2) is a constant per band: CMVN removes it
     for u in (0, 499, 998):
         ref = mo.extract(bench.FS, clips[u], diff=True, nd=2, **bench.MFCC_KW)
-        assert np.max(np.abs(X[off[u]:off[u + 1]] - ref)) < 1e-3
+        assert np.max(np.abs(X[off[u]:off[u + 1]] - ref)) < 4e-5

@@ -646,3 +646,47 @@ def test_kmeans_fast_assign_equals_the_exact_pass(built_lib):
             for a, b in zip(got[0], got[1]):
                 assert np.array_equal(a, b), (K, np.max(np.abs(a - b)))
     assert _lib.kmeans_fast_stats()[1] > 0            # some points did go through the exact pass (the repeated rows)
+
+
+@pytest.mark.parametrize("cfg", ["configs[1]", "configs[2]"])
+def test_per_frame_ll_from_pcm_end_to_end(built_lib, oracle_built, cfg):
+    """north_star's criterion on identical INPUTS: int16 PCM -> (device: MFCC -> CMVN -> deltas -> GMM) per-frame log-likelihoods
+    against (float64 restatement of MFCC.py:49-79 + utils.py:24-31, never rounded to float32) -> the reference's scoring
+    arithmetic (gmm.cc:237-244 via oracle mode FAST): |d| <= 1e-4 max(1, |LL|) per frame, identical clamp decisions, per-utterance
+    sums and argmax.  52 utterances of the configs' own audio (SURVEY.md 8d speakers, seed 2000 + u), 3 s each;
+    configs[1]: 100 models x 64 mixtures (a strided 20 of them checked per frame), configs[2]: 512-mixture UBM + 9 MAP speakers."""
+    import bench
+    from oracle import mfcc_oracle as mo
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    if cfg == "configs[1]":
+        raw = [synth.synth_gmm(bench.CFG1_MIX, bench.DIM, bench.MODEL_SEED + s) for s in range(bench.CFG1_MODELS)]
+        check = list(range(0, bench.CFG1_MODELS, 5))
+    else:
+        ubm = synth.synth_gmm(bench.CFG2_MIX, bench.DIM, 99)
+        raw = [ubm] + [synth.synth_map_speaker(ubm, 500 + s) for s in range(9)]
+        check = list(range(len(raw)))
+    ms = ModelSet([GMM.from_arrays(*m) for m in raw])
+    n_utt = 52
+    pcm = [synth.synth_speech(u % 100, 3.0, bench.FS, seed=bench.AUDIO_SEED + u) for u in range(n_utt)]
+    ex = MfccExtractor(bench.FS, **bench.MFCC_KW)
+    fb = ex.extract_batch(Batch.from_pcm(pcm), nd=bench.ND)
+    sums, arg, fll = ms.score(fb, frame_ll=True)
+    off = fb.offsets()
+    X64 = np.concatenate([mo.extract(bench.FS, p, diff=True, nd=bench.ND, **bench.MFCC_KW) for p in pcm])
+    assert len(X64) == off[-1] and X64.dtype == np.float64
+    worst = 0.0
+    want = np.zeros((n_utt, len(check)))
+    for j, s in enumerate(check):
+        ll = go.score_batch(go.GMMParams(*[np.asarray(a, dtype=np.float64) for a in raw[s]]), X64, go.MODE_FAST)
+        d = fll[s].astype(np.float64)
+        worst = max(worst, float(np.max(np.abs(d - ll) / np.maximum(1.0, np.abs(ll)))))
+        assert np.array_equal(fll[s] == np.float32(go.LN_1E_15), ll == go.LN_1E_15)
+        want[:, j] = [ll[off[u]:off[u + 1]].sum() for u in range(n_utt)]
+    assert worst <= 1e-4, worst                               # the gate
+    assert worst <= 2e-5, worst                               # what the float64 feature stage leaves (measured ~3e-6)
+    got = sums[:, check]
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-5
+    assert np.array_equal(np.argmax(got, axis=1), np.argmax(want, axis=1))
