@@ -75,8 +75,9 @@ def spawn_ranks(args):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    nonce = os.urandom(8).hex()                               # the job's own rendezvous name (two launches of one user never meet)
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, SR_RDZV_NONCE=nonce, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         out = None if r == 0 else subprocess.DEVNULL          # rank 0 prints the JSON line
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
@@ -607,6 +608,107 @@ def block_point256(_lib, hbm, preq):
             "parity": None}
 
 
+def block_vector_alu(_lib, hbm):
+    """north_star's LITERAL path -- no matrix cores: the vector-ALU engine (`score_engine` 1: gmm_score_kernel<D,F,PK>, mixture
+    parameters staged in LDS, wavefront log-sum-exp) at the 256 x 39 point and on configs[1]'s shape, beside the matrix-core engines
+    that the dispatcher picks: frames/s, fraction of the fp32 vector peak, achieved HBM GB/s and its fraction."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    out = {}
+    shapes = (("256x39", [synth.synth_gmm(256, DIM, 77)], 2000), ("configs[1]", [synth.synth_gmm(CFG1_MIX, DIM, MODEL_SEED + s) for s in range(CFG1_MODELS)], 1000))
+    for name, raw, n_utt in shapes:
+        ms = ModelSet([GMM.from_arrays(*m) for m in raw])
+        utts = [synth.draw_frames(raw[u % len(raw)], 1000, 100 + u, outlier_frac=0.001) for u in range(50)]
+        feats = Batch.from_features([utts[u % 50] for u in range(n_utt)])
+        n, S, K = n_utt * 1000, len(raw), len(raw[0][0])
+        row = {"frames": n, "models": S, "mixtures": K}
+        want = None
+        for label, eng in (("vector_alu", 1), ("auto", 0)):
+            _lib.set_option("score_engine", eng)
+            try:
+                ms.score(feats)
+                _lib.profile_reset()
+                el, (sums, arg) = timed(lambda: ms.score(feats), 0, 3, _lib.synchronize)
+                t_ms, n_k = _lib.profile_get(_lib.T_SCORE)
+                avg = t_ms / max(1, n_k) * 1e-3
+                flops = float(n) * S * K * (4 * DIM + 6)
+                byts = float(n) * 4 * DIM
+                row[label] = {"kernel": _lib.last_score_kernel()[:64], "kernel_ms": 1e3 * avg, "frames_per_s": n / avg,
+                              "algorithmic_tflops": flops / avg / 1e12, "frac_fp32_valu_peak": flops / avg / 1e12 / FP32_PEAK_TFLOPS,
+                              "hbm_GBps": byts / avg / 1e9, "hbm_frac_of_8TBps": byts / avg / 1e9 / HBM_PEAK_GBS}
+                if want is None:
+                    want = sums
+                else:
+                    row["engines_max_rel_sum_diff"] = float(np.max(np.abs(sums - want) / np.maximum(1.0, np.abs(want))))
+            finally:
+                _lib.set_option("score_engine", 0)
+        out[name] = row
+    out["note"] = ("BASELINE.json north_star asks for this path (LDS-staged parameters, wavefront log-sum-exp, no MFMA) and for >= 60 % of the HBM "
+                   "roofline at 256 x 39: the point has 40 kflop per 156-byte frame, so at 100 % of the fp32 vector peak (157.3 TFLOP/s) it moves "
+                   "613 GB/s = 7.7 % of HBM; the active bound is the ALU, and the matrix-core engines exist because of it")
+    return out
+
+
+def block_cfg2_from_host(_lib, gm, cat, off, sums_resident, arg_resident):
+    """The headline's step with the PCM handed over in HOST memory on every call (what the C-ABI boundary does for a caller that owns
+    its audio): sr_multi_predict_pcm on one slot, page-locked caller memory, uploads in pieces overlapped with the kernels."""
+    from speaker_recognition_amd.core import MultiPredictor
+    _lib.host_register(cat)
+    try:
+        mp_ = MultiPredictor(gm, FS, n_slots=1, **MFCC_KW)
+        f = lambda: mp_.predict_concat(cat, off, nd=ND)
+        f()
+        el, (s2, a2) = timed(f, 0, 3)
+        del mp_
+    finally:
+        _lib.host_unregister(cat)
+    return {"workload": "configs[2] headline step from page-locked HOST PCM (%.2f GB per call), one slot" % (cat.nbytes / 1e9),
+            "ms_per_step": 1e3 * el / 3, "pcie_floor_ms": cat.nbytes / 55e9 * 1e3,
+            "argmax_equal_resident": bool(np.array_equal(a2, arg_resident)), "sums_bit_identical_resident": bool(np.array_equal(s2, sums_resident))}
+
+
+def block_cfg0(_lib):
+    """BASELINE configs[0] end to end (src/speaker-recognition.py:52-90): 10 speakers x 30 s synthetic 16 kHz WAV each for enrolment and
+    for prediction, 25/10 ms frames, 13 MFCC, one 16-mixture diagonal GMM per speaker.  Device: this package's ModelInterface (WAV ->
+    MFCC kernels -> EM on the device -> fused scoring), timed here; CPU: oracle/cfg0_baseline.py in its own process on the same files."""
+    from scipy.io import wavfile
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.cli import read_wav
+    from speaker_recognition_amd.interface import ModelInterface
+    kw, K, spk = dict(win_length_ms=25, win_shift_ms=10), 16, [3 * i for i in range(10)]
+    tmp = tempfile.mkdtemp()
+    enroll, test = [], []
+    for sp in spk:
+        e, t = os.path.join(tmp, "enroll_%d.wav" % sp), os.path.join(tmp, "test_%d.wav" % sp)
+        wavfile.write(e, FS, synth.synth_speech(sp, 30.0, FS, seed=1000 + sp))
+        wavfile.write(t, FS, synth.synth_speech(sp, 30.0, FS, seed=2000 + sp))
+        enroll.append((str(sp), e))
+        test.append((str(sp), t))
+    m = ModelInterface(gmm_order=K, feature_kwargs=kw, lpc=False, gmm_kwargs={"seed": 1}, verbose=False)
+    m.enroll("warm", *read_wav(enroll[0][1]))         # code objects + workspaces, not timed
+    m.train()
+    m = ModelInterface(gmm_order=K, feature_kwargs=kw, lpc=False, gmm_kwargs={"seed": 1}, verbose=False)
+    t0 = time.perf_counter()
+    for label, f in enroll:
+        m.enroll(label, *read_wav(f))
+    t1 = time.perf_counter()
+    m.train()
+    t2 = time.perf_counter()
+    pred = m.predict_many([read_wav(f) for _, f in test])
+    t3 = time.perf_counter()
+    dev = {"enroll_features_s": t1 - t0, "train_s": t2 - t1, "predict_s": t3 - t2, "total_s": t3 - t0,
+           "correct": int(sum(p == l for p, (l, _) in zip(pred, test))), "of": len(test)}
+    cpu = None
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cfg0_baseline.py"), tmp], capture_output=True, text=True, timeout=400)
+        cpu = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+    return {"workload": "BASELINE configs[0]: 10 x 30 s enrol + 10 x 30 s predict, 16 kHz WAV files, 25/10 ms, 13 MFCC, 16 mixtures per speaker",
+            "device": dev, "cpu": cpu, "speedup_total": (cpu["total_s"] / dev["total_s"]) if cpu and "total_s" in cpu else None}
+
+
 def block_stream(_lib):
     """configs[4]: 1 s windows of 8 kHz audio -> (LTSD VAD ->) MFCC -> 256-mixture speaker set -> decision;
     host-observed latency per window, H2D and D2H included."""
@@ -1086,7 +1188,9 @@ def main():
         except Exception as e:
             result["parity"]["headline_sample_error"] = "%s: %s" % (type(e).__name__, e)
         del pcm
-        for name, fn in (("serving_small_batch", lambda: block_serving_small(_lib, ex, base, ms, S, CFG2_MIX, hbm)),
+        sums_res, arg_res = sums.copy(), arg.copy()
+        for name, fn in (("configs[2]_from_host_pcm", lambda: block_cfg2_from_host(_lib, models, cat, off, sums_res, arg_res)),
+                         ("serving_small_batch", lambda: block_serving_small(_lib, ex, base, ms, S, CFG2_MIX, hbm)),
                          ("configs[1]", lambda: block_cfg1(_lib, ex, base, hbm, preq)),
                          ("configs[3]_rank_shard", lambda: block_cfg3(_lib, hbm, preq, total_frames=args.cfg3_total_frames)),
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
@@ -1094,7 +1198,9 @@ def main():
                          ("reference_published_em", lambda: block_published_em(_lib)),
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
                          ("sr_multi_predict_pcm_host_pcm", lambda: block_multi_slot(_lib, ex, base)),
-                         ("north_star_256x39", lambda: block_point256(_lib, hbm, preq))):
+                         ("north_star_256x39", lambda: block_point256(_lib, hbm, preq)),
+                         ("north_star_literal_vector_alu", lambda: block_vector_alu(_lib, hbm)),
+                         ("configs[0]_end_to_end", lambda: block_cfg0(_lib))):
             if os.environ.get("SR_BENCH_BLOCKS") and name not in os.environ["SR_BENCH_BLOCKS"].split(","):
                 continue                                    # (experiments: a chosen subset of the blocks)
             try:
@@ -1132,6 +1238,8 @@ def main():
         except Exception as e:
             blocks["parity_error"] = "%s: %s" % (type(e).__name__, e)
         result["configs"] = blocks
+        if isinstance(blocks.get("configs[2]_from_host_pcm"), dict):
+            result["from_host_pcm_ms_per_step"] = blocks["configs[2]_from_host_pcm"].get("ms_per_step")
     emit(result, args.blocks_out)
     if grp is not None:
         grp.barrier()

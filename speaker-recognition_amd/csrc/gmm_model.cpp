@@ -701,8 +701,17 @@ void put_flat_row(uint16_t *img, int ksteps, int i, const std::vector<uint16_t> 
 
 }  // namespace
 
+// Experiment switch (sr_set_option "h2s_slot_order", read when a set is packed): where the three part products of a dimension sit in
+// the flat contraction.  0 = three runs [lo x hi | hi x lo | hi x hi] (the low-part slots, whose bits toggle like noise, together);
+// 1 = interleaved per dimension [lo x hi, hi x lo, hi x hi] x D.  Same arithmetic, another summation order inside the MFMA chain.
+int &h2s_slot_order_option() {
+    static int v = 0;
+    return v;
+}
+
 PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     PackedH2Shared pm;
+    const bool inter = h2s_slot_order_option() == 1;
     const GMM &g0 = *models[0];
     const int dim = g0.dim, K = g0.nr_mixtures;
     const int S = (int)models.size();
@@ -741,16 +750,20 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     // slot tables (frame side)
     pm.q_desc.assign((size_t)pm.kqf * 16, 0);
     pm.l_desc.assign((size_t)pm.klf * 16, 0);
+    // slot of part product `part` (0 lo x hi, 1 hi x lo, 2 hi x hi) of dimension d; the constant's two slots
+    auto qpos = [&](int part, int d) { return inter ? 3 * d + part : part * dim + d; };
+    auto lpos = [&](int part, int d) { return inter ? 3 * d + part : (part == 0 ? d : part == 1 ? (dim + 1) + d : (2 * dim + 1) + d); };
+    const int c_lo = inter ? 3 * dim : dim, c_hi = 3 * dim + 1;
     for (int d = 0; d < dim; d++) {
-        pm.q_desc[d] = (uint16_t)(d | (1 << 8));                    // lo(A2) x hi(z^2)
-        pm.q_desc[dim + d] = (uint16_t)(d | (2 << 8));              // hi(A2) x lo(z^2)
-        pm.q_desc[2 * dim + d] = (uint16_t)(d | (1 << 8));          // hi(A2) x hi(z^2)
-        pm.l_desc[d] = (uint16_t)(d | (1 << 8));                    // lo(A1) x hi(z)
-        pm.l_desc[(dim + 1) + d] = (uint16_t)(d | (2 << 8));        // hi(A1) x lo(z)
-        pm.l_desc[(2 * dim + 1) + d] = (uint16_t)(d | (1 << 8));    // hi(A1) x hi(z)
+        pm.q_desc[qpos(0, d)] = (uint16_t)(d | (1 << 8));           // lo(A2) x hi(z^2)
+        pm.q_desc[qpos(1, d)] = (uint16_t)(d | (2 << 8));           // hi(A2) x lo(z^2)
+        pm.q_desc[qpos(2, d)] = (uint16_t)(d | (1 << 8));           // hi(A2) x hi(z^2)
+        pm.l_desc[lpos(0, d)] = (uint16_t)(d | (1 << 8));           // lo(A1) x hi(z)
+        pm.l_desc[lpos(1, d)] = (uint16_t)(d | (2 << 8));           // hi(A1) x lo(z)
+        pm.l_desc[lpos(2, d)] = (uint16_t)(d | (1 << 8));           // hi(A1) x hi(z)
     }
-    pm.l_desc[dim] = (uint16_t)(3 << 8);                            // lo(C) x 1
-    pm.l_desc[3 * dim + 1] = (uint16_t)(3 << 8);                    // hi(C) x 1
+    pm.l_desc[c_lo] = (uint16_t)(3 << 8);                           // lo(C) x 1
+    pm.l_desc[c_hi] = (uint16_t)(3 << 8);                           // hi(C) x 1
     const int n_blocks = (S + SHARED_SB - 1) / SHARED_SB;
     const size_t block_u16 = (size_t)pm.n_tiles * (1 + SHARED_SB) * img_u16;
     pm.params.assign((size_t)n_blocks * block_u16, 0);
@@ -770,9 +783,9 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                         pm.coef_max = std::max(pm.coef_max, (double)std::fabs(a2));
                         uint16_t parts[2];
                         split_f16x2(a2, parts);
-                        slots[d] = parts[1];
-                        slots[dim + d] = parts[0];
-                        slots[2 * dim + d] = parts[0];
+                        slots[qpos(0, d)] = parts[1];
+                        slots[qpos(1, d)] = parts[0];
+                        slots[qpos(2, d)] = parts[0];
                     }
                 }
                 put_flat_row(qimg.data() + (size_t)t * img_u16, pm.kqf, i, slots);
@@ -825,9 +838,9 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                             coef_l = std::max(coef_l, (double)std::fabs(a1));
                             uint16_t parts[2];
                             split_f16x2(a1, parts);
-                            slots[d] = parts[1];
-                            slots[(dim + 1) + d] = parts[0];
-                            slots[(2 * dim + 1) + d] = parts[0];
+                            slots[lpos(0, d)] = parts[1];
+                            slots[lpos(1, d)] = parts[0];
+                            slots[lpos(2, d)] = parts[0];
                             cst -= lsg[(size_t)k * dim + d] + 0.5 * mu * mu * iv;
                             a += mu * mu * iv;
                         }
@@ -842,8 +855,8 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
                     }
                     uint16_t parts[2];
                     split_f16x2(cst_f, parts);
-                    slots[dim] = parts[1];
-                    slots[3 * dim + 1] = parts[0];
+                    slots[c_lo] = parts[1];
+                    slots[c_hi] = parts[0];
                     put_flat_row(lt, pm.klf, i, slots);
                 }
             }

@@ -5,18 +5,23 @@ The data path of this package never crosses GPUs (utterances shard, models are r
 exchange is a barrier around a timed region, the slowest rank's time and 4 bytes per utterance -- what the reference's
 ``multiprocessing.Pool`` hands back to its parent (src/test/test-gmm.py:128-133).  That needs no tensor library: rank 0
 listens on an abstract Unix-domain socket named after the job (MASTER_PORT and, under torch.distributed.run,
-TORCHELASTIC_RUN_ID -- the launcher's own store keeps MASTER_PORT itself), the others connect, and every collective is one
-length-prefixed pickle per rank to rank 0 and the gathered list back.
+TORCHELASTIC_RUN_ID or SR_RDZV_NONCE -- the launcher's own store keeps MASTER_PORT itself), the others connect, and every
+collective is one length-prefixed message per rank to rank 0 and the gathered list back.  Messages are JSON + raw array bytes
+(nothing is unpickled), both ends check the peer's uid (SO_PEERCRED), and rank 0 seats only ranks 1..N-1 of its own world size.
 
 ``init(backend="socket" | "gloo")``: "gloo" keeps the round-1..3 path (torch.distributed over gloo) for those who want it;
-the default imports nothing but the standard library."""
+the default imports the standard library and numpy only."""
 from __future__ import annotations
 
+import json
 import os
-import pickle
 import socket
 import struct
 import time
+
+import numpy as np
+
+MAX_MESSAGE = 1 << 30          # bytes; a gather of per-utterance sums of a very large job stays far below
 
 
 def rank_env():
@@ -25,18 +30,70 @@ def rank_env():
 
 
 def _job_key() -> str:
-    return "sr-rdzv-%s-%s-%d" % (os.environ.get("MASTER_PORT", "29512"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getuid())
+    """One name per job and user: MASTER_PORT, the launcher's run id (torch.distributed.run) or this package's own nonce
+    (SR_RDZV_NONCE: bench.py's spawner draws one per launch, so two jobs of one user on the default port do not meet), uid."""
+    run = os.environ.get("SR_RDZV_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    return "sr-rdzv-%s-%s-%d" % (os.environ.get("MASTER_PORT", "29512"), run, os.getuid())
+
+
+# ---- wire format: no pickle.  A message is JSON (None / bool / int / float / str / list / dict with string keys) in which every
+# numpy array is a placeholder {"__nd__": i, "dtype": ..., "shape": [...]} whose bytes follow the JSON text; tuples travel as lists.
+_DTYPES = {"b", "i", "u", "f"}
+
+
+def _encode(obj) -> bytes:
+    blobs = []
+
+    def walk(o):
+        if isinstance(o, np.ndarray):
+            if o.dtype.kind not in _DTYPES:
+                raise TypeError("rendezvous: arrays of dtype %s do not travel" % o.dtype)
+            blobs.append(np.ascontiguousarray(o).tobytes())
+            return {"__nd__": len(blobs) - 1, "dtype": o.dtype.str, "shape": list(o.shape)}
+        if isinstance(o, np.generic):
+            return o.item()
+        if isinstance(o, (list, tuple)):
+            return [walk(v) for v in o]
+        if isinstance(o, dict):
+            return {str(k): walk(v) for k, v in o.items()}
+        if o is None or isinstance(o, (bool, int, float, str)):
+            return o
+        raise TypeError("rendezvous: objects of type %s do not travel" % type(o).__name__)
+    head = json.dumps({"v": walk(obj), "blobs": [len(b) for b in blobs]}).encode()
+    return struct.pack("<I", len(head)) + head + b"".join(blobs)
+
+
+def _decode(data: bytes):
+    (hl,) = struct.unpack_from("<I", data, 0)
+    head = json.loads(data[4:4 + hl].decode())
+    pos, blobs = 4 + hl, []
+    for n in head["blobs"]:
+        blobs.append(data[pos:pos + n])
+        pos += n
+
+    def walk(o):
+        if isinstance(o, dict):
+            if "__nd__" in o:
+                dt = np.dtype(o["dtype"])
+                if dt.kind not in _DTYPES:
+                    raise ValueError("rendezvous: refused dtype %s" % o["dtype"])
+                return np.frombuffer(blobs[int(o["__nd__"])], dtype=dt).reshape(o["shape"]).copy()
+            return {k: walk(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [walk(v) for v in o]
+        return o
+    return walk(head["v"])
 
 
 def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    data = _encode(obj)
     sock.sendall(struct.pack("<Q", len(data)) + data)
 
 
 def _recv_exact(sock, n):
     buf = bytearray()
     while len(buf) < n:
-        chunk = sock.recv(n - len(buf))
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
         if not chunk:
             raise ConnectionError("rendezvous: a rank closed its connection (did it die?)")
         buf += chunk
@@ -45,7 +102,15 @@ def _recv_exact(sock, n):
 
 def _recv(sock):
     (n,) = struct.unpack("<Q", _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > MAX_MESSAGE:
+        raise ConnectionError("rendezvous: a %d-byte message was announced (limit %d)" % (n, MAX_MESSAGE))
+    return _decode(_recv_exact(sock, n))
+
+
+def _peer_is_me(sock) -> bool:
+    """An abstract socket name carries no permissions: anybody on the host may bind or connect to it.  The kernel tells who did."""
+    pid, uid, gid = struct.unpack("3i", sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i")))
+    return uid == os.getuid()
 
 
 class SocketGroup:
@@ -67,8 +132,17 @@ class SocketGroup:
             while len(conns) < world - 1:
                 c, _ = srv.accept()
                 c.settimeout(timeout)
-                r = _recv(c)
-                conns[int(r)] = c
+                try:
+                    if not _peer_is_me(c):
+                        raise ConnectionError("another user's process")
+                    hello = _recv(c)
+                    r = int(hello["rank"])
+                    if hello.get("world") != world or not 1 <= r < world or r in conns:
+                        raise ConnectionError("not a rank of this job: %r" % (hello,))
+                except Exception:
+                    c.close()                      # a stranger, a stray rank of another job, a duplicate: no slot for it
+                    continue
+                conns[r] = c
             srv.close()
             self._peers = [conns[r] for r in range(1, world)]
         else:
@@ -84,7 +158,10 @@ class SocketGroup:
                         raise TimeoutError("rendezvous: rank 0 never opened %r" % name[1:])
                     time.sleep(0.01)
             c.settimeout(timeout)
-            _send(c, rank)
+            if not _peer_is_me(c):
+                c.close()
+                raise ConnectionError("rendezvous: %r is held by another user's process" % name[1:])
+            _send(c, {"rank": rank, "world": world})
             self._hub = c
 
     # every collective is an all-gather of one object per rank

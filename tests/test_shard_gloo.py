@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -101,3 +102,59 @@ def test_socket_group_collectives():
     for p in procs:
         p.join(30)
     assert [r[1] for r in res] == [[0, 1, 2, 3]] * 4 and all(r[2] == 13.0 for r in res)
+
+
+def test_rendezvous_wire_format_carries_no_pickle():
+    """What the ranks exchange -- None, numbers, dicts of them, (index, argmax, sums) array triples -- survives the JSON + raw-bytes
+    encoding bit for bit; anything else is refused at the sender, and no byte of a message is ever unpickled."""
+    import inspect
+    from speaker_recognition_amd import rendezvous as rv
+    assert "pickle" not in inspect.getsource(rv).replace("unpickled", "").replace("no pickle", "")
+    rng = np.random.default_rng(0)
+    msg = [None, 1.5, {"rate": 3.25e7, "device": 2, "ok": True, "numa_node": -1},
+           (np.arange(5, dtype=np.int64), rng.integers(0, 9, 5).astype(np.int32), rng.standard_normal((5, 3))), np.float64(2.0)]
+    back = rv._decode(rv._encode(msg))
+    assert back[0] is None and back[1] == 1.5 and back[2] == msg[2] and back[4] == 2.0
+    for a, b in zip(msg[3], back[3]):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    with pytest.raises(TypeError):
+        rv._encode({"f": lambda: 0})
+    with pytest.raises(TypeError):
+        rv._encode(np.array(["a"], dtype=object))
+
+
+def _stray_then_real(key, q):
+    """a process that is not a rank of the job (wrong world size, then a rank out of range) knocks first"""
+    sys.path.insert(0, ROOT)
+    import socket
+    import time
+    from speaker_recognition_amd import rendezvous as rv
+    for hello in ({"rank": 1, "world": 7}, {"rank": 5, "world": 2}, "garbage"):
+        while True:
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            try:
+                c.connect("\0" + key)
+                break
+            except (ConnectionRefusedError, FileNotFoundError):
+                c.close()
+                time.sleep(0.01)
+        rv._send(c, hello)
+        c.close()
+    g = rv.SocketGroup(1, 2, key=key, timeout=60)
+    q.put(g.all_gather("one"))
+    g.close()
+
+
+def test_rank0_seats_only_ranks_of_its_own_job():
+    import multiprocessing as mp
+    from speaker_recognition_amd.rendezvous import SocketGroup
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = "sr-test-stray-%d" % os.getpid()
+    p = ctx.Process(target=_stray_then_real, args=(key, q))
+    p.start()
+    g = SocketGroup(0, 2, key=key, timeout=60)
+    assert g.all_gather("zero") == ["zero", "one"]
+    assert q.get(timeout=60) == ["zero", "one"]
+    g.close()
+    p.join(30)
