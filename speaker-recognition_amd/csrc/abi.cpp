@@ -32,7 +32,6 @@ std::atomic<int> &multi_pieces_option();                // multi.cpp
 std::atomic<int> &multi_merge_option();
 namespace sr {
 int &h2s_group_major_option();                          // gmm_score_h2_shared.hip
-int &h2s_slot_order_option();                           // gmm_model.cpp
 }
 namespace sr {
 void kmeans_fast_stats(long *passes, long *rechecked);
@@ -782,9 +781,6 @@ int sr_set_option(const char *key, long value) {
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
-    } else if (k == "h2s_slot_order") {
-        if (value != 0 && value != 1) fail("h2s_slot_order must be 0 (three runs of part products) or 1 (interleaved per dimension); read when a set is packed");
-        sr::h2s_slot_order_option() = (int)value;
     } else if (k == "score_h2s_group_major") {
         sr::h2s_group_major_option() = value != 0;
     } else if (k == "multi_merge_same_device") {

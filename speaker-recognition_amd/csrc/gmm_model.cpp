@@ -701,17 +701,8 @@ void put_flat_row(uint16_t *img, int ksteps, int i, const std::vector<uint16_t> 
 
 }  // namespace
 
-// Experiment switch (sr_set_option "h2s_slot_order", read when a set is packed): where the three part products of a dimension sit in
-// the flat contraction.  0 = three runs [lo x hi | hi x lo | hi x hi] (the low-part slots, whose bits toggle like noise, together);
-// 1 = interleaved per dimension [lo x hi, hi x lo, hi x hi] x D.  Same arithmetic, another summation order inside the MFMA chain.
-int &h2s_slot_order_option() {
-    static int v = 0;
-    return v;
-}
-
 PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     PackedH2Shared pm;
-    const bool inter = h2s_slot_order_option() == 1;
     const GMM &g0 = *models[0];
     const int dim = g0.dim, K = g0.nr_mixtures;
     const int S = (int)models.size();
@@ -751,9 +742,10 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     pm.q_desc.assign((size_t)pm.kqf * 16, 0);
     pm.l_desc.assign((size_t)pm.klf * 16, 0);
     // slot of part product `part` (0 lo x hi, 1 hi x lo, 2 hi x hi) of dimension d; the constant's two slots
-    auto qpos = [&](int part, int d) { return inter ? 3 * d + part : part * dim + d; };
-    auto lpos = [&](int part, int d) { return inter ? 3 * d + part : (part == 0 ? d : part == 1 ? (dim + 1) + d : (2 * dim + 1) + d); };
-    const int c_lo = inter ? 3 * dim : dim, c_hi = 3 * dim + 1;
+    // (three runs; interleaving the parts per dimension instead changes nothing: profiles/r05_slot_order_ab.txt)
+    auto qpos = [&](int part, int d) { return part * dim + d; };
+    auto lpos = [&](int part, int d) { return part == 0 ? d : part == 1 ? (dim + 1) + d : (2 * dim + 1) + d; };
+    const int c_lo = dim, c_hi = 3 * dim + 1;
     for (int d = 0; d < dim; d++) {
         pm.q_desc[qpos(0, d)] = (uint16_t)(d | (1 << 8));           // lo(A2) x hi(z^2)
         pm.q_desc[qpos(1, d)] = (uint16_t)(d | (2 << 8));           // hi(A2) x lo(z^2)
