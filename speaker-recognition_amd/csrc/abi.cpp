@@ -785,6 +785,9 @@ int sr_set_option(const char *key, long value) {
         sr::h2s_group_major_option() = value != 0;
     } else if (k == "multi_merge_same_device") {
         multi_merge_option().store(value != 0);
+    } else if (k == "multi_numa_bind") {
+        if (value != 0 && value != 1) fail("multi_numa_bind must be 0 or 1");
+        numa_bind_option().store((int)value);
     } else if (k == "multi_pieces") {
         if (value < 0 || value > 8) fail("multi_pieces must be 0 (automatic) .. 8");
         multi_pieces_option().store((int)value);

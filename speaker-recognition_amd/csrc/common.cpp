@@ -1,6 +1,9 @@
 // common.cpp -- error parking, lazy device context, HIP-event kernel timers.
 #include "common.hpp"
 
+#include <climits>
+#include <mutex>
+
 #include <mutex>
 #include <new>
 
@@ -70,6 +73,7 @@ void reference_rand_fork_child();       // kmeans_init.hip
 // ---- fork (common.hpp) ----
 static std::atomic<long> g_runtime_pid{0};       // the process that made the first HIP call (0: none yet)
 static std::atomic<bool> g_runtime_lost{false};
+void fork_proxy_atfork_child();       // fork_proxy.cpp
 static std::atomic<bool> g_atfork_installed{false};
 
 static void atfork_child() {
@@ -79,6 +83,7 @@ static void atfork_child() {
     new (&g_slot_mu) std::mutex();
     for (int i = 0; i < MAX_DEVICES; i++) new (&g_api_mutex[i]) std::recursive_mutex();
     reference_rand_fork_child();
+    fork_proxy_atfork_child();
     if (g_runtime_pid.load() != 0) g_runtime_lost.store(true);
 }
 
@@ -158,10 +163,12 @@ static bool read_small_file(const std::string &path, char *buf, size_t cap) {
 }
 
 int device_numa_node(int device) {
-    static int cache[MAX_DEVICES];
-    static bool have[MAX_DEVICES];
+    // (slot threads of sr_multi ask concurrently: one atomic per device, "unknown yet" = INT_MIN; a race computes the same value twice)
+    static std::atomic<int> cache[MAX_DEVICES];
+    static std::once_flag init;
+    std::call_once(init, [] { for (auto &c : cache) c.store(INT_MIN); });
     check_device_index(device);
-    if (have[device]) return cache[device];
+    if (cache[device].load() != INT_MIN) return cache[device].load();
     int node = -1;
     if (!gpu_runtime_lost()) {
         note_gpu_runtime_use();
@@ -174,9 +181,13 @@ int device_numa_node(int device) {
             (void)hipGetLastError();
         }
     }
-    cache[device] = node;
-    have[device] = true;
+    cache[device].store(node);
     return node;
+}
+
+std::atomic<int> &numa_bind_option() {      // sr_set_option("multi_numa_bind", 0 | 1)
+    static std::atomic<int> v{1};
+    return v;
 }
 
 int bind_thread_near_device(int device) {
@@ -197,7 +208,15 @@ int bind_thread_near_device(int device) {
                 n_set++;
             }
     }
-    if (n_set == 0 || sched_setaffinity(0, sizeof set, &set) != 0) return -1;
+    // never WIDEN what the thread may use: a taskset, a launcher's per-rank pinning or a cgroup cpuset stays in force, and a mask
+    // that shares no CPU with the node is left alone (sched_setaffinity would fail with EINVAL on an empty intersection)
+    cpu_set_t have;
+    CPU_ZERO(&have);
+    if (n_set == 0 || sched_getaffinity(0, sizeof have, &have) != 0) return -1;
+    CPU_AND(&set, &set, &have);
+    if (CPU_COUNT(&set) == 0) return -1;
+    if (CPU_EQUAL(&set, &have)) return node;               // already there
+    if (sched_setaffinity(0, sizeof set, &set) != 0) return -1;
     return node;
 }
 

@@ -83,7 +83,8 @@ struct Ctx {
 // does not say; bind_thread_near_device: pins the CALLING thread to that node's cores (sched_setaffinity) and returns the node
 // (-1: left alone).  Used by the slot threads of sr_multi_* and, through sr_bind_thread_near_device, by bench.py's ranks.
 int device_numa_node(int device);
-int bind_thread_near_device(int device);
+int bind_thread_near_device(int device);    // (intersected with the thread's current mask: never widens it)
+std::atomic<int> &numa_bind_option();        // sr_set_option("multi_numa_bind", 0 | 1): sr_multi slot threads bind themselves (default 1)
 Ctx &ctx();             // of the calling thread's current device
 void ensure_device();   // hipSetDevice(current) for THIS thread + lazy stream; throws sr::Error when no usable GPU
 

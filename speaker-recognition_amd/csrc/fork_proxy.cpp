@@ -190,6 +190,10 @@ void get_params(Reader &r, GMM &g) {
     g.drop_single();
 }
 
+// what the helper answers when asked to use a model it has evicted (the conversation stays intact; the caller sends it again)
+constexpr char HELPER_MISS[] = "fork helper miss";
+constexpr size_t HELPER_MAX_MODELS = 64;       // models (host parameters + packed device set) the helper keeps, least recently used out
+
 // ---- the options set so far: a fresh helper starts from the library's defaults, the forked child did not ----
 std::vector<std::pair<std::string, long>> &option_log() {
     static auto *v = new std::vector<std::pair<std::string, long>>();
@@ -202,11 +206,16 @@ struct Helper {
     pid_t pid = -1;
     int fd = -1;
     std::unordered_map<uint64_t, uint64_t> sent;      // handle -> hash of the parameters the helper holds for it
+    // one conversation at a time: the callers' api_mutex is per DEVICE, and two threads of a forked child on two devices would
+    // interleave their frames on the one socket.  (A pointer: a grandchild gets a fresh one, see start_helper.)
+    std::mutex *mu = new std::mutex();
 };
 Helper &helper() {
     static Helper *h = new Helper();
     return *h;
 }
+
+std::mutex *helper_mutex(Helper &h) { return h.mu; }
 
 std::string helper_path() {
     if (const char *e = getenv("SR_FORK_HELPER")) return e;
@@ -279,8 +288,10 @@ void start_helper(Helper &h) {
     } catch (...) {
         ::close(h.fd);
         h.fd = -1;
+        (void)::kill(pid, SIGTERM);
         int st = 0;
-        (void)::waitpid(pid, &st, WNOHANG);
+        (void)::waitpid(pid, &st, 0);
+        h.pid = -1;
         throw;
     }
 }
@@ -288,9 +299,11 @@ void start_helper(Helper &h) {
 void drop_helper(Helper &h) {
     if (h.fd >= 0) ::close(h.fd);
     h.fd = -1;
-    if (h.pid > 0) {
+    if (h.pid > 0 && h.owner_pid == (long)getpid()) {
+        // the helper leaves on end-of-file; it is told to as well in case it is stuck in a request, then reaped (no zombie)
+        (void)::kill(h.pid, SIGTERM);
         int st = 0;
-        (void)::waitpid(h.pid, &st, WNOHANG);
+        (void)::waitpid(h.pid, &st, 0);
     }
     h.pid = -1;
     h.sent.clear();
@@ -315,6 +328,9 @@ void put_model_tracked(Writer &w, Helper &h, const GMM &g, std::vector<std::pair
 
 // ---------------- client entry points (abi.cpp calls these when gpu_runtime_lost()) ----------------
 
+// pthread_atfork child handler (common.cpp): only the forking thread exists; whoever held the record's mutex does not
+void fork_proxy_atfork_child() { helper().mu = new std::mutex(); }
+
 void fork_proxy_note_option(const char *key, long value) {
     auto &log = option_log();
     bool known = false;
@@ -325,16 +341,24 @@ void fork_proxy_note_option(const char *key, long value) {
         }
     if (!known) log.emplace_back(key, value);
     Helper &h = helper();
-    if (gpu_runtime_lost() && h.fd >= 0 && h.owner_pid == (long)getpid()) {
-        Writer w;
-        w.pod<uint32_t>(MAGIC);
-        w.pod<uint32_t>(OP_OPTION);
-        w.str(key);
-        w.pod<int64_t>(value);
-        w.flush(h.fd);
-        Reader r;
-        r.fill(h.fd);
-        reply_status(r);
+    if (!gpu_runtime_lost()) return;
+    std::lock_guard<std::mutex> lock(*helper_mutex(h));
+    if (h.fd >= 0 && h.owner_pid == (long)getpid()) {
+        // the option IS set in this process (and logged for the next helper): a helper that died must not turn that into a failure
+        try {
+            Writer w;
+            w.pod<uint32_t>(MAGIC);
+            w.pod<uint32_t>(OP_OPTION);
+            w.str(key);
+            w.pod<int64_t>(value);
+            w.flush(h.fd);
+            Reader r;
+            r.fill(h.fd);
+            reply_status(r);
+        } catch (const Error &e) {
+            if (std::strncmp(e.what(), "fork helper:", 12) == 0) drop_helper(h);      // the next call starts a fresh one from the log
+            else throw;                                                             // the helper refused the value: the caller hears it
+        }
     }
 }
 
@@ -343,7 +367,9 @@ void fork_proxy_score(GMM *g, const float *X, long n, int dim, float *ll_out, do
     if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
     if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
     Helper &h = helper();
+    std::lock_guard<std::mutex> lock(*helper_mutex(h));
     start_helper(h);
+    for (int attempt = 0;; attempt++)
     try {
         std::vector<std::pair<uint64_t, uint64_t>> pending;
         Writer w;
@@ -362,7 +388,13 @@ void fork_proxy_score(GMM *g, const float *X, long n, int dim, float *ll_out, do
         const double sum = r.pod<double>();
         if (sum_out) *sum_out = sum;
         if (ll_out && n > 0) std::memcpy(ll_out, r.take((size_t)n * sizeof(float)), (size_t)n * sizeof(float));
+        return;
     } catch (const Error &e) {
+        // the helper keeps a bounded number of models: one it has evicted is sent again, once
+        if (attempt == 0 && std::strncmp(e.what(), HELPER_MISS, sizeof HELPER_MISS - 1) == 0) {
+            h.sent.erase((uint64_t)(uintptr_t)g);
+            continue;
+        }
         // an error raised BY the helper leaves the conversation intact; a broken conversation does not
         if (std::strncmp(e.what(), "fork helper:", 12) == 0) drop_helper(h);
         throw;
@@ -371,7 +403,9 @@ void fork_proxy_score(GMM *g, const float *X, long n, int dim, float *ll_out, do
 
 int fork_proxy_train(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param, long seed) {
     Helper &h = helper();
+    std::lock_guard<std::mutex> lock(*helper_mutex(h));
     start_helper(h);
+    for (int attempt = 0;; attempt++)
     try {
         std::vector<std::pair<uint64_t, uint64_t>> pending;
         Writer w;
@@ -399,6 +433,10 @@ int fork_proxy_train(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, 
         h.sent.erase((uint64_t)(uintptr_t)&gmm);
         return n_iter;
     } catch (const Error &e) {
+        if (attempt == 0 && ubm && std::strncmp(e.what(), HELPER_MISS, sizeof HELPER_MISS - 1) == 0) {
+            h.sent.erase((uint64_t)(uintptr_t)ubm);
+            continue;
+        }
         if (std::strncmp(e.what(), "fork helper:", 12) == 0) drop_helper(h);
         throw;
     }
@@ -412,10 +450,12 @@ using namespace sr;
 extern "C" int sr_fork_helper_main(int fd) {
     ::prctl(PR_SET_PDEATHSIG, SIGTERM);      // (and EOF on the socket: whichever comes first)
     struct Held {
-        uint64_t hash = 0;
+        uint64_t hash = 0, tick = 0;
         std::unique_ptr<GMM> g;
     };
     std::unordered_map<uint64_t, Held> models;
+    Held scratch;
+    uint64_t clock = 0;
     // a model off the wire -> the helper's copy of it (kept per caller handle; rebuilt when the contents changed)
     auto take_model = [&](Reader &r, bool keep) -> GMM * {
         const uint64_t key = r.pod<uint64_t>();
@@ -423,11 +463,14 @@ extern "C" int sr_fork_helper_main(int fd) {
         const int K = r.pod<int32_t>();
         const int D = r.pod<int32_t>();
         const int state = r.pod<uint8_t>();
-        Held &slot = models[keep ? key : ~key];
         if (state == 2) {
-            if (!slot.g || slot.hash != hash) fail("fork helper: the caller believes this helper holds a model it does not hold");
-            return slot.g.get();
+            const auto it = models.find(key);
+            if (it == models.end() || !it->second.g || it->second.hash != hash) fail("%s: model %llx", HELPER_MISS, (unsigned long long)key);
+            it->second.tick = ++clock;
+            return it->second.g.get();
         }
+        Held &slot = keep ? models[key] : scratch;       // a training target is single-use: it never enters the kept set
+        slot.tick = ++clock;
         slot.g = std::make_unique<GMM>();
         slot.hash = hash;
         slot.g->nr_mixtures = K;
@@ -521,6 +564,15 @@ extern "C" int sr_fork_helper_main(int fd) {
             w.flush(fd);
         } catch (const std::exception &) {
             return 0;
+        }
+        // training targets are single-use (scratch); the rest is a bounded least-recently-used set, so that a long-lived pool worker
+        // enrolling speaker after speaker does not grow this process (and its packed device sets) without bound
+        scratch = Held();
+        while (models.size() > HELPER_MAX_MODELS) {
+            auto oldest = models.begin();
+            for (auto it = models.begin(); it != models.end(); ++it)
+                if (it->second.tick < oldest->second.tick) oldest = it;
+            models.erase(oldest);
         }
     }
 }

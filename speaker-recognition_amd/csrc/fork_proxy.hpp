@@ -15,5 +15,7 @@ int fork_proxy_train(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, 
 // every successful sr_set_option is recorded (a helper starts from the library's defaults and is told) and, in a forked child with a
 // live helper, forwarded
 void fork_proxy_note_option(const char *key, long value);
+// pthread_atfork child handler: a fresh mutex for the helper record
+void fork_proxy_atfork_child();
 
 }  // namespace sr

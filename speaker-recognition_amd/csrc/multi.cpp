@@ -175,7 +175,8 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
     try {
         set_thread_device(s.device);
         ensure_device();
-        s.numa_node = bind_thread_near_device(s.device);       // this thread fills staging buffers and waits on this GPU's events
+        // this thread fills staging buffers and waits on this GPU's events: next to its PCIe root unless told not to
+        s.numa_node = numa_bind_option().load() ? bind_thread_near_device(s.device) : device_numa_node(s.device);
         const auto t0 = std::chrono::steady_clock::now();
         const int U = (int)s.utts.size();
         const int S = m->n_models;

@@ -172,3 +172,23 @@ def test_pool_before_first_compute_call_initialises_per_worker():
     ) % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def _many_models_task(_):
+    """one forked worker scores MORE models than its helper keeps (64), then the first ones again: the helper has evicted them,
+    says so, and the library sends them again (csrc/fork_proxy.cpp: HELPER_MAX_MODELS, "fork helper miss")"""
+    models, x = _STATE["many"], _STATE["utts"][0]
+    first = [m.score_all(x) for m in models]
+    again = [m.score_all(x) for m in models[:8]]
+    return first, again
+
+
+def test_forked_worker_with_more_models_than_its_helper_keeps(built_lib):
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.pygmm import GMM
+    models = [GMM.from_arrays(*synth.synth_gmm(4, 13, 900 + s)) for s in range(80)]
+    x = synth.draw_frames(synth.synth_gmm(4, 13, 900), 120, 5).astype(np.float64)
+    want = [m.score_all(x) for m in models]                 # parent: GPU runtime up before the fork
+    _STATE["many"], _STATE["utts"] = models, [x]
+    (first, again), = _run_pool(_many_models_task, [0], workers=1)
+    assert np.allclose(first, want, rtol=0, atol=0) and np.allclose(again, want[:8], rtol=0, atol=0)
