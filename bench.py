@@ -57,6 +57,7 @@ AUDIO_SEED, MODEL_SEED = 2000, 7
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA16_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak == fp32 dense MFMA peak
+FP64_PEAK_TFLOPS = 78.6        # fp64 vector peak
 MFCC_FLOPS_PER_FRAME = 2.5 * 2048 * 11 + 3 * 1025 + 2 * 1989 + 50 + 2 * 13 * 50     # ~64.7 kflop
 MFCC_BYTES_PER_FRAME = 2 * 160 + 4 * 13                                            # 372 B
 
@@ -181,7 +182,7 @@ def score_roofline(kname, n_frames, S, K, D, avg_s, hbm_measured):
     r = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak if peak else 0.0,
          "frac_algorithmic": ach / peak if peak else 0.0, "frac_executed_mfma": (ach * ratio / peak) if ratio else None,
          "note": note, "avg_launch_ms": 1e3 * avg_s,
-         # long grids of the shared-sigma kernel are cut into several launches per pass (DESIGN.md 2.1 point 4): rocprofv3's
+         # long grids of the shared-sigma kernel are cut into several launches per pass (HISTORY.md 2.1 point 4): rocprofv3's
          # per-call average is avg_launch_ms / launches_per_pass
          "launches_per_pass": int(kname.split("[")[1].split()[0]) if "launches per pass" in kname else 1,
          "traffic": None, "traffic_note": "not collected for this block (the headline's is: rocprofv3 --pmc passes of this script, separate runs)",
@@ -198,16 +199,18 @@ def score_roofline(kname, n_frames, S, K, D, avg_s, hbm_measured):
     return r
 
 
-def mfcc_roofline(n_raw_frames, avg_s, hbm_measured):
+def mfcc_roofline(n_raw_frames, avg_s, hbm_measured, precision=2):
     fl = MFCC_FLOPS_PER_FRAME * n_raw_frames
     by = MFCC_BYTES_PER_FRAME * n_raw_frames
-    return {"kernel": "mfcc_frames_fft2048_kernel", "bound": "valu (fp32 vector ALU: an FFT is not a contraction)",
-            "achieved": fl / avg_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / FP32_PEAK_TFLOPS,
+    peak = FP64_PEAK_TFLOPS if precision == 2 else FP32_PEAK_TFLOPS
+    return {"kernel": "mfcc_frames_fft2048_f64_kernel" if precision == 2 else "mfcc_frames_fft2048_kernel",
+            "bound": "valu (%s vector ALU: an FFT is not a contraction) + LDS exchanges" % ("fp64" if precision == 2 else "fp32"),
+            "achieved": fl / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": fl / avg_s / 1e12 / peak,
             "avg_launch_ms": 1e3 * avg_s, "flops_per_frame": MFCC_FLOPS_PER_FRAME, "bytes_per_frame": MFCC_BYTES_PER_FRAME,
             "hbm": {"achieved_GBps": by / avg_s / 1e9, "peak_GBps": HBM_PEAK_GBS, "frac": by / avg_s / 1e9 / HBM_PEAK_GBS,
                     "measured_copy_ceiling_GBps": hbm_measured},
-            "note": "1- and 2-flop butterflies on the vector ALU: issue-bound well below the FMA peak; see DESIGN.md 2.2 "
-                    "and profiles/ for the instruction-mix evidence"}
+            "note": "float64 spectrum, ln and DCT (mfcc_precision 2, the default): DESIGN.md 3.1, profiles/r05_mfcc_f64_notes.txt"
+                    if precision == 2 else "fp32 throughout (mfcc_precision 0): DESIGN.md 3.2"}
 
 
 # ------------------------------------------------------------------ HBM traffic of the dominant kernel (PMC)

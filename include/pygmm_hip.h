@@ -262,20 +262,19 @@ int sr_profile_enable(int on);
 int sr_profile_reset(void);
 int sr_profile_get(int kind, double *total_ms, long *launches);
 
-/* Tunables (kernel variant selection for A/B runs); value 0 = automatic:
- *   "score_engine" 1 vector ALU | 2 fp32 matrix cores | 3 split-bf16 | 4 split-bf16 shared-sigma |
- *                  5 split-fp16 | 6 split-fp16 shared-sigma,
- *   "score_frames_per_lane" 1|2|4, "score_model_groups" n, "score_packed" -1 (scalar FMA) | 1 (packed),
- *   "score_mfma_ft" column tiles per wave, "score_h2s_force_exc" 1 (testing: everything through the
- *   exception pass of engine 6), "score_h2s_shape" 1 (4-wave workgroups) | 2 (12-wave workgroups) | 3 (12 waves, image loop pipelined inside the wave) of engine 6,
- *   "score_h2s_tiles_per_launch" 32-frame tiles per launch of engine 6, "mfcc_waves_per_block" 4|12,
- *   "mfcc_generic" 1 (route FFT_SIZE 2048 through the generic LDS-pass FFT kernel),
- *   "flush_order" 2 | 1 (see SR_CLAMP_COMPAT),
- *   "score_h2s_exact_offset" 1: engine 6's reference-offset pre-pass with all three part products (default: the high parts only),
- *   "kmeans_assign_engine" 1: the k-means initialiser's nearest-centre search by the exact pass only (csrc/kmeans_init.hip),
- *   "reference_side_effects" 1: train_model / train_model_from_ubm print the parameter block (pygmm.cc:31-41) and the
- *   trainer writes ./gmm-training-intermediate-dump.model after every second iteration (gmm.cc:622-630), as the
- *   reference does unconditionally; 0 (default): neither. */
+/* Options (process-wide; value 0 = automatic unless stated).  The complete table -- key, values, default, the test that pins it --
+ * is DESIGN.md section 8.  The ones a caller may want:
+ *   "mfcc_precision" 2 (default: float64 spectrum, ln and DCT for every frame, the reference's arithmetic) | 0 (fp32 throughout,
+ *                    ~1.5x faster feature stage; cepstra up to 2e-2 off on voices whose mel bands lie > 60 dB apart),
+ *   "score_engine"   1 vector ALU | 3 split-bf16 | 4 split-bf16 shared-sigma | 5 split-fp16 | 6 split-fp16 shared-sigma,
+ *   "flush_order"    2 | 1 (see SR_CLAMP_COMPAT),
+ *   "reference_side_effects" 1: train_model / train_model_from_ubm print the parameter block (pygmm.cc:31-41) and the trainer
+ *                    writes ./gmm-training-intermediate-dump.model after every second iteration (gmm.cc:622-630), as the reference
+ *                    does unconditionally; 0 (default): neither,
+ *   "multi_numa_bind" 0: sr_multi slot threads leave their CPU affinity alone (default 1: bound to the cores of their GPU's NUMA
+ *                    node, intersected with the mask the thread already has),
+ *   "multi_merge_same_device" 0: slots that share a device get a host thread each (default 1: one queue per device).
+ * The rest select kernel variants for A/B runs and tests. */
 int sr_set_option(const char *key, long value);
 /* Counters of the partial-product path since the library was loaded: resolve calls, (frame tile, model) pairs
  * noted by the engines, frames re-evaluated.  Any pointer may be NULL. */

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised check of the generic engines (vector ALU, fp32 MFMA, split-bf16, split-fp16, automatic incl. the hybrid
+"""Randomised check of the generic engines (vector ALU, split-bf16, split-fp16, automatic incl. the hybrid
 form) against the float64 oracle: random dims 1..64, K 1..200, 1..6 models of different sizes, weights with zeros,
 shifted / scaled feature spaces, ragged utterances, far outliers, clamp on / off.  `fuzz_generic.py [cases] [seed]`"""
 import os
@@ -45,7 +45,7 @@ for c in range(cases):
     compat = bool(rng.integers(2))
     want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
-    for eng in (0, 1, 2, 3, 5):
+    for eng in (0, 1, 3, 5):
         _lib.set_option("score_engine", eng)
         try:
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
@@ -71,7 +71,7 @@ for c in range(cases):
         limit = 1e-4
         if err >= limit:
             amp = ms.info()["amp"]
-            flag = "(forced engine on an ill-conditioned set, amp %.0f)" % amp if eng in (2, 3, 5) and amp > 1000 else "!!"
+            flag = "(forced engine on an ill-conditioned set, amp %.0f)" % amp if eng in (3, 5) and amp > 1000 else "!!"
             if flag == "!!":
                 fails += 1
             print("  case %d D %d S %d shift %g scale %g clamp %d engine %d: err %.2e %s [%s]" % (c, D, S, shift, scale, compat, eng, err, flag, name[:50]))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-frame log-likelihood error of each scoring engine against the float64 oracle (exact
 log-sum-exp, no clamp) on frames drawn from BASELINE configs[1]-shaped models: max and RMS of
-|LL - LL64| / max(1, |LL64|).  Evidence for "the split-bf16 engine is fp32-grade" (DESIGN.md 2.1)."""
+|LL - LL64| / max(1, |LL64|).  Evidence for "the split-bf16 engine is fp32-grade" (HISTORY.md 2.1)."""
 import json
 import os
 import sys

@@ -28,11 +28,7 @@ void set_reference_side_effects(int v);
 void set_kmeans_assign_engine(int v);
 }
 std::atomic<int> &stream_debug_capture_delay_ms();      // stream.cpp
-std::atomic<int> &multi_pieces_option();                // multi.cpp
 std::atomic<int> &multi_merge_option();
-namespace sr {
-int &h2s_group_major_option();                          // gmm_score_h2_shared.hip
-}
 namespace sr {
 void kmeans_fast_stats(long *passes, long *rechecked);
 int reference_side_effects();
@@ -443,8 +439,6 @@ int sr_modelset_info(SRModelSet *set, double *out8) {
         out8[0] = set->shared.amp; out8[1] = set->shared.pad_waste;
     } else if (!set->bx3.params.empty()) {
         out8[0] = set->bx3.amp; out8[1] = set->bx3.pad_waste; out8[2] = set->bx3.sigma_ratio;
-    } else if (!set->mfma.params.empty()) {
-        out8[0] = set->mfma.amp; out8[1] = set->mfma.pad_waste;
     }
     out8[4] = shared ? 1.0 : 0.0;
     out8[5] = set->host.n_models;
@@ -737,16 +731,14 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "score_packed") {
         score_options().packed = (int)value;
     } else if (k == "score_engine") {
-        if (value < 0 || value > 6)
-            fail("score_engine must be 0 (auto), 1 (vector ALU), 2 (fp32 matrix cores), 3 (split-bf16 matrix cores), "
-                 "4 (split-bf16, shared-sigma form), 5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form)");
+        if (value < 0 || value > 6 || value == 2)
+            fail("score_engine must be 0 (auto), 1 (vector ALU), 3 (split-bf16 matrix cores), 4 (split-bf16, shared-sigma form), "
+                 "5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form); 2 was the fp32 matrix-core engine, removed in round 5 "
+                 "(never selected: 1.45-1.8x slower than split-bf16 at the same accuracy)");
         score_options().engine = (int)value;
     } else if (k == "score_h2s_tiles_per_launch") {
         if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
         score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
-    } else if (k == "score_h2s_exact_offset") {
-        if (value != 0 && value != 1) fail("score_h2s_exact_offset must be 0 or 1");
-        score_options().h2s_exact_offset = (int)value;
     } else if (k == "score_h2s_shape") {
         if (value < 0 || value > 4)
             fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups), 3 (12 waves, image loop pipelined inside the wave) "
@@ -781,16 +773,11 @@ int sr_set_option(const char *key, long value) {
         set_em_stats_engine((int)value);
     } else if (k == "mfcc_waves_per_block") {
         mfcc_set_waves_per_block((int)value);
-    } else if (k == "score_h2s_group_major") {
-        sr::h2s_group_major_option() = value != 0;
     } else if (k == "multi_merge_same_device") {
         multi_merge_option().store(value != 0);
     } else if (k == "multi_numa_bind") {
         if (value != 0 && value != 1) fail("multi_numa_bind must be 0 or 1");
         numa_bind_option().store((int)value);
-    } else if (k == "multi_pieces") {
-        if (value < 0 || value > 8) fail("multi_pieces must be 0 (automatic) .. 8");
-        multi_pieces_option().store((int)value);
     } else if (k == "debug_capture_delay_ms") {
         if (value < 0 || value > 1000) fail("debug_capture_delay_ms must be 0 .. 1000");
         stream_debug_capture_delay_ms().store((int)value);         // test hook (tests/test_gpu_pipeline.py)

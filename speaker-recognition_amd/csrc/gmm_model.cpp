@@ -323,80 +323,6 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
     return pm;
 }
 
-PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp) {
-    PackedMfma pm;
-    const int dim = models[0]->dim;
-    pm.dp = dp;
-    pm.kkp = (dp + 1 + 3) & ~3;
-    const int KQ = pm.kkp / 4;
-    const size_t tile_floats = (size_t)KQ * 64 * 4;
-    const double LOG2E = 1.4426950408889634073599;
-    const double SQRT_2_PI = 2.5066282746310002;
-    // centre of all mixture means: removes the common offset before the expanded form squares it
-    pm.center.assign(dp, 0.0f);
-    {
-        std::vector<double> acc(dim, 0.0);
-        size_t cnt = 0;
-        for (const GMM *g : models) {
-            for (int k = 0; k < g->nr_mixtures; k++)
-                for (int d = 0; d < dim; d++) acc[d] += g->mean[(size_t)k * dim + d];
-            cnt += (size_t)g->nr_mixtures;
-        }
-        for (int d = 0; d < dim; d++) pm.center[d] = (float)(acc[d] / (double)cnt);
-    }
-    size_t live = 0, padded = 0;
-    pm.model_chunk_begin.push_back(0);
-    for (size_t s = 0; s < models.size(); s++) {
-        const GMM &g = *models[s];
-        const int K = g.nr_mixtures;
-        const int n_tiles = (K + MT - 1) / MT;
-        const size_t base = pm.params.size();
-        pm.params.resize(base + (size_t)n_tiles * tile_floats, 0.0f);
-        live += (size_t)K;
-        padded += (size_t)n_tiles * MT;
-        for (int t = 0; t < n_tiles; t++) {
-            float *tile = pm.params.data() + base + (size_t)t * tile_floats;
-            for (int i = 0; i < MT; i++) {
-                const int k = t * MT + i;
-                auto put = [&](int kidx, float v) {   // contraction index kidx of mixture row i
-                    const int kk = kidx >> 1, hh = kidx & 1;
-                    const int lane = i + 32 * hh;
-                    tile[((size_t)(kk >> 2) * 64 + lane) * 4 + (kk & 3)] = v;
-                };
-                if (k >= K) {
-                    put(2 * dp, NEG_BIG);
-                    continue;
-                }
-                double cst = g.weights[k] > 0 ? std::log(g.weights[k]) : -INFINITY;
-                double a = 0.0;
-                for (int d = 0; d < dim; d++) {
-                    const double sg = g.sigma[(size_t)k * dim + d];
-                    const double mu = g.mean[(size_t)k * dim + d] - (double)pm.center[d];
-                    const double iv = 1.0 / (sg * sg);
-                    put(2 * d, (float)(-0.5 * LOG2E * iv));
-                    put(2 * d + 1, (float)(LOG2E * mu * iv));
-                    cst -= std::log(SQRT_2_PI * sg) + 0.5 * mu * mu * iv;
-                    a += mu * mu * iv;
-                }
-                pm.amp = std::max(pm.amp, a);
-                cst *= LOG2E;
-                put(2 * dp, (std::isfinite(cst) && cst > (double)NEG_BIG) ? (float)cst : NEG_BIG);
-            }
-        }
-        for (int t0 = 0; t0 < n_tiles; t0 += MFMA_CT) {
-            ChunkDesc cd;
-            cd.offset_f4 = (uint32_t)((base + (size_t)t0 * tile_floats) / 4);
-            cd.n_records = std::min(MFMA_CT, n_tiles - t0);
-            cd.model_done = (t0 + MFMA_CT >= n_tiles) ? (int)s : -1;
-            cd.pad = 0;
-            pm.chunks.push_back(cd);
-        }
-        pm.model_chunk_begin.push_back((int)pm.chunks.size());
-    }
-    pm.pad_waste = 1.0 - (double)live / (double)padded;
-    return pm;
-}
-
 static inline uint32_t f32_bits(float v) {
     uint32_t u;
     std::memcpy(&u, &v, 4);

@@ -75,26 +75,13 @@ struct PackedModels {
 };
 PackedModels pack_models(const std::vector<const GMM *> &models);
 
-// ---- second layout: mixture coefficients as MFMA A-fragments (expanded quadratic form) ----
+// ---- the expanded quadratic form the matrix-core layouts below share ----
 //   log2 density_k(x) = sum_d ( A2_kd x'_d^2 + A1_kd x'_d ) + C_k,   x' = x - center
 //   A2 = -log2e/(2 sigma^2),  A1 = log2e mu'/sigma^2,  C = log2e (ln w - sum ln(sqrt(2pi) sigma) - sum mu'^2/(2 sigma^2))
-// The contraction index k runs over (x'_0^2, x'_0, x'_1^2, x'_1, ..., 1, 0): K = 2*DP + 2, taken two at
-// a time by v_mfma_f32_32x32x2_f32 (KK = DP+1 steps, padded to a multiple of 4).  A mixture tile =
-// 32 mixtures; its image is [kq][lane][4]: lane l supplies A[mixture = l & 31][k = 2*(4 kq + e) + (l >> 5)].
-// `amp` = max_k sum_d (mu'_d / sigma_d)^2 measures the cancellation the expanded form has to
-// survive in fp32; the dispatcher keeps the 2-FMA vector kernel when it is large.
+// `amp` = max_k sum_d (mu'_d / sigma_d)^2 measures the cancellation the expanded form has to survive; the dispatcher keeps
+// the 2-FMA vector kernel (first layout) when it is large.  (The fp32 image of this form, for v_mfma_f32_32x32x2_f32, was the
+// round-1 engine 2: never selected once the split engines existed, removed in round 5.)
 constexpr int MT = 32;          // mixtures per MFMA tile
-constexpr int MFMA_CT = 2;      // mixture tiles per LDS chunk
-struct PackedMfma {
-    int dp = 0, kkp = 0;
-    std::vector<float> params;       // float4-granular
-    std::vector<ChunkDesc> chunks;   // n_records = mixture tiles in the chunk
-    std::vector<int> model_chunk_begin;
-    std::vector<float> center;       // [dp]
-    double amp = 0.0;
-    double pad_waste = 0.0;          // fraction of padded (dead) mixtures
-};
-PackedMfma pack_models_mfma(const std::vector<const GMM *> &models, int dp);
 
 // ---- third layout: the same expanded form with every coefficient split into three bf16 parts
 // (hi + mid + lo carries all 24 significand bits of the fp32 value), for the bf16 matrix cores:
@@ -187,9 +174,6 @@ struct SRModelSet {
     sr::PackedModels host;
     sr::DevBuf<float> d_params, d_center0;     // vector layout and its centre
     sr::DevBuf<sr::ChunkDesc> d_chunks;
-    sr::PackedMfma mfma;             // expanded-form layout for the matrix-core engine
-    sr::DevBuf<float> d_mfma_params, d_center;
-    sr::DevBuf<sr::ChunkDesc> d_mfma_chunks;
     sr::PackedSplit bx3;             // split-bf16 layout for the bf16 matrix-core engine
     sr::DevBuf<uint16_t> d_bx3_params;
     sr::DevBuf<float> d_bx3_center;

@@ -483,14 +483,6 @@ void upload_model_set(SRModelSet &s) {
 }
 
 // The expanded-form (matrix-core) layout is packed lazily: only sets that take that engine pay.
-static void ensure_mfma_layout(SRModelSet &s) {
-    if (s.d_mfma_params.p) return;
-    s.d_mfma_params.upload(s.mfma.params.data(), s.mfma.params.size());
-    s.d_mfma_chunks.upload(s.mfma.chunks.data(), s.mfma.chunks.size());
-    s.d_center.upload(s.mfma.center.data(), s.mfma.center.size());
-    sync_stream();
-}
-
 static bool h2s_ok(const PackedH2Shared &p) {
     return !p.params.empty() && p.amp <= F16_MAX_AMP && p.pad_waste <= MFMA_MAX_PAD_WASTE &&
            p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
@@ -619,7 +611,6 @@ static void pack_model_set_plain(SRModelSet &s, const std::vector<const GMM *> &
         if (!small && forced == 0 && !h2s_fits) s.h2s = PackedH2Shared();
     }
     if (shared_ok && (small || forced == 4 || (forced == 0 && !h2s_fits))) s.shared = pack_models_bx3_shared(models);
-    if (small || forced == 2) s.mfma = pack_models_mfma(models, s.host.dp);
     if (small || forced == 3 || (forced == 0 && !shared_ok)) s.bx3 = pack_models_split(models, SPLIT_BF16X3);
     if (small || forced == 5 || (forced == 0 && !shared_ok)) s.h2 = pack_models_split(models, SPLIT_F16X2);
 }
@@ -693,13 +684,12 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     const ScoreOptions &opt = score_options();
     // engine choice (see score.hpp): the matrix-core kernel when its layout exists, is well
     // conditioned and not mostly padding; the vector-ALU kernel otherwise or when forced
-    const bool mfma_ok = !set.mfma.params.empty();
     const bool bx3_ok = !set.bx3.params.empty();
     const bool shared_ok = !set.shared.params.empty();
     const bool h2_ok = !set.h2.params.empty();
     const bool h2s_present = !set.h2s.params.empty();
     const bool precise = (flags & SCORE_PRECISE) != 0;
-    bool use_mfma = false, use_bx3 = false, use_shared = false, use_h2 = false, use_h2s = false;
+    bool use_bx3 = false, use_shared = false, use_h2 = false, use_h2s = false;
     auto precise_fallback = [&]() {      // best fp32-grade engine whose layout this set carries
         use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
         if (!use_shared) use_bx3 = bx3_ok && set.bx3.amp <= MFMA_MAX_AMP && set.bx3.pad_waste <= MFMA_MAX_PAD_WASTE;
@@ -724,13 +714,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         if (!bx3_ok) fail("split-bf16 engine requested but the set has no bf16x3 layout (sets of more than 65536 mixtures pack "
                          "only the layouts selected by score_engine when they are created)");
         use_bx3 = true;
-    } else if (opt.engine == 2) {
-        if (!mfma_ok) fail("fp32 matrix-core engine requested but the set has no expanded-form layout (sets of more than 65536 "
-                         "mixtures pack only the layouts selected by score_engine when they are created)");
-        use_mfma = true;
     } else if (opt.engine == 0) {
-        // the split-bf16 kernel is 1.45-1.8x the fp32 matrix-core one at the same accuracy on every
-        // shape swept (profiles/r01_tune_score.log); the fp32 one stays selectable (score_engine = 2)
         use_h2s = !precise && h2s_ok(set.h2s);
         if (!use_h2s) use_shared = shared_ok && set.shared.amp <= MFMA_MAX_AMP && set.shared.pad_waste <= MFMA_MAX_PAD_WASTE;
         if (!use_h2s && !use_shared) use_h2 = !precise && f16_ok(set.h2);
@@ -739,7 +723,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     }
     const bool use_split = use_bx3 || use_h2;
     const PackedSplit &split = use_h2 ? set.h2 : set.bx3;
-    const bool use_mat = use_mfma || use_split || use_shared || use_h2s;
+    const bool use_mat = use_split || use_shared || use_h2s;
     int F = opt.frames_per_lane ? opt.frames_per_lane : auto_frames_per_lane(feat, DP);
     if (DP > 40 && F > 2) F = 2;
     if (DP > 64) F = 1;
@@ -747,18 +731,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     // F times as long, so the frames go to more workgroups first (3000 frames x 1 model: 3 workgroups at F = 4, 12 at F = 1)
     if (!opt.frames_per_lane)
         while (F > 1 && ((feat.n_rows + 256 * F - 1) / (256 * F)) * (int64_t)std::max(1, S) < 2 * (int64_t)ctx().n_cu) F >>= 1;
-    int FT = opt.mfma_ft;
-    if (FT == 0) {
-        // measured (scripts/tune_score.py over D in {13,26,34,39}, K in {64..2048}): one 32-frame column
-        // tile per wave (88 VGPRs, 5 waves/SIMD) is up to 15 % faster than two for K >= 128 and model
-        // sets of >= 8; two win slightly at K = 64; short utterances want the smaller 128-frame tile
-        const double mean_len = feat.n_utt ? (double)feat.n_rows / feat.n_utt : 0.0;
-        const double fill2 = mean_len / (256.0 * std::ceil(std::max(1.0, mean_len) / 256.0));
-        const double tiles_per_model = (double)set.mfma.chunks.size() * MFMA_CT / std::max(1, S);   // ~K/32
-        FT = ((S >= 8 && tiles_per_model >= 4.0) || (mean_len > 0 && fill2 < 0.80)) ? 1 : 2;
-    }
-    if (DP > 40 && FT > 3) FT = 3;
-    if (use_shared || use_h2s) FT = 1;
+    int FT = 1;
     if (use_split) FT = opt.mfma_ft ? std::min(opt.mfma_ft, split_max_ft(split.ks)) : 1;   // one column tile per wave won or tied every sweep
     int h2s_shape = 0;      // 0: 4-wave workgroups; 1: 12-wave workgroups (launch_score_h2_shared)
     if (use_h2s) {
@@ -864,8 +837,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         if (use_shared || use_h2s) {
             for (int g = 0; g <= G; g++) gcb[g] = (int)(((int64_t)g * n_units) / G);
         } else {
-            const std::vector<int> &mcb = use_split ? split.model_chunk_begin
-                                          : use_mfma ? set.mfma.model_chunk_begin : set.host.model_chunk_begin;
+            const std::vector<int> &mcb = use_split ? split.model_chunk_begin : set.host.model_chunk_begin;
             for (int g = 0; g <= G; g++) {
                 const int model = (int)(((int64_t)g * S) / G);
                 gcb[g] = mcb[model];
@@ -923,7 +895,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 r.n_tiles = tt_ref.n_tiles;
                 ScopedKernelTimer t(T_SCORE_REF);
                 // (high parts only: a third of the MFMAs; an offset a few nats off is as good as an exact one, gmm_score_split.hip)
-                launch_score_split(r, opt.h2s_exact_offset ? SPLIT_F16X2 : SPLIT_F16X1, h.ref.ks, 1);
+                launch_score_split(r, SPLIT_F16X1, h.ref.ks, 1);
             }
             const int n_blocks = (int)h.blocks.size();
             w.exc_list.ensure((size_t)std::max(1, tt.n_tiles) * n_blocks);
@@ -989,16 +961,14 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             ScopedKernelTimer t(T_SCORE);
             launch_score_bx3_shared(a, set.shared.kq, set.shared.kl);
         } else if (use_mat) {
-            if (use_h2) ensure_h2_layout(set); else if (use_bx3) ensure_bx3_layout(set); else ensure_mfma_layout(set);
+            if (use_h2) ensure_h2_layout(set); else ensure_bx3_layout(set);
             MfmaLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;
-            a.params = use_h2 ? reinterpret_cast<const float4 *>(set.d_h2_params.p)
-                       : use_bx3 ? reinterpret_cast<const float4 *>(set.d_bx3_params.p)
-                                 : reinterpret_cast<const float4 *>(set.d_mfma_params.p);
-            a.chunks = use_h2 ? set.d_h2_chunks.p : use_bx3 ? set.d_bx3_chunks.p : set.d_mfma_chunks.p;
+            a.params = use_h2 ? reinterpret_cast<const float4 *>(set.d_h2_params.p) : reinterpret_cast<const float4 *>(set.d_bx3_params.p);
+            a.chunks = use_h2 ? set.d_h2_chunks.p : set.d_bx3_chunks.p;
             a.group_chunk_begin = d_gcb;
-            a.center = use_h2 ? set.d_h2_center.p : use_bx3 ? set.d_bx3_center.p : set.d_center.p;
+            a.center = use_h2 ? set.d_h2_center.p : set.d_bx3_center.p;
             if (use_h2) {
                 a.scale = set.d_h2_scale.p;
                 a.oor_flag = w.oor_p();
@@ -1024,13 +994,10 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 snprintf(g_last_kernel, sizeof(LastKernel::name),
                          "gmm_score_split_kernel<f16x2,%d,%d> (3 x v_mfma_f32_32x32x16_f16 per fp32 product)", split.ks, FT);
                 launch_score_split(a, SPLIT_F16X2, split.ks, FT);
-            } else if (use_bx3) {
+            } else {
                 snprintf(g_last_kernel, sizeof(LastKernel::name),
                          "gmm_score_split_kernel<bf16x3,%d,%d> (6 x v_mfma_f32_32x32x16_bf16 per fp32 product)", split.ks, FT);
                 launch_score_split(a, SPLIT_BF16X3, split.ks, FT);
-            } else {
-                snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_mfma_kernel<%d,%d> (v_mfma_f32_32x32x2_f32)", DP, FT);
-                launch_score_mfma(a, DP, FT);
             }
         } else {
             ScoreArgs a;

@@ -461,7 +461,7 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 // a wait for the whole stream in flight), and the stages that hold only phantom models of a set's last block skipped (a scalar
 // test per image: this loop's order is pinned, the same test cost the round-2 loop 9 %).  The matrix work itself cannot shrink
 // inside the 1e-4 tolerance (one part product instead of three on the MAP shift: 4.7e-4 on the benchmark's own speakers; fp8
-// cross terms: ~1e-4).
+// cross terms: ~1e-4; HISTORY.md 2.1).
 //
 // Slot u of image i (one per MFMA of the chain):
 //     s_waitcnt lgkmcnt  fragment u is here (counting only this loop's reads: safe beside the compiler's own, returns are in order)
@@ -944,10 +944,6 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
 // LDS the pipelined kernel takes: its ring of two stages of four images plus the 12 waves' quadratic-half fragments
 __host__ __device__ constexpr bool h2p_fits(int kqf, int klf) { return klf >= 2 && kqf <= klf && (2 * 4 * klf + 12 * kqf) * 1024 <= 160 * 1024; }
 
-int &h2s_group_major_option() {
-    static int v = 1;       // sr_set_option("score_h2s_group_major", 0 | 1): A/B of the launch order (h2s_wg_assignment)
-    return v;
-}
 
 template <int KQF, int KLF, int COLS, int WAVES, bool PIN = false, bool MS = false>
 static int launch_h2s(const H2sLaunch &l) {
@@ -1001,7 +997,7 @@ static int launch_h2s(const H2sLaunch &l) {
         // block's workgroups side by side.
         a.rows8 = (n + 7) / 8;
         a.n_wg = n;
-        a.group_major = l.n_groups > 1 && h2s_group_major_option();
+        a.group_major = l.n_groups > 1;
         constexpr size_t dyn = (BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0) + (MS ? sizeof(uint4) : 0);
         if constexpr (dyn > 0) {
             static bool attr_set[MAX_DEVICES] = {};

@@ -32,13 +32,9 @@
 using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
-constexpr int MULTI_DEFAULT_PIECES = 6; // ... and in this many unless sr_set_option("multi_pieces", n) says otherwise
+constexpr int MULTI_DEFAULT_PIECES = 6; // ... and in this many (6 equal pieces measured best: profiles/r04)
 std::atomic<int> &multi_merge_option() {     // sr_set_option("multi_merge_same_device", 0 | 1)
     static std::atomic<int> v{1};
-    return v;
-}
-std::atomic<int> &multi_pieces_option() {   // sr_set_option("multi_pieces", n): 0 = MULTI_DEFAULT_PIECES, 1 .. MULTI_CHUNKS
-    static std::atomic<int> v{0};
     return v;
 }
 
@@ -187,7 +183,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // piece boundaries: whole utterances, about equal sample counts; pieces of at least ~2 MB of PCM (smaller ones are
         // all launch overhead and kernel tails)
         const int64_t total = s.offsets[U];
-        const int want = multi_pieces_option().load() > 0 ? std::min(MULTI_CHUNKS, multi_pieces_option().load()) : MULTI_DEFAULT_PIECES;
+        const int want = MULTI_DEFAULT_PIECES;
         // Copy and kernels take about the same time on this path (configs[1]: 5.6 and 5.3 ms), so the call ends at about
         // copy(everything) + kernels(last piece): equal pieces, enough of them that the last one is short and few enough that
         // the per-piece launches do not add up (scripts/debug/multi_pieces_sweep.py, page-locked PCM: 1 piece 11.3 ms, 2 8.7,

@@ -10,12 +10,12 @@ struct ScoreOptions {
     int frames_per_lane = 0;   // 0 = auto; 1, 2 or 4 frames resident per lane
     int model_groups = 0;      // 0 = auto; workgroups per frame tile along the model axis
     int packed = 0;            // -1 = scalar v_fma_f32; 0 (auto) / 1 = v_pk_fma_f32, two frames per VGPR pair
-    int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; 2 = fp32 matrix-core kernel;
+    int engine = 0;            // 0 = auto; 1 = vector-ALU 2-FMA kernel; (2 = the fp32 matrix-core kernel of round 1, removed);
                                // 3 = split-bf16 (3 parts, 6 products) matrix-core kernel;
                                // 4 = split-bf16, shared-sigma form (sets whose models share sigma and weights)
                                // 5 = split-fp16 (2 parts, 3 products) matrix-core kernel;
                                // 6 = split-fp16, shared-sigma form
-    int mfma_ft = 0;           // 32-frame column tiles per wave in the matrix-core kernels (0 = auto)
+    int mfma_ft = 0;           // 32-frame column tiles per wave in the 4-wave generic split kernels (0 = one)
     int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
                                // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS); 3 = 12 waves with the
@@ -23,7 +23,6 @@ struct ScoreOptions {
     int split_shape = 0;       // workgroup shape of the generic split-fp16 engine: 0 = automatic; 1 = 4 waves (gmm_score_split_kernel);
                                // 16 / 12 / 8 = gmm_score_splitp_kernel with that many waves (one 32-frame tile each, log-sum-exp pipelined
                                // under the next chunk's MFMAs; 16 and 12: one workgroup per CU, 8: two)
-    int h2s_exact_offset = 0;  // 1: the reference-offset pre-pass of the split-fp16 shared-sigma engine with all three part products (round 2's)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
     int flush_list_cap = 0;    // testing: capacity of the list of (tile, model) pairs in the partial-product band (0 = automatic);
                                // a pass that notes more re-runs with a list of the counted length
@@ -36,7 +35,7 @@ constexpr double MFMA_MAX_PAD_WASTE = 0.25;
 // The two-part fp16 engines carry 22 significand bits per operand (error ~4x an fp32 FMA chain's per
 // term, scripts/emulate_split.py) and fp16's 5-bit exponent: offered when the cancellation is
 // moderate, every dimension's sigmas stay within a factor the gradual-underflow error analysis
-// covers, and the scaled coefficients fit fp16.
+// covers (HISTORY.md 2.1), and the scaled coefficients fit fp16.
 constexpr double F16_MAX_AMP = 1000.0;
 // Hybrid form: a set the expanded form is ill conditioned for (amp above the limits) because of FEW of its mixtures
 // -- collapsed components at the sigma floor, outlier catchers -- is cut in two: those mixtures (at most
@@ -64,7 +63,6 @@ struct MfmaLaunch {
     int dim, n_models, clamp, n_groups, n_tiles;
     float band_hi = -__builtin_inff();   // below it a frame goes to the partial-product path (lse.hpp); -inf: never
 };
-void launch_score_mfma(const MfmaLaunch &a, int DP, int FT);
 struct SharedLaunch {
     const float *X;
     const TileDesc *tiles;

@@ -45,10 +45,10 @@ def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
         m = _gmm(g, c)
         ref = g[c + "_ll"]
         for F, pk, eng, ft in ((0, 0, 1, 0), (1, 0, 1, 0), (2, -1, 1, 0), (4, -1, 1, 0), (2, 1, 1, 0), (4, 1, 1, 0),
-                               (0, 0, 2, 1), (0, 0, 2, 2), (0, 0, 2, 3), (0, 0, 3, 1), (0, 0, 3, 2), (0, 0, 5, 1), (0, 0, 5, 2), (0, 0, 0, 0)):
+                               (0, 0, 3, 1), (0, 0, 3, 2), (0, 0, 5, 1), (0, 0, 5, 2), (0, 0, 0, 0)):
             _lib.set_option("score_frames_per_lane", F)
             _lib.set_option("score_packed", pk)
-            _lib.set_option("score_engine", eng)      # 1: vector ALU, 2: fp32 matrix cores, 3: split-bf16, 5: split-fp16 matrix cores, 0: auto
+            _lib.set_option("score_engine", eng)      # 1: vector ALU, 3: split-bf16, 5: split-fp16 matrix cores, 0: auto
             _lib.set_option("score_mfma_ft", ft)
             ll = m.score(g[c + "_X"])
             assert ll_close(ll, ref) < TOL, (c, F, pk, eng, ft, ll_close(ll, ref))
@@ -103,7 +103,7 @@ def test_speaker_set_ragged_batch_vs_oracle(built_lib, oracle_built):
     off = np.concatenate([[0], np.cumsum(lens)])
     want_sums = np.array([[want[s, off[u]:off[u + 1]].sum() for s in range(S)] for u in range(len(lens))])
     for F, pk, G, eng in ((0, 0, 0, 1), (1, 0, 1, 1), (2, -1, 3, 1), (4, -1, 7, 1), (4, 1, 2, 1), (2, 1, 0, 1),
-                          (0, 0, 0, 2), (0, 0, 3, 2), (0, 0, 0, 3), (0, 0, 2, 3), (0, 0, 0, 0)):
+                          (0, 0, 0, 5), (0, 0, 3, 5), (0, 0, 0, 3), (0, 0, 2, 3), (0, 0, 0, 0)):
         _lib.set_option("score_frames_per_lane", F)
         _lib.set_option("score_packed", pk)
         _lib.set_option("score_model_groups", G)
@@ -245,7 +245,7 @@ def test_cfg2_ubm_map_speakers_vs_oracle(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     off = np.concatenate([[0], np.cumsum([len(u) for u in utts])])
-    for eng in (1, 2, 3, 5, 0):
+    for eng in (1, 3, 5, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         assert ll_close(fll, want) < TOL, (eng, ll_close(fll, want))
@@ -270,7 +270,7 @@ def test_streaming_shape_short_windows(built_lib, oracle_built):
     X = np.concatenate(utts).astype(np.float64)
     want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
     off = np.concatenate([[0], np.cumsum(lens)])
-    for eng in (1, 2, 3, 0):
+    for eng in (1, 3, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         assert ll_close(fll, want) < TOL, eng
@@ -299,7 +299,7 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
         utts = [synth.draw_frames(models[u % 3], n, 40 + u) for u, n in enumerate([3, 130, 257, 1])]
         X = np.concatenate(utts).astype(np.float64)
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
-        for eng in ((1, 2, 3) if D <= 64 else (0, 1)):
+        for eng in ((1, 3) if D <= 64 else (0, 1)):
             _lib.set_option("score_engine", eng)
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
             assert ll_close(fll, want) < TOL, (K, D, eng, ll_close(fll, want))
@@ -345,13 +345,13 @@ def test_engine_selection_and_split_bf16_accuracy(built_lib, oracle_built):
     want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=False) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
     err = {}
-    for eng in (1, 2, 3, 5, 0):
+    for eng in (1, 3, 5, 0):
         _lib.set_option("score_engine", eng)
         sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
         err[eng] = float(np.max(np.abs(fll - want) / np.maximum(1.0, np.abs(want))))
         if eng == 0:
             assert "f16x2" in _lib.last_score_kernel()     # well conditioned, moderate sigma range: 3 products
-    assert err[3] < 5e-6 and err[3] <= 2.0 * max(err[1], err[2]) + 1e-7, err
+    assert err[3] < 5e-6 and err[3] <= 6.0 * err[1] + 1e-7, err     # (vector ALU: 3.7e-7; the fp32 MFMA chain of rounds 1-4 measured 1.7e-6, bf16x3 1.2e-6)
     assert err[5] < 1e-5 and err[0] == err[5], err            # two fp16 parts: 22 bits per operand
     _lib.set_option("score_engine", 0)
     # ill-conditioned expanded form: means ~30 sigma apart -> direct form on the vector ALU
@@ -393,7 +393,7 @@ def test_random_shapes_all_engines(built_lib, oracle_built):
         want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
         off = np.concatenate([[0], np.cumsum(lens)])
         ms = ModelSet([GMM.from_arrays(*m) for m in models])
-        for eng in (1, 2, 3, 5, 0):
+        for eng in (1, 3, 5, 0):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_model_groups", int(rng.integers(0, 4)))
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
@@ -591,7 +591,7 @@ def test_clamp_band_matches_reference_all_engines(built_lib, clamp_golden):
         m = _gmm(g, c)
         X, ref = g[c + "_X"], g[c + "_ll"]
         clamped = ref == np.log(1e-15)
-        for eng, wide in ((1, 0), (2, 0), (3, 0), (5, 1), (5, 8), (5, 12), (5, 16), (0, 0)):
+        for eng, wide in ((1, 0), (3, 0), (5, 1), (5, 8), (5, 12), (5, 16), (0, 0)):
             _lib.set_option("score_engine", eng)
             _lib.set_option("score_split_shape", wide)       # the generic split-fp16 engine: 4-wave kernel / the wide pipelined forms
             ll = m.score(X)
@@ -627,7 +627,7 @@ def test_partial_product_flushes_match_reference_all_engines(built_lib, oracle_b
         n_wrong_before += int(np.sum(np.abs(g[c + "_full_rule_ll"] - ref) > 1e-3))
         # ---- the legacy one-model path (score / score_all of every engine that fits the model)
         m = GMM.from_arrays(*models[0])
-        for eng in ((1, 2, 3, 5, 0) if c in conditioned else (1, 0)):
+        for eng in ((1, 3, 5, 0) if c in conditioned else (1, 0)):
             _lib.set_option("score_engine", eng)
             ll = m.score(X)
             assert np.array_equal(ll == floor32, clamped[0]), (c, eng, _lib.last_score_kernel())
