@@ -747,6 +747,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "flush_list_cap") {
         if (value < 0) fail("flush_list_cap must be >= 0");
         score_options().flush_list_cap = (int)value;
+    } else if (k == "score_h2s_pack_tails") {
+        if (value != 0 && value != 1) fail("score_h2s_pack_tails must be 0 or 1");
+        score_options().h2s_pack_tails = (int)value;
     } else if (k == "score_h2s_force_exc") {
         score_options().h2s_force_exc = value != 0;
     } else if (k == "score_split_shape") {

@@ -23,7 +23,15 @@ struct TileTable {
     DevBuf<TileDesc> d_tiles;
     DevBuf<int> d_utt_tile_begin;  // [U+1]
     std::vector<TileDesc> h_tiles; // host copy (the partial-product path maps noted tiles back to utterances)
+    // 32-frame tables: the pipelined shared-sigma kernel's view -- the same tiles followed by its work items (int4 {tile, tile or -1,
+    // tile or -1, tile or -1}: a full tile each, the ragged tail tiles of different utterances packed up to four to a wave when
+    // `work_packed`), padded with empty items {-1, ..} to whole rounds of 8 workgroups x 12 waves.  Built on first use.
+    DevBuf<TileDesc> d_tiles_work;
+    int n_work = 0;
+    bool work_packed = false;
 };
+
+void ensure_work_table(TileTable &tt, bool pack_tails);   // gmm_score.hip
 
 }  // namespace sr
 

@@ -927,6 +927,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.force_exc = opt.h2s_force_exc;
             a.tiles_per_launch = opt.h2s_tiles_per_launch;
             a.shape = h2s_shape;
+            if (h2s_shape == 2) {      // the pipelined kernel walks work items: ragged tail tiles share a wave
+                ensure_work_table(tt, opt.h2s_pack_tails != 0);
+                a.tiles = tt.d_tiles_work.p;
+                a.n_work = tt.n_work;
+            }
             a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "%s<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
@@ -1182,6 +1187,44 @@ void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argm
     fetch_results(set, feat, flags | SCORE_PRECISE, r2, sums_out, argmax_out, frame_ll_out);
 }
 
+}  // namespace sr
+
+// Work items of the pipelined shared-sigma kernel over a 32-frame tile table: tiles in order, every full one an item of its own, the
+// ragged tails (1000-frame utterances leave 8 of 32 columns: 2.3 % of the pass's MFMAs on dead frames) packed greedily, in order,
+// up to four and up to 32 columns to an item, placed where the first of them stood.
+namespace sr {
+void ensure_work_table(TileTable &tt, bool pack_tails) {
+    if ((tt.n_work > 0 && tt.work_packed == pack_tails) || tt.n_tiles == 0) return;
+    static_assert(sizeof(TileDesc) == sizeof(int4), "work items travel in the tile table's buffer");
+    std::vector<int4> work;
+    work.reserve(tt.h_tiles.size() + 96);
+    int open_item = -1, open_n = 0, open_cols = 0;
+    for (int t = 0; t < tt.n_tiles; t++) {
+        const int c = tt.h_tiles[t].count;
+        if (!pack_tails || c >= tt.frames_per_tile) {
+            work.push_back(make_int4(t, -1, -1, -1));
+            continue;
+        }
+        if (open_item < 0 || open_n == 4 || open_cols + c > tt.frames_per_tile) {
+            open_item = (int)work.size();
+            open_n = 0;
+            open_cols = 0;
+            work.push_back(make_int4(-1, -1, -1, -1));
+        }
+        int4 &w = work[open_item];
+        (open_n == 0 ? w.x : open_n == 1 ? w.y : open_n == 2 ? w.z : w.w) = t;
+        open_n++;
+        open_cols += c;
+    }
+    tt.n_work = (int)work.size();
+    tt.work_packed = pack_tails;
+    work.resize(((work.size() + 95) / 96) * 96, make_int4(-1, -1, -1, -1));      // whole rounds of 8 workgroups x 12 waves
+    std::vector<TileDesc> both(tt.h_tiles);
+    both.resize(tt.h_tiles.size() + work.size());
+    std::memcpy(both.data() + tt.h_tiles.size(), work.data(), work.size() * sizeof(int4));
+    tt.d_tiles_work.upload(both.data(), both.size());
+    sync_stream();
+}
 }  // namespace sr
 
 sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {

@@ -100,6 +100,16 @@ __device__ __forceinline__ void h2s_build_b(f16x8 (&out)[KN], const float *__res
     }
 }
 
+// value of `v` in lane (lane + shift) & 63 (ds_bpermute: an LDS-pipe round trip; the packed close of a few percent of the waves only)
+__device__ __forceinline__ double lane_shift_down_f64(double v, int shift, int lane) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    const int addr = ((lane + shift) & 63) << 2;
+    b.i[0] = __builtin_amdgcn_ds_bpermute(addr, a.i[0]);
+    b.i[1] = __builtin_amdgcn_ds_bpermute(addr, a.i[1]);
+    return b.d;
+}
+
 struct H2sArgs {
     const float *X;
     const TileDesc *tiles;
@@ -121,6 +131,7 @@ struct H2sArgs {
     int rows8;                    // rows of 8 workgroups (one per XCD) this launch has per model group
     int group_major;              // launch order of the model groups' workgroups (h2s_wg_assignment): 0 group-fastest, 1 group-major
     int n_wg;                     // workgroups (of TILES_WG tiles) per group in this launch
+
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
@@ -195,6 +206,74 @@ __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBl
         if (lane == 0 && has && si < sb.n_models)
             a.partial[(int64_t)tile_id * a.n_models + sb.first_model + si] = mine;
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Work item `unit` of the pipelined kernel -- a full 32-frame tile, or up to four ragged TAIL tiles of different utterances side by
+// side in the wave's 32 columns (ensure_work_table; the table sits right behind the tile table in the same buffer, padded with empty
+// items to the grid's size: no kernel argument of its own -- the kernel has no scalar register to spare): its canonical tiles
+// tids[0 .. n_seg - 1] and the column each starts at (absent ones: 64).  An empty item has tids[0] < 0.
+__device__ __forceinline__ void h2p_unit(const H2sArgs &a, int unit, int (&tids)[4], int (&first_col)[4], int &n_seg) {
+    const int4 wk = reinterpret_cast<const int4 *>(a.tiles + a.n_tiles)[unit];
+    tids[0] = wk.x; tids[1] = wk.y; tids[2] = wk.z; tids[3] = wk.w;
+    first_col[0] = 0; first_col[1] = 64; first_col[2] = 64; first_col[3] = 64;
+    n_seg = 1;
+    int cum = 0;
+#pragma unroll
+    for (int p = 1; p < 4; p++)
+        if (tids[p] >= 0) {                                    // wave-uniform
+            cum += a.tiles[tids[p - 1]].count;
+            first_col[p] = cum;
+            n_seg = p + 1;
+        }
+}
+
+// The same close for a wave whose 32 columns hold up to four ragged tail tiles of DIFFERENT utterances (the pipelined kernel's packed
+// work items): every segment is one canonical tile of the batch's tile table -- its fate (results or exception list) is decided on
+// its own frames only, and its float64 partial is formed exactly as if it sat alone in a wave: the segment's values are moved down to
+// lane 0 .. count-1 (zeros elsewhere) before the fixed-order wave sum.  An utterance's result does not depend on what it was packed with.
+__device__ __forceinline__ void h2s_close_block_packed(const H2sArgs &a, const SharedBlock &sb, int blk, const float (&ssum)[SHARED_SB], float off,
+                                                       bool valid, bool has, const int (&tids)[4], const int (&first_col)[4], int n_seg,
+                                                       int64_t row, int lane, int hh, float safe_ll2) {
+    constexpr int SB = SHARED_SB;
+    const int col = lane & 31;
+    const int seg = (col >= first_col[1]) + (col >= first_col[2]) + (col >= first_col[3]);      // (absent segments start at column 64)
+    bool bad = false;
+    float ll_keep[SB];
+#pragma unroll
+    for (int si = 0; si < SB; si++) {
+        const float tot = ssum[si] + other_half(ssum[si]);
+        const float ll2 = off + log2f(tot);
+        ll_keep[si] = LSE_LN2 * ll2;
+        const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
+        bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+    }
+    const uint64_t bad_mask = __builtin_amdgcn_ballot_w64(bad);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (p >= n_seg) break;                                          // wave-uniform
+        const uint64_t seg_mask = __builtin_amdgcn_ballot_w64(seg == p);
+        if ((bad_mask & seg_mask) != 0) {
+            if (lane == 0 && has) {
+                const int idx = atomicAdd(a.exc_count + blk, 1);
+                a.exc_list[(size_t)blk * a.n_tiles + idx] = tids[p];
+            }
+            continue;
+        }
+        const bool mine_seg = valid && hh == 0 && seg == p;
+#pragma unroll
+        for (int si = 0; si < SB; si++) {
+            double mine = 0.0;
+            if (mine_seg && si < sb.n_models) {
+                mine = (double)ll_keep[si];
+                if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll_keep[si];
+            }
+            mine = lane_shift_down_f64(mine, first_col[p], lane);
+            mine = wave_sum_f64(mine);
+            if (lane == 0 && has && si < sb.n_models)
+                a.partial[(int64_t)tids[p] * a.n_models + sb.first_model + si] = mine;
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -611,11 +690,26 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
     // ---- resident B fragments of this lane's frame ----
     f16x8 bl[KLF];
     float zmax = 0.0f;
-    const int tile_id = tile0 + wave;
-    const bool has = tile_id < a.n_tiles;
-    const TileDesc tile = a.tiles[has ? tile_id : a.n_tiles - 1];
-    const bool valid = has && col < tile.count;
-    const int64_t row = tile.start + (valid ? col : 0);
+    // this wave's work item (h2p_unit).  What describes it is read here and AGAIN at every close: ten more scalar registers held
+    // across the image loop spilled 35 of them into vector lanes.
+    const int unit = tile0 + wave;
+    bool has;
+    TileDesc tile;
+    int my_col = col;
+    {
+        int tids[4], first_col[4], n_seg;
+        h2p_unit(a, unit, tids, first_col, n_seg);
+        has = tids[0] >= 0;
+        tile = a.tiles[has ? tids[0] : 0];
+#pragma unroll
+        for (int p = 1; p < 4; p++)
+            if (p < n_seg && col >= first_col[p]) {
+                my_col = col - first_col[p];
+                tile = a.tiles[tids[p]];
+            }
+    }
+    const bool valid = has && my_col < tile.count;
+    const int64_t row = tile.start + (valid ? my_col : 0);
     {
         f16x8 bq[KQF];
         h2s_build_b<KQF>(bq, a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
@@ -807,7 +901,12 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
         const int last_model = n_st * G - 2;                  // image n_st * G - 1
 #pragma unroll
         for (int si = 0; si < SB; si++) fin[si] = ssum[si] + (si == last_model ? ssum[SB] : 0.0f);
-        h2s_close_block(a, sb, blk, fin, off, valid, has, tile_id, row, lane, hh, safe_ll2);
+        {
+            int tids[4], first_col[4], n_seg;
+            h2p_unit(a, unit, tids, first_col, n_seg);
+            if (n_seg == 1) h2s_close_block(a, sb, blk, fin, off, valid, has, tids[0], row, lane, hh, safe_ll2);
+            else h2s_close_block_packed(a, sb, blk, fin, off, valid, has, tids, first_col, n_seg, row, lane, hh, safe_ll2);
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -978,7 +1077,8 @@ static int launch_h2s(const H2sLaunch &l) {
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
     constexpr int TILES_WG = MS ? 1 : WAVES * COLS;
     const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES, MS));
-    const int n_wg = (l.n_tiles + TILES_WG - 1) / TILES_WG;
+    if (PIN && l.n_work <= 0) fail("the pipelined shared-sigma kernel needs its work table behind the tile table (ensure_work_table)");
+    const int n_wg = ((PIN ? l.n_work : l.n_tiles) + TILES_WG - 1) / TILES_WG;
     // (the 12-wave form has one workgroup per CU sweeping the stream: nothing drifts apart, 1 / 3 / 5 / 9 / 18 launches
     // per configs[2] pass all take 0.281-0.283 s -- one launch)
     int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)

@@ -23,6 +23,7 @@ struct ScoreOptions {
     int split_shape = 0;       // workgroup shape of the generic split-fp16 engine: 0 = automatic; 1 = 4 waves (gmm_score_split_kernel);
                                // 16 / 12 / 8 = gmm_score_splitp_kernel with that many waves (one 32-frame tile each, log-sum-exp pipelined
                                // under the next chunk's MFMAs; 16 and 12: one workgroup per CU, 8: two)
+    int h2s_pack_tails = 1;    // 0: the pipelined shared-sigma kernel takes one tile per wave even when it is a ragged tail (A/B, tests)
     int h2s_force_exc = 0;     // testing: send every workgroup of the split-fp16 shared-sigma engine through its exception pass
     int flush_list_cap = 0;    // testing: capacity of the list of (tile, model) pairs in the partial-product band (0 = automatic);
                                // a pass that notes more re-runs with a list of the counted length
@@ -89,6 +90,7 @@ struct H2sLaunch {
     double *partial;
     float *frame_ll;
     int *oor_flag;
+    int n_work = 0;     // pipelined shape: `tiles` is TileTable::d_tiles_work -- the tiles, then this many work items (+ padding)
     int *exc_list;      // [n_blocks][n_tiles] tile ids
     int *exc_count;     // [n_blocks]
     int n_blocks;

@@ -34,6 +34,7 @@ def _reset_options(built_lib):
         _lib.set_option(k, 0)
     _lib.set_option("flush_order", 2)
     _lib.set_option("flush_list_cap", 0)
+    _lib.set_option("score_h2s_pack_tails", 1)
 
 
 def test_golden_per_frame_ll_all_variants(built_lib, gmm_golden):
@@ -920,3 +921,49 @@ def test_matrix_peak_probe_reports_a_plausible_rate(built_lib):
     assert 800.0 < mhz < 2500.0, mhz
     # the two figures describe the same run: 256 CUs x 4 SIMDs x 1024 flop per cycle at a pipe that is (nearly) always busy
     assert 0.85 < tflops * 1e12 / (mhz * 1e6 * 1024 * 1024) <= 1.02, (tflops, mhz)
+
+
+def test_packed_tail_tiles_leave_every_utterance_its_own_bits(built_lib, oracle_built):
+    """The pipelined shared-sigma kernel packs the ragged TAIL tiles of different utterances (count < 32) up to four to a wave
+    (csrc/gmm_score.hip: ensure_work_table, gmm_score_h2_shared.hip: h2s_close_block_packed).  An utterance's sums, per-frame
+    values and its trip through the exception pass must not depend on what it was packed with: packing on / off bit-identical,
+    every utterance scored ALONE bit-identical to its row in the batch, a rogue frame (+60 on every dimension: offset form
+    refuses, the online pass takes the tile) in ONE tail leaves its pack-mates' results where they were, all against the oracle."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    ubm = synth.synth_gmm(64, 39, 4242)
+    models = [ubm] + [synth.synth_map_speaker(ubm, 8100 + s) for s in range(16)]
+    ms = ModelSet([GMM.from_arrays(*m) for m in models])
+    lens = [1000, 33, 8, 40, 63, 32, 1, 97, 159, 31, 64, 200, 5, 17] * 3           # tails of 8, 1, 8, 31, 1, 1, 31, 31, 8, 5, 17 ... and none
+    utts = [synth.draw_frames(models[1 + u % 16], n, 300 + u) for u, n in enumerate(lens)]
+    rogue = 3                                                                     # its tail tile (8 frames) is packed with neighbours'
+    utts[rogue] = utts[rogue].copy()
+    utts[rogue][-2] += 60.0
+    _lib.set_option("score_engine", 6)
+    _lib.set_option("score_h2s_shape", 3)                                         # the pipelined kernel
+    out = {}
+    for pack in (1, 0):
+        _lib.set_option("score_h2s_pack_tails", pack)
+        out[pack] = ms.score(Batch.from_features(utts), frame_ll=True)
+        assert "pipelined" in _lib.last_score_kernel()
+    _lib.set_option("score_h2s_pack_tails", 1)
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)
+    sums, arg, fll = out[1]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for u in (0, 1, 2, 3, 4, 6, 9, 12, 13, 20, 41):
+        s1, a1, f1 = ms.score(Batch.from_features([utts[u]]), frame_ll=True)     # alone: nothing to be packed with
+        assert np.array_equal(s1[0], sums[u]) and np.array_equal(f1, fll[:, off[u]:off[u + 1]]), u
+    X = np.concatenate(utts).astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+    assert ll_close(fll, want) < TOL
+    for u in range(len(lens)):
+        w = want[:, off[u]:off[u + 1]].sum(axis=1)
+        assert np.max(np.abs(sums[u] - w) / np.maximum(1.0, np.abs(w))) < 1e-5
+    # the rogue frame's tile went through the exception pass, its pack-mates' did not change (checked above against the unpacked
+    # run); and with EVERY tile forced through the online pass the answers stay within the gate
+    _lib.set_option("score_h2s_force_exc", 1)
+    s_f, a_f, f_f = ms.score(Batch.from_features(utts), frame_ll=True)
+    assert ll_close(f_f, want) < TOL and np.array_equal(a_f, arg)
