@@ -837,7 +837,8 @@ def compact(result, blocks_file=None):
         "n_gpus": result.get("n_gpus"), "steps": result.get("steps"), "warmup": result.get("warmup"),
         "ms_per_step": _r(result.get("ms_per_step"), 6), "higher_is_better": True, "scaling": result.get("scaling"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[2]: 16 kHz PCM -> 39-dim MFCC+d+dd, 512-mix UBM + 200 MAP speakers, 10 M frames/GPU",
+        "config": {"workload": "configs[2]: 16 kHz PCM -> 39-dim MFCC+d+dd, 512-mix UBM + 200 MAP speakers, %s M frames/GPU"
+                               % _r((cfg.get("frames_per_gpu") or 0) / 1e6, 4),
                    "frames_per_gpu": cfg.get("frames_per_gpu"), "models": cfg.get("models"), "mixtures": cfg.get("mixtures"),
                    "dim": cfg.get("dim"), "sharding": "utterances, no collective"},
         "roofline": {"kernel": str(rf.get("kernel", ""))[:48], "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")),
@@ -849,7 +850,7 @@ def compact(result, blocks_file=None):
         "cpu_baseline": ({"error": str(cb.get("error"))[:80]} if "error" in cb else
                          {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
                           "sample": ("%s utt x 10.04 s, all %s models: reference C++ score_batch on Pool(%s) + f64 MFCC.py restatement"
-                                     % (e2e.get("utterances"), e2e.get("models"), cb.get("cores"))) if cb else None}),
+                                     % (e2e.get("utterances"), e2e.get("models"), cb.get("cores"))) if cb else "measured at N = 1 only"}),
         "parity": {"argmax_mismatches": e2e.get("argmax_mismatches"), "utt_sum_max_rel": _r(e2e.get("max_rel_sum_diff"), 3),
                    "frame_ll_from_pcm_max_rel": _r(pf.get("max_rel"), 3), "frame_ll_from_pcm_frames": pf.get("frames"),
                    "mfcc_max_abs": _r(mf.get("max_abs_diff_vs_oracle"), 3), "mfcc_mean_abs": _r(mf.get("mean_abs_diff_vs_oracle"), 3),
