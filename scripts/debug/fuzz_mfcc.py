@@ -14,6 +14,8 @@ from speaker_recognition_amd import _lib, synth  # noqa: E402
 from speaker_recognition_amd.core import Batch, MfccExtractor  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+prec = int(sys.argv[3]) if len(sys.argv) > 3 else 2            # mfcc_precision: 2 float64 spectrum (default), 0 fp32
+_lib.set_option("mfcc_precision", prec)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 worst_raw = worst_feat = 0.0
 fails = 0
@@ -63,7 +65,7 @@ for c in range(cases):
             continue
         e_feat = float(np.max(np.abs(got - ref)))
         worst_raw, worst_feat = max(worst_raw, e_raw), max(worst_feat, e_feat)
-        if e_raw > 3e-4 or e_feat > 6e-3:
+        if e_raw > (3e-6 if prec == 2 else 3e-4) or e_feat > (1e-4 if prec == 2 else 6e-3):
             msg += " [utt %d raw %.1e feat %.1e]" % (i, e_raw, e_feat)
     if msg:
         fails += 1

@@ -967,3 +967,43 @@ def test_packed_tail_tiles_leave_every_utterance_its_own_bits(built_lib, oracle_
     _lib.set_option("score_h2s_force_exc", 1)
     s_f, a_f, f_f = ms.score(Batch.from_features(utts), frame_ll=True)
     assert ll_close(f_f, want) < TOL and np.array_equal(a_f, arg)
+
+
+def test_split_fp16_engines_on_trained_models_vs_oracle(built_lib, oracle_built):
+    """The 22-bit split-fp16 engines (a1 b1 dropped) on models that were TRAINED, not drawn: a 64-mixture UBM by EM on the MFCC
+    features of 24 synthetic speakers and their means-only MAP adaptations (what enrolment produces: collapsed and wide mixtures side by
+    side, weights over four decades), scored on held-out audio.  The dispatcher's guards (amp <= 1000, sigma ratio <= 256, coefficients
+    within fp16) decide what runs; whatever does must sit inside the 1e-4 gate per frame against the float64 oracle, and the forced
+    fp16 engines -- where the set qualifies -- within 2e-5."""
+    import bench
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
+    go = oracle_built
+    ex = MfccExtractor(bench.FS, **bench.MFCC_KW)
+    n_samples = 600 * ex.FRAME_SHIFT + ex.FRAME_LEN
+    base = bench.base_clips(24, n_samples)
+    ubm, spk = bench.train_cfg2_models(ex, base, 64, em_iters=8)
+    models = [ubm] + spk
+    ms = ModelSet(models)
+    info = ms.info()
+    test = [np.rint(base[s] * 0.8).astype(np.int16) for s in range(0, 24, 3)]
+    fb = ex.extract_batch(Batch.from_pcm(test), nd=bench.ND)
+    X = fb.download().astype(np.float64)
+    want = np.stack([go.score_batch(go.GMMParams(*m.params()), X) for m in models])
+    worst = {}
+    for eng in (0, 1, 3, 4, 5, 6):
+        _lib.set_option("score_engine", eng)
+        try:
+            sums, arg, fll = ms.score(fb, frame_ll=True)
+        except Exception as e:                        # a forced engine the set does not qualify for says so
+            assert eng in (4, 5, 6) and ("does not qualify" in str(e) or "layout" in str(e)), (eng, str(e))
+            continue
+        worst[eng] = ll_close(fll, want)
+        assert worst[eng] < TOL, (eng, worst[eng], info, _lib.last_score_kernel())
+        if eng in (5, 6):
+            assert worst[eng] < 2e-5, (eng, worst[eng], info)
+    assert 0 in worst and 1 in worst
+    _lib.set_option("score_engine", 0)
+    # held-out renditions are identified (speaker s of `test` is base[3 s])
+    sums, arg = ms.score(fb)
+    assert np.array_equal(np.argmax(sums[:, 1:], axis=1), np.arange(0, 24, 3))
