@@ -51,10 +51,9 @@ static int check_packers(int S, int K, int D) {
         std::vector<const GMM *> v;
         for (auto &g : ms) v.push_back(&g);
         auto host = pack_models(v);
-        auto mf = pack_models_mfma(v, host.dp);
         auto b3 = pack_models_split(v, SPLIT_BF16X3);
         auto h2 = pack_models_split(v, SPLIT_F16X2);
-        if (host.params.empty() || mf.params.empty() || b3.params.empty() || h2.params.empty()) return 1;
+        if (host.params.empty() || b3.params.empty() || h2.params.empty()) return 1;
         if (models_share_sigma_and_weights(v) != (shared != 0 && false)) {
             // (the dead mixture breaks weight sharing on purpose: both answers are exercised below)
         }
