@@ -506,10 +506,22 @@ void mfcc_launch_f64(SRMfcc &m, const MfccDev &dev, int pcm_kind, const void *pc
             mr.pass_len[ps] = tabs.pass_len[ps];
         }
         // one contiguous frame range per wave; one 8-wave workgroup per CU (its LDS)
+        // Frames per wave: the chip holds ONE round of waves at a time (a workgroup per CU), every wave walks its frames one after the
+        // other, so a pass costs rounds x frames per wave.  Of 1..4 rounds the cheapest (64 utterances x 300
+        // frames: one round of 10 frames per wave, not 1.17 rounds of 8 -- 0.108 -> 0.07 ms); large batches end up with four rounds
+        // of equal waves, which evens out what the scheduler does to them.
         const int64_t one_round = (int64_t)ctx().n_cu * F64_WPB;
-        const int64_t max_waves = one_round * 4;
-        int64_t frames_per_wave = std::max<int64_t>(1, (n_frames + one_round - 1) / one_round);
-        if (frames_per_wave > 8) frames_per_wave = std::max<int64_t>(8, (n_frames + max_waves - 1) / max_waves);
+        int64_t frames_per_wave = 1, best_cost = -1;
+        for (int64_t r = 1; r <= 4; r++) {
+            const int64_t fpw = std::max<int64_t>(1, (n_frames + r * one_round - 1) / (r * one_round));
+            const int64_t waves = (n_frames + fpw - 1) / fpw;
+            const int64_t cost = ((waves + one_round - 1) / one_round) * fpw;
+            // (more rounds of shorter waves are preferred within 2 % while a wave still has >= 32 frames to amortise its start on)
+            if (best_cost < 0 || cost < best_cost - best_cost / 50 || (cost <= best_cost + best_cost / 50 && fpw >= 32)) {
+                best_cost = cost;
+                frames_per_wave = fpw;
+            }
+        }
         const int64_t n_waves = (n_frames + frames_per_wave - 1) / frames_per_wave;
         const int grid = (int)((n_waves + F64_WPB - 1) / F64_WPB);
         int preset = 0;
