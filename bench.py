@@ -653,6 +653,36 @@ def block_vector_alu(_lib, hbm):
     return out
 
 
+def block_mfcc_precision(_lib, base, preq):
+    """The feature stage in both precision modes on the configs[1] audio (1000 utterances x 1002 raw frames): kernel time, and 100
+    utterances of each mode's output for the float64 oracle (SURVEY.md 8d gate: 1e-3 max / 1e-5 mean after CMVN).  What the float64
+    spectrum costs and buys, in the driver-visible record."""
+    from speaker_recognition_amd.core import Batch, MfccExtractor
+    cat, off = make_pcm(base[:CFG1_MODELS], CFG1_UTTS, 0)
+    pcm = Batch.from_pcm((cat, off))
+    out = {"workload": "configs[1] audio: %d utterances x %d frames, 25/10 ms, FFT 2048, 13 MFCC + delta + delta-delta" % (CFG1_UTTS, FRAMES_PER_UTT)}
+    n100 = 100
+    for mode, name in ((0, "fp32"), (2, "float64_spectrum")):
+        _lib.set_option("mfcc_precision", mode)
+        try:
+            ex = MfccExtractor(FS, **MFCC_KW)
+            ex.extract_batch(pcm, nd=ND)
+            ts = []
+            for _ in range(5):
+                _lib.profile_reset()
+                ex.extract_batch(pcm, nd=ND)
+                _lib.synchronize()
+                ts.append(_lib.profile_get(_lib.T_MFCC)[0])
+            fb = ex.extract_batch(Batch.from_pcm((cat[:off[n100]], off[:n100 + 1])), nd=ND)
+            preq["mfcc_mode_" + name] = {"kind": "mfcc", "pcm": cat[:off[n100]], "sample_offsets": off[:n100 + 1], "fs": FS, "mfcc_kw": MFCC_KW,
+                                         "nd": ND, "device_feats": fb.download(), "offsets": fb.offsets()}
+            out[name] = {"mfcc_kernel_ms": float(np.median(ts)), "frames_per_s": CFG1_UTTS * (FRAMES_PER_UTT + ND) / (float(np.median(ts)) * 1e-3)}
+        finally:
+            _lib.set_option("mfcc_precision", 2)
+    out["float64_over_fp32_time"] = out["float64_spectrum"]["mfcc_kernel_ms"] / out["fp32"]["mfcc_kernel_ms"]
+    return out
+
+
 def block_cfg2_from_host(_lib, gm, cat, off, sums_resident, arg_resident):
     """The headline's step with the PCM handed over in HOST memory on every call (what the C-ABI boundary does for a caller that owns
     its audio): sr_multi_predict_pcm on one slot, page-locked caller memory, uploads in pieces overlapped with the kernels."""
@@ -1204,6 +1234,7 @@ def main():
                          ("sr_multi_predict_pcm_host_pcm", lambda: block_multi_slot(_lib, ex, base)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq)),
                          ("north_star_literal_vector_alu", lambda: block_vector_alu(_lib, hbm)),
+                         ("mfcc_precision_modes", lambda: block_mfcc_precision(_lib, base, preq)),
                          ("configs[0]_end_to_end", lambda: block_cfg0(_lib))):
             if os.environ.get("SR_BENCH_BLOCKS") and name not in os.environ["SR_BENCH_BLOCKS"].split(","):
                 continue                                    # (experiments: a chosen subset of the blocks)
@@ -1224,6 +1255,10 @@ def main():
                     blocks[name]["parity"] = dict(blocks[name].get("parity") or {}, **v)
                 elif name == "configs[2]_headline":
                     result["parity"]["headline_200_utterances_x_all_models"] = v
+                elif name.startswith("mfcc_mode_"):
+                    if isinstance(blocks.get("mfcc_precision_modes"), dict) and name[len("mfcc_mode_"):] in blocks["mfcc_precision_modes"]:
+                        blocks["mfcc_precision_modes"][name[len("mfcc_mode_"):]]["vs_float64_oracle"] = {
+                            k: v.get(k) for k in ("utterances", "frames", "max_abs_diff_vs_oracle", "mean_abs_diff_vs_oracle")}
                 elif name.startswith("mfcc_"):
                     result["parity"][name] = v
                 elif name.endswith("_from_pcm"):

@@ -627,6 +627,28 @@ void put_flat_row(uint16_t *img, int ksteps, int i, const std::vector<uint16_t> 
 
 }  // namespace
 
+std::vector<WorkItem> pack_tail_tiles(const std::vector<int> &counts, int frames_per_tile, bool pack_tails) {
+    std::vector<WorkItem> work, packs;
+    work.reserve(counts.size());
+    int open_n = 4, open_cols = 0;                       // (no pack open)
+    for (int t = 0; t < (int)counts.size(); t++) {
+        const int c = counts[t];
+        if (!pack_tails || c >= frames_per_tile) {
+            work.push_back(WorkItem{{t, -1, -1, -1}});
+            continue;
+        }
+        if (open_n == 4 || open_cols + c > frames_per_tile) {
+            open_n = 0;
+            open_cols = 0;
+            packs.push_back(WorkItem{{-1, -1, -1, -1}});
+        }
+        packs.back().t[open_n++] = t;
+        open_cols += c;
+    }
+    work.insert(work.end(), packs.begin(), packs.end());
+    return work;
+}
+
 PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     PackedH2Shared pm;
     const GMM &g0 = *models[0];

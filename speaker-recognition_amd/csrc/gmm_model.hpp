@@ -160,6 +160,13 @@ struct PackedH2Shared {
     PackedSplit ref;
 };
 PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models);
+// Work items of the pipelined shared-sigma kernel over a table of tiles with `counts[t]` frames each (<= frames_per_tile): item =
+// {tile, tile or -1, tile or -1, tile or -1}.  Every FULL tile is an item of its own, in order; with `pack_tails` the ragged ones are
+// packed greedily, in order, up to four and up to frames_per_tile columns to an item, and all packed items come LAST (their waves
+// close several tiles per model block: together at the end of the grid they stay in step with each other, scattered they push their
+// workgroups out of phase with the others of their XCD and the parameter stream out of its L2).  Host-only: tests/host/host_checks.cpp.
+struct WorkItem { int t[4]; };
+std::vector<WorkItem> pack_tail_tiles(const std::vector<int> &counts, int frames_per_tile, bool pack_tails);
 bool models_share_sigma_and_weights(const std::vector<const GMM *> &models);
 PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models);
 void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts

@@ -1196,30 +1196,12 @@ namespace sr {
 void ensure_work_table(TileTable &tt, bool pack_tails) {
     if ((tt.n_work > 0 && tt.work_packed == pack_tails) || tt.n_tiles == 0) return;
     static_assert(sizeof(TileDesc) == sizeof(int4), "work items travel in the tile table's buffer");
-    // Full tiles first, in order; the packed items together at the END of the list: a wave with a packed item closes four tiles per
-    // block instead of one, its workgroup falls behind the others of its XCD at every block, and workgroups out of phase stop sharing
-    // the parameter stream in L2 (packed items scattered through the list: 11x the HBM-side fetches of the pass, FETCH_SIZE 1.2e7 ->
-    // 1.4e8 KiB, and a third of the gain gone at 10 M frames).  Together at the end they are in step with each other.
-    std::vector<int4> work, packs;
-    work.reserve(tt.h_tiles.size() + 96);
-    int open_n = 4, open_cols = 0;                       // (no pack open)
-    for (int t = 0; t < tt.n_tiles; t++) {
-        const int c = tt.h_tiles[t].count;
-        if (!pack_tails || c >= tt.frames_per_tile) {
-            work.push_back(make_int4(t, -1, -1, -1));
-            continue;
-        }
-        if (open_n == 4 || open_cols + c > tt.frames_per_tile) {
-            open_n = 0;
-            open_cols = 0;
-            packs.push_back(make_int4(-1, -1, -1, -1));
-        }
-        int4 &w = packs.back();
-        (open_n == 0 ? w.x : open_n == 1 ? w.y : open_n == 2 ? w.z : w.w) = t;
-        open_n++;
-        open_cols += c;
-    }
-    work.insert(work.end(), packs.begin(), packs.end());
+    // (pack_tail_tiles, gmm_model.cpp: full tiles in order, the packed items together at the end of the list)
+    std::vector<int> counts(tt.h_tiles.size());
+    for (size_t t = 0; t < counts.size(); t++) counts[t] = tt.h_tiles[t].count;
+    const std::vector<WorkItem> items = pack_tail_tiles(counts, tt.frames_per_tile, pack_tails);
+    std::vector<int4> work(items.size());
+    for (size_t i = 0; i < items.size(); i++) work[i] = make_int4(items[i].t[0], items[i].t[1], items[i].t[2], items[i].t[3]);
     tt.n_work = (int)work.size();
     tt.work_packed = pack_tails;
     work.resize(((work.size() + 95) / 96) * 96, make_int4(-1, -1, -1, -1));      // whole rounds of 8 workgroups x 12 waves

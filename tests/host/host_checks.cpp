@@ -148,11 +148,57 @@ static int check_numbers(int n) {
     return 0;
 }
 
+// pack_tail_tiles: every tile exactly once; full tiles alone and in order; packs of <= 4 tiles and <= 32 columns, all behind the full ones
+static int check_tail_packing() {
+    std::mt19937 rng(5);
+    for (int round = 0; round < 200; round++) {
+        const int n = (int)(rng() % 400);
+        std::vector<int> counts(n);
+        for (int &c : counts) c = (rng() % 3 == 0) ? 1 + (int)(rng() % 31) : 32;
+        if (round == 0) counts.assign(64, 8);                          // only tails: 16 packs of 4
+        if (round == 1) counts.assign(10, 32);                         // no tails
+        for (int pack = 0; pack < 2; pack++) {
+            const auto items = pack_tail_tiles(counts, 32, pack != 0);
+            std::vector<int> seen(counts.size(), 0);
+            bool in_packs = false;
+            int last_full = -1;
+            for (const auto &it : items) {
+                int cols = 0, members = 0;
+                for (int p = 0; p < 4; p++) {
+                    if (it.t[p] < 0) continue;
+                    if (p > 0 && it.t[p - 1] < 0) return 1;               // members are packed to the front
+                    if (it.t[p] >= (int)counts.size()) return 2;
+                    seen[it.t[p]]++;
+                    cols += counts[it.t[p]];
+                    members++;
+                }
+                if (members == 0 || cols > 32) return 3;
+                const bool is_pack = pack && counts[it.t[0]] < 32;
+                if (!is_pack) {
+                    if (members != 1 || in_packs) return 4;               // a full tile after a pack, or sharing its wave
+                    if (it.t[0] <= last_full) return 5;
+                    last_full = it.t[0];
+                } else {
+                    in_packs = true;
+                    for (int p = 0; p < members; p++)
+                        if (counts[it.t[p]] >= 32) return 6;
+                }
+            }
+            for (int v : seen)
+                if (v != 1) return 7;
+            if (!pack && items.size() != counts.size()) return 8;
+        }
+        if (round == 0 && pack_tail_tiles(counts, 32, true).size() != 16) return 9;
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const bool big = argc > 1 && std::strcmp(argv[1], "threads") == 0;     // sizes at which the packers go multi-threaded
     int rc = big ? check_packers(150, 1024, 39) : (check_packers(17, 37, 13) | check_packers(31, 64, 39));
     if (rc) return printf("packers: %d\n", rc), 10 + rc;
     if (!big) {
+        if ((rc = check_tail_packing())) return printf("tail packing: %d\n", rc), 40 + rc;
         if ((rc = check_parser(20000))) return printf("parser: %d\n", rc), 20 + rc;
         if ((rc = check_numbers(300000))) return printf("numbers: %d\n", rc), 30 + rc;
     }
