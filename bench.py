@@ -23,9 +23,13 @@ GPU's NUMA node.  At N > 1 the line also carries the weak-scaling efficiency aga
 step ALONE in the same run, the configs[3] strong-scaling split, and the ONE-process path over the N devices
 (sr_multi_predict_pcm from page-locked host PCM).
 
-Beside the headline the JSON line carries a `configs` block (N = 1 only, outside the timed region):
-configs[1], a stated sub-sample of one rank's configs[3] shard, configs[4] latencies, and the
-256-mixture x 39-dim point of BASELINE.json's north_star, each with its own roofline and parity sample.
+Beside the headline the full record (bench_blocks.json) carries a `configs` block (N = 1 only, outside the timed region):
+configs[0] end to end through the CLI surface with the reference's C++ + numpy MFCC timed beside it, configs[1], one rank's
+configs[3] shard in full, configs[4] latencies, the 256-mixture x 39-dim point of BASELINE.json's north_star on the matrix
+cores and on north_star's literal vector-ALU path, the feature stage in both precision modes, the headline from HOST PCM,
+serving-size batches, a set trained on the device, the reference's published EM benchmark, the legacy ABI's per-speaker loop --
+each with its own roofline and a parity sample checked by oracle/parity_check.py on all host cores (per frame on the device's
+own features AND end to end from PCM against the float64 feature oracle).
 
 oracle/ is never imported by this process: the CPU baseline (oracle/cpu_baseline.py) and the parity
 samples (oracle/parity_check.py) run as subprocesses, outside every timed region, as checkers.
