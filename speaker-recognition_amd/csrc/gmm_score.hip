@@ -1168,6 +1168,14 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
             n_flush = st.oor.p[1];
             if (n_flush > r.flush_cap) fail("partial-product band: %d (tile, model) pairs noted, list of %d", n_flush, r.flush_cap);
         }
+        if (!fll_n && sums_out && argmax_out && U) {
+            // Sums and argmax are already here: complete the HOST copies (one more wait for the tiles' exact sums; what sr_multi's
+            // pieces do) instead of patching the device's and copying everything a second time -- two waits, two uploads, two
+            // kernels and a copy of all U x S sums less per call.
+            // The device-resident sums stay unpatched: nobody reads them after this call.
+            flush_resolve_host(set, feat, *r.tiles, r.d_flush_list, n_flush, st.sums.p, const_cast<int *>(h_argmax));
+            break;
+        }
         flush_resolve(set, feat, *r.tiles, r.d_flush_list, n_flush, const_cast<double *>(r.d_sums),
                       const_cast<int *>(r.d_argmax), const_cast<float *>(r.d_frame_ll));
         r.d_flush_count = nullptr;          // resolved: copy the patched results out
