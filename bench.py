@@ -869,6 +869,7 @@ def compact(result, blocks_file=None):
     line = {
         "metric": result.get("metric"), "value": _r(result.get("value"), 7), "unit": result.get("unit"),
         "n_gpus": result.get("n_gpus"), "steps": result.get("steps"), "warmup": result.get("warmup"),
+        "frames_per_s_per_gpu": _r(result.get("frames_per_s_per_gpu"), 7),
         "ms_per_step": _r(result.get("ms_per_step"), 6), "higher_is_better": True, "scaling": result.get("scaling"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: 16 kHz PCM -> 39-dim MFCC+d+dd, 512-mix UBM + 200 MAP speakers, %s M frames/GPU"
