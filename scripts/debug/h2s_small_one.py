@@ -15,8 +15,6 @@ ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + [synth.synth_map_speaker(ubm
 _lib.profile_enable(True)
 _lib.set_option("score_h2s_shape", shape)
 _lib.set_option("score_model_groups", groups)
-if os.environ.get("SR_GM") is not None:
-    _lib.set_option("score_h2s_group_major", int(os.environ["SR_GM"]))          # launch order of the model groups (1 = group-major)
 for U in Us:
     feats = Batch.from_features([synth.draw_frames(ubm, 300, 10 + u) for u in range(U)])
     ts, tr = [], []
