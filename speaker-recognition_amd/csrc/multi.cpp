@@ -186,7 +186,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         const int want = MULTI_DEFAULT_PIECES;
         // Copy and kernels take about the same time on this path (configs[1]: 5.6 and 5.3 ms), so the call ends at about
         // copy(everything) + kernels(last piece): equal pieces, enough of them that the last one is short and few enough that
-        // the per-piece launches do not add up (scripts/debug/multi_pieces_sweep.py, page-locked PCM: 1 piece 11.3 ms, 2 8.7,
+        // the per-piece launches do not add up (round 4's sweep, HISTORY.md section 5; page-locked PCM: 1 piece 11.3 ms, 2 8.7,
         // 4 7.5, 6 7.2, 8 7.25; a small-first / small-last shape, round 4's first attempt, 7.7)
         const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, U), total / ((int64_t)1 << 20)));
         for (int c = 0; c < MULTI_CHUNKS; c++) {
