@@ -55,6 +55,7 @@ MFCC_KW = dict(win_length_ms=25, win_shift_ms=10)      # cfg-0 framing; FFT 2048
 ND = 2                                                  # 13 -> 39 dims
 DIM = 39
 FRAMES_PER_UTT = 1000
+MFCC_PRECISION = 2                                      # sr_set_option("mfcc_precision"): 2 = float64 spectrum / ln / DCT (the library's default), 0 = fp32
 CFG2_SPEAKERS, CFG2_MIX, CFG2_UTTS = 200, 512, 10000
 CFG1_MODELS, CFG1_MIX, CFG1_UTTS = 100, 64, 1000
 AUDIO_SEED, MODEL_SEED = 2000, 7
@@ -405,6 +406,7 @@ def block_cfg3(_lib, hbm, preq, world=1, rank=0, barrier=None, total_frames=CFG3
     from speaker_recognition_amd.core import Batch, ModelSet
     from speaker_recognition_amd.pygmm import GMM
     S, K, T = CFG3_S, CFG3_K, FRAMES_PER_UTT
+    t_block = time.perf_counter()
     n_ranks = world if world > 1 else 8
     U = total_frames // T // n_ranks
     ubm, spk = cfg3_models()
@@ -429,7 +431,7 @@ def block_cfg3(_lib, hbm, preq, world=1, rank=0, barrier=None, total_frames=CFG3
     out = {"workload": "BASELINE.json configs[3]: 2048-mixture UBM + 1000 MAP speakers (all 1001 models), rank %d of %d: %d utterances x %d "
                        "frames = %d of the job's 100 M frames, IN FULL (features drawn from the models, 0.1 %% outliers; %d distinct "
                        "utterances repeated to the shard's size)" % (rank, n_ranks, U, T, n, distinct),
-           "frames": n, "frames_per_s": n / el, "s_per_pass": el, "model_pack_upload_s": t_pack,
+           "frames": n, "frames_per_s": n / el, "s_per_pass": el, "model_pack_upload_s": t_pack, "block_wall_s": time.perf_counter() - t_block,
            "roofline": score_roofline(kname, n, S + 1, K, DIM, (ms_k + ms_r) / max(1, n_k) * 1e-3, hbm),
            "parity": {"own_speaker_wins": bool(np.array_equal(np.argmax(sums[:, 1:], axis=1), (first + np.arange(U) % distinct) % S))}}
     if preq is not None:
@@ -871,9 +873,11 @@ def compact(result, blocks_file=None):
         "n_gpus": result.get("n_gpus"), "steps": result.get("steps"), "warmup": result.get("warmup"),
         "frames_per_s_per_gpu": _r(result.get("frames_per_s_per_gpu"), 7),
         "ms_per_step": _r(result.get("ms_per_step"), 6), "higher_is_better": True, "scaling": result.get("scaling"),
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[2]: 16 kHz PCM -> 39-dim MFCC+d+dd, 512-mix UBM + 200 MAP speakers, %s M frames/GPU"
-                               % _r((cfg.get("frames_per_gpu") or 0) / 1e6, 4),
+        "vs_baseline": result.get("vs_baseline"), "dtype": str(result.get("dtype") or "").split(" ")[0][:8], "data": result.get("data", "synthetic"),
+        "config": {"workload": "%s: 16 kHz PCM -> %s-dim MFCC+d+dd, %s-mix UBM + %s MAP speakers, %s M frames/GPU"
+                               % ("configs[2]" if (cfg.get("frames_per_gpu"), cfg.get("models"), cfg.get("mixtures")) ==
+                                  (CFG2_UTTS * FRAMES_PER_UTT, CFG2_SPEAKERS + 1, CFG2_MIX) else "configs[2] shape, non-default size",
+                                  cfg.get("dim"), cfg.get("mixtures"), (cfg.get("models") or 1) - 1, _r((cfg.get("frames_per_gpu") or 0) / 1e6, 4)),
                    "frames_per_gpu": cfg.get("frames_per_gpu"), "models": cfg.get("models"), "mixtures": cfg.get("mixtures"),
                    "dim": cfg.get("dim"), "sharding": "utterances, no collective"},
         "roofline": {"kernel": str(rf.get("kernel", ""))[:48], "bound": rf.get("bound"), "achieved": _r(rf.get("achieved")),
@@ -898,9 +902,18 @@ def compact(result, blocks_file=None):
         line["scaling_efficiency_vs_rank0_alone"] = _r(result.get("scaling_efficiency_vs_rank0_alone"), 4)
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > COMPACT_LIMIT:                          # cannot happen with the fields above; never let it break the driver
-        for k in ("parity", "from_host_pcm_ms_per_step", "mfcc_ms_per_step", "blocks_file"):
+        for k in ("parity", "from_host_pcm_ms_per_step", "mfcc_ms_per_step", "blocks_file", "clock"):
             line.pop(k, None)
         text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:                          # still too long: some string came in far wider than any this script writes
+        def clip(o, n):
+            if isinstance(o, dict):
+                return {k: clip(v, n) for k, v in o.items()}
+            return o[:n] if isinstance(o, str) else o
+        for n in (64, 24, 8):
+            text = json.dumps(clip(line, n), separators=(",", ":"))
+            if len(text) <= COMPACT_LIMIT:
+                break
     return text
 
 
@@ -918,7 +931,13 @@ def emit(result, blocks_file):
 
 
 # ------------------------------------------------------------------ main
+def peak_rss_mb():
+    import resource
+    return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0
+
+
 def main():
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -972,6 +991,7 @@ def main():
         sys.exit("bench.py: rank %d wants device %d but only %d visible" % (rank, dev, _lib.device_count()))
     _lib.set_device(dev)
     numa_node = _lib.bind_thread_near_device(dev)          # this rank's host thread next to its GPU's PCIe root (-1: platform does not say)
+    _lib.set_option("mfcc_precision", MFCC_PRECISION)
     ex = MfccExtractor(FS, **MFCC_KW)
     L, shift = ex.FRAME_LEN, ex.FRAME_SHIFT
     n_samples = (FRAMES_PER_UTT + ND - 1) * shift + L
@@ -1000,6 +1020,7 @@ def main():
         _lib.host_register(o[0])
     step = lambda i: ex.predict_batch(ms, pcm, nd=ND, out=outs[i & 1])
     _lib.profile_enable(True)      # HIP-event kernel timers (pre-warms the runtime's event pool once)
+    setup_s = time.perf_counter() - t_start        # process start -> workload resident, models packed (per rank; host-side, outside every timed region)
     for i in range(args.warmup):
         step(i)
     # N > 1: rank 0 runs the same step ALONE first (the others wait), so that the line carries its own weak-scaling reference
@@ -1026,10 +1047,10 @@ def main():
     rank_rate = n_frames * args.steps / elapsed
     if grp is not None:
         elapsed = grp.all_max(elapsed)
-        info = grp.all_gather({"rate": rank_rate, "device": dev, "numa_node": numa_node})
+        info = grp.all_gather({"rate": rank_rate, "device": dev, "numa_node": numa_node, "setup_s": setup_s, "peak_rss_mb": peak_rss_mb()})
         rates = [v["rate"] for v in info]
     else:
-        info = [{"rate": rank_rate, "device": dev, "numa_node": numa_node}]
+        info = [{"rate": rank_rate, "device": dev, "numa_node": numa_node, "setup_s": setup_s, "peak_rss_mb": peak_rss_mb()}]
         rates = [rank_rate]
     kt = kernel_times(_lib, args.steps)
     kname = _lib.last_score_kernel()
@@ -1045,7 +1066,8 @@ def main():
             del pcm
             mine = block_cfg3(_lib, None, None, world, rank, barrier, args.cfg3_total_frames)
             wall = grp.all_max(mine["s_per_pass"])
-            per_rank = grp.all_gather({"frames": mine["frames"], "s_per_pass": mine["s_per_pass"], "own_speaker_wins": mine["parity"]["own_speaker_wins"]})
+            per_rank = grp.all_gather({"frames": mine["frames"], "s_per_pass": mine["s_per_pass"], "own_speaker_wins": mine["parity"]["own_speaker_wins"],
+                                       "block_wall_s": mine["block_wall_s"], "peak_rss_mb": peak_rss_mb()})
             strong = {"workload": "BASELINE.json configs[3] at its stated size: 2048-mixture UBM + 1000 MAP speakers, 100 M frames split by utterance "
                                   "over %d ranks (strong scaling; models replicated; no collective on the data path)" % world,
                       "frames_total": sum(p["frames"] for p in per_rank), "stated_frames": CFG3_TOTAL_FRAMES, "n_gpus": world, "wall_s": wall,
@@ -1089,8 +1111,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (operands split exactly into 2 fp16 parts, 3 part products on the fp16 matrix cores, fp32 accumulate; "
-                 "MFCC in fp32, CMVN statistics in f64)",
+        "dtype": "f32 (scoring: fp32 operands split exactly into 2 fp16 parts, 3 part products on the fp16 matrix cores, fp32 accumulate; "
+                 "MFCC: %s; CMVN statistics and per-utterance sums in f64)"
+                 % ("float64 spectrum / ln / DCT" if MFCC_PRECISION == 2 else "fp32"),
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]: 16 kHz synthetic PCM -> 13 MFCC (25/10 ms, FFT 2048, 50 filters) + CMVN + "
                                "delta + delta-delta = 39 dims; 512-mixture diagonal UBM + %d speaker GMMs MAP-style adapted from it (SURVEY.md 8d's "

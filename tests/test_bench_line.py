@@ -54,3 +54,23 @@ def test_compact_line_survives_missing_blocks():
                           "scaling": "weak", "cpu_baseline": {"error": "x" * 5000}, "roofline": {"kernel": "k" * 5000}})
     assert len(text) <= bench.COMPACT_LIMIT
     json.loads(text)
+
+
+def test_compact_line_names_the_run_it_describes():
+    """workload / dtype come from the record, not from literals: a run at another size is not labelled as configs[2] at its stated size"""
+    bench = _bench()
+    rec = {"metric": "frames/sec scored (MFCC+GMM)", "value": 1.0, "unit": "frames/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+           "scaling": "weak", "dtype": "f32 (split fp16 ...)", "data": "synthetic",
+           "config": {"frames_per_gpu": 10_000_000, "models": 201, "mixtures": 512, "dim": 39}}
+    line = json.loads(bench.compact(rec))
+    assert line["dtype"] == "f32" and line["config"]["workload"].startswith("configs[2]: ")
+    assert "512-mix UBM + 200 MAP speakers, 10.0 M frames/GPU" in line["config"]["workload"]
+    rec["config"]["frames_per_gpu"] = 200_000
+    line = json.loads(bench.compact(rec))
+    assert "non-default size" in line["config"]["workload"] and "0.2 M frames/GPU" in line["config"]["workload"]
+    # strings far wider than anything the script writes are cut, the line stays parseable and short
+    rec["metric"] = "m" * 4000
+    rec["unit"] = "u" * 4000
+    text = bench.compact(rec)
+    assert len(text) <= bench.COMPACT_LIMIT
+    json.loads(text)
