@@ -13,9 +13,9 @@ else
   CMD="python bench.py $ARGS"
 fi
 echo "$CMD" >> $O/r06_n8_wall.txt
-S=$(date +%s.%N)
+SECONDS=0
 timeout ${REHEARSE_TIMEOUT:-1500} $CMD > $O/r06_n8_line.json 2> $O/r06_n8_err.txt < /dev/null
-echo "rc $? wall_s $(echo "$(date +%s.%N) - $S" | bc)" >> $O/r06_n8_wall.txt
+echo "rc $? wall_s $SECONDS" >> $O/r06_n8_wall.txt
 cat $O/r06_n8_wall.txt
 tail -c 1600 $O/r06_n8_line.json
 grep -v '^{' $O/r06_n8_err.txt | tail -5 | cut -c1-300

@@ -382,7 +382,7 @@ struct ScoreWorkspace {
     DevBuf<float> frame_ll;
     DevBuf<float> ref_ll;                // split-fp16 shared-sigma engine: the reference model's per-frame LL
     DevBuf<double> ref_partial;
-    DevBuf<int> exc_list;                // ... and its (tile, block) exception list
+    DevBuf<int> exc_list;                // ... and its exception lists ({tile, listed frames} per block) + the exception pass's plan
     DevBuf<float> hy_a, hy_b;            // hybrid sets: per-frame LL of the two sub-sets
     DevBuf<int2> flush_list;             // (tile, model) pairs in the partial-product band (lse.hpp, gmm_flush.hip)
     size_t flush_min_cap = 0;            // set after an overflow: the next pass gets a list of that length
@@ -784,7 +784,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
 
     auto &w = ws();
     bool used_oor = false;
-    const size_t n_counters = 4 + set.h2s.blocks.size();
+    const size_t n_counters = 4 + 2 * set.h2s.blocks.size();      // (shared-sigma engine: exception entries and items per block)
     w.counters.ensure(n_counters);
     SR_HIP(hipMemsetAsync(w.counters.p, 0, n_counters * sizeof(int), ctx().stream));     // the pass's counters, all at once
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
@@ -898,7 +898,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
                 launch_score_split(r, SPLIT_F16X1, h.ref.ks, 1);
             }
             const int n_blocks = (int)h.blocks.size();
-            w.exc_list.ensure((size_t)std::max(1, tt.n_tiles) * n_blocks);
+            w.exc_list.ensure((size_t)std::max(1, tt.n_tiles) * n_blocks * 2 + (size_t)(std::max(1, tt.n_tiles) + 1) * n_blocks);
             H2sLaunch a;
             a.X = feat.data.p;
             a.tiles = tt.d_tiles.p;

@@ -122,8 +122,10 @@ struct H2sArgs {
     double *partial;
     float *frame_ll;
     int *oor_flag;
-    int *exc_list;                // the ONLINE pass's work: per block, the tiles the offset form could not vouch for ([n_blocks][n_tiles])
-    int *exc_count;               // ... and how many of them ([n_blocks])
+    int2 *exc_list;               // the ONLINE pass's work: per block, {tile, mask of the COLUMNS (frames) the offset form could not vouch for}
+                                  // ([n_blocks][n_tiles]); behind it the plan of the pass: int [n_blocks][n_tiles + 1], entry index at which
+                                  // each wave's item starts (h2s_plan_kernel)
+    int *exc_count;               // ... how many entries ([n_blocks]), and behind them the number of items per block ([n_blocks])
     int n_blocks;
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
@@ -158,11 +160,14 @@ __device__ __forceinline__ bool h2s_wg_assignment(const H2sArgs &a, int tiles_wg
 }
 
 // Close of one block's models for one 32-frame tile (both main kernels): the offset form is only trusted well inside fp32's
-// exponent range and well above the reference's underflow boundary; a tile with a frame outside goes to the exception list
-// (decided per tile of ONE utterance, so an utterance's results do not depend on the batch around it), the others leave one
-// partial per model: a fixed-order float64 sum over the wave's lanes.
+// exponent range and well above the reference's underflow boundary.  A FRAME outside (for any model of the block) is left out
+// of the tile's partials and its column is listed -- {tile, column mask} on the block's exception list (round 6; through round 5
+// the whole tile went: at configs[3]'s 0.1 % outlier frames 3.1 % of the tiles re-scored in full, 0.37 s of a 6.2 s pass);
+// the other frames leave one partial per model: a fixed-order float64 sum over the wave's lanes, to which the exception pass
+// adds the listed frames' values.  A frame's fate depends on that frame alone, so an utterance's results do not depend on the
+// batch around it.
 // MS (round 4, the model-split shape of small batches): the workgroup's four waves hold the SAME tile and every fourth model of
-// the block each; the tile's fate is decided by all of them together (through `s_bad` in LDS), wave 0 reports it.
+// the block each; the columns' fate is decided by all of them together (through `s_bad` in LDS), wave 0 reports it.
 template <bool MS = false>
 __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBlock &sb, int blk, const float (&ssum)[SHARED_SB], float off,
                                                 bool valid, bool has, int tile_id, int64_t row, int lane, int hh, float safe_ll2,
@@ -177,28 +182,30 @@ __device__ __forceinline__ void h2s_close_block(const H2sArgs &a, const SharedBl
         const float ll2 = off + log2f(tot);
         ll_keep[si] = LSE_LN2 * ll2;
         const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
-        bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+        bad |= si < sb.n_models && !ok;
     }
-    bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;      // wave-uniform
+    bad = valid && (bad || a.force_exc);
+    // the frames (columns) of this tile that go to the exception pass: both half-waves hold the same columns and agree on them
+    unsigned bad_cols = (unsigned)__builtin_amdgcn_ballot_w64(bad);           // wave-uniform
     if constexpr (MS) {
-        if (any_bad && lane == 0) atomicOr(s_bad, 1);
+        if (bad_cols != 0 && lane == 0) atomicOr(s_bad, (int)bad_cols);
         __syncthreads();
-        any_bad = *reinterpret_cast<volatile int *>(s_bad) != 0;
+        bad_cols = (unsigned)*reinterpret_cast<volatile int *>(s_bad);
         __syncthreads();                               // everybody has read it
         if (threadIdx.x == 0) *s_bad = 0;              // (for the next block: published by the barrier at its top)
+        bad = (bad_cols >> (lane & 31)) & 1u;
     }
-    if (any_bad) {
-        if (lane == 0 && has && (!MS || wave == 0)) {
-            const int idx = atomicAdd(a.exc_count + blk, 1);          // (a tile meets a block once: idx < n_tiles)
-            a.exc_list[(size_t)blk * a.n_tiles + idx] = tile_id;
-        }
-        return;
+    if (bad_cols != 0 && lane == 0 && has && (!MS || wave == 0)) {
+        const int idx = atomicAdd(a.exc_count + blk, 1);          // (a tile meets a block once: idx < n_tiles)
+        a.exc_list[(size_t)blk * a.n_tiles + idx] = make_int2(tile_id, (int)bad_cols);
     }
+    // the other frames' values stand: one partial per model, a fixed-order float64 sum over the wave's lanes (the exception pass
+    // adds the listed frames' values to it)
 #pragma unroll
     for (int si = 0; si < SB; si++) {
         if (MS && (si & 3) != wave) continue;
         double mine = 0.0;
-        if (valid && hh == 0 && si < sb.n_models) {
+        if (valid && !bad && hh == 0 && si < sb.n_models) {
             mine = (double)ll_keep[si];
             if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll_keep[si];
         }
@@ -246,21 +253,19 @@ __device__ __forceinline__ void h2s_close_block_packed(const H2sArgs &a, const S
         const float ll2 = off + log2f(tot);
         ll_keep[si] = LSE_LN2 * ll2;
         const bool ok = tot >= H2S_SUM_LO && tot <= H2S_SUM_HI && ll2 >= safe_ll2;
-        bad |= (valid && si < sb.n_models && !ok) || a.force_exc;
+        bad |= si < sb.n_models && !ok;
     }
-    const uint64_t bad_mask = __builtin_amdgcn_ballot_w64(bad);
+    bad = valid && (bad || a.force_exc);
+    const unsigned bad_cols = (unsigned)__builtin_amdgcn_ballot_w64(bad);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         if (p >= n_seg) break;                                          // wave-uniform
-        const uint64_t seg_mask = __builtin_amdgcn_ballot_w64(seg == p);
-        if ((bad_mask & seg_mask) != 0) {
-            if (lane == 0 && has) {
-                const int idx = atomicAdd(a.exc_count + blk, 1);
-                a.exc_list[(size_t)blk * a.n_tiles + idx] = tids[p];
-            }
-            continue;
+        const unsigned seg_cols = (unsigned)__builtin_amdgcn_ballot_w64(seg == p);
+        if ((bad_cols & seg_cols) != 0 && lane == 0 && has) {           // the segment's listed frames, as columns of ITS tile
+            const int idx = atomicAdd(a.exc_count + blk, 1);
+            a.exc_list[(size_t)blk * a.n_tiles + idx] = make_int2(tids[p], (int)((bad_cols & seg_cols) >> first_col[p]));
         }
-        const bool mine_seg = valid && hh == 0 && seg == p;
+        const bool mine_seg = valid && !bad && hh == 0 && seg == p;
 #pragma unroll
         for (int si = 0; si < SB; si++) {
             double mine = 0.0;
@@ -911,12 +916,56 @@ void gmm_score_h2p_kernel(const H2sArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-// The exception pass: the (32-frame tile, block) pairs the main pass listed, classic online log-sum-exp with the reference's
-// underflow semantics (lse.hpp).  Round 4: a 4-wave workgroup takes four tiles of ONE block's list (the lists are per block) and
-// streams that block's images through LDS once for all four, as the main kernel does -- through round 3 a lone wave per pair
-// fetched its images straight from L2, 8 KB per image and wave, and the pass ran at the L2's bandwidth: 1.0 s of the configs[3]
-// block's 6.9 s at that block's 0.1 % outlier frames.  Results unchanged bit for bit: a (frame, model) value is formed by one lane
-// over the mixture tiles in order, as before.
+// The exception pass (gmm.cc:34-38, :237-244 semantics: lse.hpp): the FRAMES the main pass listed, classic online log-sum-exp with
+// the reference's underflow rule.  Round 4: a 4-wave workgroup streams ONE block's images through LDS once for its four waves, as
+// the main kernel does (through round 3 a lone wave fetched its images straight from L2 and the pass ran at the L2's bandwidth).
+// Round 6: the list holds {tile, column mask} and a wave's 32 columns take the listed frames of SEVERAL tiles side by side
+// (h2s_plan_kernel cuts a block's list into items of <= 32 frames; a tile's frames never straddle two items) -- configs[3]'s
+// shard lists 12 200 tiles per block with one or two frames each: 390 items instead of 12 200 whole tiles.
+//
+// What a (tile, model) partial is, whatever the packing: the main pass's fixed-order sum over the tile's unlisted frames, plus the
+// sum of the listed frames' values taken one by one in ascending column order (formed by the lane that owns the entry).  A (frame,
+// model) value is formed by one lane over the mixture tiles in order.  Neither depends on what a tile is packed with or where.
+__device__ __forceinline__ int *h2s_plan_starts(const H2sArgs &a, int blk) {
+    return reinterpret_cast<int *>(a.exc_list + (size_t)a.n_blocks * a.n_tiles) + (size_t)blk * (a.n_tiles + 1);
+}
+
+// One wave per block: walks the block's entries in list order and opens a new item whenever the next tile's frames do not fit the
+// current item's 32 columns.  starts[i] = first entry of item i, starts[n_items] = count; n_items behind the counts.
+__global__ __launch_bounds__(64)
+void h2s_plan_kernel(const H2sArgs a) {
+    const int blk = blockIdx.x, lane = threadIdx.x;
+    const int count = min(a.exc_count[blk], a.n_tiles);
+    int *starts = h2s_plan_starts(a, blk);
+    const int2 *list = a.exc_list + (size_t)blk * a.n_tiles;
+    int n_items = 0, fill = 32;                                 // (the first entry opens item 0)
+    for (int base = 0; base < count; base += 64) {
+        const int pop = base + lane < count ? __builtin_popcount((unsigned)list[base + lane].y) : 0;
+        const int n = min(64, count - base);
+        for (int i = 0; i < n; i++) {                           // wave-uniform: scalar arithmetic
+            const int p = __builtin_amdgcn_readlane(pop, i);
+            if (fill + p > 32) {
+                if (lane == 0) starts[n_items] = base + i;
+                n_items++;
+                fill = 0;
+            }
+            fill += p;
+        }
+    }
+    if (lane == 0) {
+        starts[n_items] = count;
+        a.exc_count[a.n_blocks + blk] = n_items;
+    }
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) {
+    union { double d; int i[2]; } x, y;
+    x.d = v;
+    y.i[0] = __shfl(x.i[0], src_lane);
+    y.i[1] = __shfl(x.i[1], src_lane);
+    return y.d;
+}
+
 template <int KQF, int KLF>
 __global__ __launch_bounds__(256, 2)
 void gmm_score_h2s_online_kernel(const H2sArgs a) {
@@ -936,8 +985,10 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
     const int hh = lane >> 5;
     const int gy = (int)gridDim.x / a.n_blocks;            // workgroups per block
     const int blk = (int)blockIdx.x / gy, y = (int)blockIdx.x - blk * gy;
-    const int count = min(a.exc_count[blk], a.n_tiles);
-    if (y * WAVES >= count) return;                         // (the usual case: nothing listed)
+    const int n_items = a.exc_count[a.n_blocks + blk];
+    if (y * WAVES >= n_items) return;                       // (the usual case: nothing listed)
+    const int *starts = h2s_plan_starts(a, blk);
+    const int2 *list = a.exc_list + (size_t)blk * a.n_tiles;
     const float near_thr = lse_near_threshold(a.clamp);
     const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const SharedBlock sb = a.blocks[blk];
@@ -957,22 +1008,43 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
         __syncthreads();
     };
     const int n_stage_total = a.n_mix_tiles * N_STAGES;
-    for (int chunk = y; chunk * WAVES < count; chunk += gy) {
-        const int e = chunk * WAVES + wave;
-        const bool has = e < count;                         // (a wave beyond the list shadows its last entry and stores nothing)
-        const int tile_id = a.exc_list[(size_t)blk * a.n_tiles + (has ? e : count - 1)];
-        const TileDesc tile = a.tiles[tile_id];
-        const bool valid = col < tile.count;
-        const int64_t row = tile.start + (valid ? col : 0);
+    for (int chunk = y; chunk * WAVES < n_items; chunk += gy) {
+        const int item = chunk * WAVES + wave;
+        const bool has = item < n_items;                    // (a wave beyond the plan shadows its last item and stores nothing)
+        const int it = has ? item : n_items - 1;
+        const int e0 = starts[it], n_ent = starts[it + 1] - e0;            // 1 .. 32 entries, <= 32 frames between them
+        // lane i < n_ent owns entry i: its tile, its listed columns, where they start among the wave's 32 columns
+        const int2 ent = lane < n_ent ? list[e0 + lane] : make_int2(0, 0);
+        const int pop = __builtin_popcount((unsigned)ent.y);
+        int incl = pop;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int excl = incl - pop;
+        const int total = __shfl(incl, n_ent - 1);
+        // column c of the wave: the entry it belongs to, and which of that entry's listed frames it is
+        int my_e = 0;
+        for (int i = 1; i < n_ent; i++)                                     // wave-uniform trip count
+            if (col >= __shfl(excl, i)) my_e = i;
+        const bool valid = col < total;
+        const int my_tile = __shfl(ent.x, my_e);
+        unsigned m = (unsigned)__shfl(ent.y, my_e);
+        const int rank = col - __shfl(excl, my_e);
+        for (int r = 0; r < rank; r++) m &= m - 1;                          // drop the `rank` lowest listed columns
+        const int tcol = valid ? __builtin_ctz(m | 0x80000000u) : 0;
+        const TileDesc tile = a.tiles[my_tile];
+        const int64_t row = tile.start + tcol;
         f16x8 bq[1][KQF], bl[1][KLF];
         float zmax = 0.0f;
         h2s_build_b<KQF>(bq[0], a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
         h2s_build_b<KLF>(bl[0], a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
         if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
-        float m[SB], ssum[SB];
+        float mx[SB], ssum[SB];
 #pragma unroll
         for (int si = 0; si < SB; si++) {
-            m[si] = NEG_BIG;
+            mx[si] = NEG_BIG;
             ssum[si] = 0.0f;
         }
         uint4 fr[KM];
@@ -1015,26 +1087,36 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (img > 0) {
-                        lse_update16(acc[0], m[img - 1], ssum[img - 1], near_thr);
-                        asm volatile("" : "+v"(m[img - 1]), "+v"(ssum[img - 1]));
+                        lse_update16(acc[0], mx[img - 1], ssum[img - 1], near_thr);
+                        asm volatile("" : "+v"(mx[img - 1]), "+v"(ssum[img - 1]));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        // most listed frames a tile of this item has (wave-uniform)
+        int max_pop = pop;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) max_pop = max(max_pop, __shfl_xor(max_pop, o));
+        const unsigned own_cols = pop >= 32 ? 0xffffffffu : ((1u << pop) - 1u);
 #pragma unroll
         for (int si = 0; si < SB; si++) {
-            const float ll = lse_close2(m[si], ssum[si], other_half(m[si]), other_half(ssum[si]), a.clamp);
-            double mine = 0.0;
-            if (has && valid && hh == 0 && si < sb.n_models) {
-                mine = (double)ll;
-                if (a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll;
+            const float ll = lse_close2(mx[si], ssum[si], other_half(mx[si]), other_half(ssum[si]), a.clamp);
+            const bool live = has && valid && hh == 0 && si < sb.n_models;
+            const double v = live ? (double)ll : 0.0;
+            if (live && a.frame_ll) a.frame_ll[(int64_t)(sb.first_model + si) * a.n_frames + row] = ll;
+            const unsigned hot_cols = (unsigned)__builtin_amdgcn_ballot_w64(live && ll < a.band_hi);
+            // the owner of an entry adds its frames' values one by one, in ascending column order
+            double sum = 0.0;
+            for (int j = 0; j < max_pop; j++) {
+                const double t = shfl_f64(v, min(excl + j, 31));
+                if (j < pop) sum += t;
             }
-            const bool hot = valid && hh == 0 && si < sb.n_models && ll < a.band_hi;
-            mine = wave_sum_f64(mine);
-            if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
-            if (lane == 0 && has && si < sb.n_models)
-                a.partial[(int64_t)tile_id * a.n_models + sb.first_model + si] = mine;
+            if (has && lane < n_ent && si < sb.n_models) {
+                double *p = a.partial + (int64_t)ent.x * a.n_models + sb.first_model + si;
+                // (a frame in the band where the reference's partial products decide: the whole (tile, model) goes to gmm_flush.hip)
+                *p = ((hot_cols >> excl) & own_cols) != 0 ? SR_FLUSH_POISON : *p + sum;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1061,7 +1143,7 @@ static int launch_h2s(const H2sLaunch &l) {
     a.partial = l.partial;
     a.frame_ll = l.frame_ll;
     a.oor_flag = l.oor_flag;
-    a.exc_list = l.exc_list;
+    a.exc_list = reinterpret_cast<int2 *>(l.exc_list);
     a.exc_count = l.exc_count;
     a.n_blocks = l.n_blocks;
     a.n_frames = l.n_frames;
@@ -1117,8 +1199,10 @@ static int launch_h2s(const H2sLaunch &l) {
             hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES, MS>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
     }
     a.tile_base = 0;
-    // the exception pass: 4-wave workgroups over the per-block tile lists the main pass left (a couple of resident ones per block
-    // and CU's worth of the chip; with nothing listed -- the usual case -- they leave at once)
+    // the exception pass: the plan (one wave per block cuts its list into items of <= 32 listed frames), then 4-wave workgroups over
+    // the items (a couple of resident ones per block and CU's worth of the chip; with nothing listed -- the usual case -- they
+    // leave at once)
+    hipLaunchKernelGGL(h2s_plan_kernel, dim3((unsigned)l.n_blocks), dim3(64), 0, ctx().stream, a);
     const int gy = std::max(1, (2 * ctx().n_cu) / std::max(1, l.n_blocks));
     hipLaunchKernelGGL((gmm_score_h2s_online_kernel<KQF, KLF>), dim3((unsigned)(l.n_blocks * gy)), dim3(256), 0, ctx().stream, a);
     return n_launches;

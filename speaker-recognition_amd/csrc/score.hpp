@@ -91,8 +91,8 @@ struct H2sLaunch {
     float *frame_ll;
     int *oor_flag;
     int n_work = 0;     // pipelined shape: `tiles` is TileTable::d_tiles_work -- the tiles, then this many work items (+ padding)
-    int *exc_list;      // [n_blocks][n_tiles] tile ids
-    int *exc_count;     // [n_blocks]
+    int *exc_list;      // int2 [n_blocks][n_tiles] {tile, listed columns}, then int [n_blocks][n_tiles + 1] (the exception pass's plan)
+    int *exc_count;     // [n_blocks] entries, then [n_blocks] items
     int n_blocks;
     int64_t n_frames;
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
