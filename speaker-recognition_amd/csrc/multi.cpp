@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <deque>
 #include <numeric>
@@ -33,6 +34,7 @@ using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
 constexpr int MULTI_DEFAULT_PIECES = 6; // ... and in this many (6 equal pieces measured best: profiles/r04)
+constexpr double MULTI_GROWTH = 3.0;    // kernel-bound slots (run_slot): every piece this many times everything before it
 std::atomic<int> &multi_merge_option() {     // sr_set_option("multi_merge_same_device", 0 | 1)
     static std::atomic<int> v{1};
     return v;
@@ -68,6 +70,11 @@ struct SRMulti {
         std::string error;
         double seconds = 0.0;               // wall time of the slot's last pass
         int numa_node = -1;                 // where the slot's host thread was pinned (-1: nowhere)
+        // what the last passes told about this slot's work: device time per PCM byte against the link's time per byte (rho >= 1:
+        // the kernels are the longer leg) on a batch of rho_samples samples -- two passes in a row that agree change the shape of
+        // the next pass's pieces (run_slot): 0 = equal pieces, 1 = growing pieces
+        int schedule = 0, votes = 0;
+        int64_t rho_samples = 0;
     };
     std::unique_ptr<SRMfcc> mfcc;           // host tables shared; device tables per GPU inside
     std::deque<Slot> slots;                // (a slot owns page-locked buffers and events: not movable)
@@ -160,7 +167,8 @@ bool host_pinned(const void *p) {
 // flushes (lse.hpp) -- is noticed in the piece's flags afterwards and that piece is scored again, synchronously, from its
 // features, which are still on the device (as csrc/stream.cpp does for a serving tick).
 // The device's lock is taken piece by piece, so slots that share a GPU interleave on its stream.
-void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *off, int nd, int flags, bool pinned) {
+void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *off, int nd, int flags, bool pinned,
+              double *sums_out, int *argmax_out) {
     auto drain = [&]() {                   // nothing of this call may still be reading the caller's buffer when it returns
         try {
             (void)hipStreamSynchronize(ctx().copy);
@@ -178,8 +186,8 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         const int S = m->n_models;
         s.offsets.assign(U + 1, 0);
         for (int i = 0; i < U; i++) s.offsets[i + 1] = s.offsets[i] + (off[s.utts[i] + 1] - off[s.utts[i]]);
-        s.sums.assign((size_t)U * S, 0.0);
-        s.argmax.assign((size_t)U, -1);
+        if (!sums_out) s.sums.assign((size_t)U * S, 0.0);
+        if (!argmax_out) s.argmax.assign((size_t)U, -1);
         // piece boundaries: whole utterances, about equal sample counts; pieces of at least ~2 MB of PCM (smaller ones are
         // all launch overhead and kernel tails)
         const int64_t total = s.offsets[U];
@@ -188,12 +196,31 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // copy(everything) + kernels(last piece): equal pieces, enough of them that the last one is short and few enough that
         // the per-piece launches do not add up (round 4's sweep, HISTORY.md section 5; page-locked PCM: 1 piece 11.3 ms, 2 8.7,
         // 4 7.5, 6 7.2, 8 7.25; a small-first / small-last shape, round 4's first attempt, 7.7)
-        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, U), total / ((int64_t)1 << 20)));
+        //
+        // Round 6: equal pieces are right when copy and kernels are about as long.  When the kernels are the longer leg by a
+        // factor rho (configs[2]: 3.2 GB = 58 ms of link time under 280 ms of kernels, rho ~ 4.8) the only exposed copy is the
+        // FIRST piece's, and a piece may be rho times everything before it without the device ever waiting for its bytes:
+        // cumulative shares S_k = rho S_{k-1} + s_0, S_{n-1} = 1  =>  s_0 = (rho - 1) / (rho^n - 1).  Two shapes only (a new
+        // shape means new buffers and tables for every piece): equal pieces, and four pieces growing by MULTI_GROWTH = 3
+        // (2.5 / 7.5 / 22.5 / 67.5 %) once two passes in a row on a batch of about this size measured rho >= 3.5; back to equal
+        // pieces when two in a row measure < 2.5.  Pieces are whole utterances and an utterance's results do not depend on the batch
+        // around it: the bits are the same for any cut.
+        if (s.rho_samples > 0 && !(total > s.rho_samples / 2 && total < s.rho_samples * 2)) s.schedule = s.votes = 0;
+        const double rho = s.schedule ? MULTI_GROWTH : 1.0;
+        const int want_n = s.schedule ? 4 : want;
+        const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want_n, U), total / ((int64_t)1 << 20)));
+        double cum[MULTI_CHUNKS + 1];                    // cumulative shares S_k, cum[n_chunks] = 1
+        {
+            const double s0 = rho > 1.0 + 1e-9 ? (rho - 1.0) / (std::pow(rho, n_chunks) - 1.0) : 1.0 / n_chunks;
+            cum[0] = 0.0;
+            for (int c = 1; c <= n_chunks; c++) cum[c] = rho * cum[c - 1] + s0;
+            for (int c = 1; c <= n_chunks; c++) cum[c] = std::min(1.0, cum[c] / cum[n_chunks]);
+        }
         for (int c = 0; c < MULTI_CHUNKS; c++) {
             auto &ch = s.chunk[c];
             ch.u0 = ch.u1 = 0;
             if (c >= n_chunks) continue;
-            const int64_t lo = total * c / n_chunks, hi = total * (c + 1) / n_chunks;
+            const int64_t lo = (int64_t)((double)total * cum[c]), hi = (int64_t)((double)total * cum[c + 1]);
             ch.u0 = c == 0 ? 0 : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), lo) - s.offsets.begin());
             ch.u1 = c == n_chunks - 1 ? U : (int)(std::lower_bound(s.offsets.begin(), s.offsets.end(), hi) - s.offsets.begin());
             ch.u0 = std::min(ch.u0, U);
@@ -293,11 +320,34 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                     fetch_results(*s.set, ch.feat, fl | SCORE_PRECISE, r, ch.h_sums.p, ch.h_argmax.p, nullptr);
                 }
             }
-            std::memcpy(s.sums.data() + (size_t)ch.u0 * S, ch.h_sums.p, (size_t)nu * S * sizeof(double));
-            std::memcpy(s.argmax.data() + ch.u0, ch.h_argmax.p, (size_t)nu * sizeof(int));
+            // the piece's rows go straight to the caller's arrays (runs of neighbouring utterances as one copy)
+            for (int i = ch.u0; i < ch.u1;) {
+                int j = i;
+                while (j + 1 < ch.u1 && s.utts[j + 1] == s.utts[j] + 1) j++;
+                const size_t n = (size_t)(j + 1 - i), at = (size_t)(i - ch.u0);
+                if (sums_out) std::memcpy(sums_out + (size_t)s.utts[i] * S, ch.h_sums.p + at * S, n * S * sizeof(double));
+                else std::memcpy(s.sums.data() + (size_t)i * S, ch.h_sums.p + at * S, n * S * sizeof(double));
+                if (argmax_out) std::memcpy(argmax_out + s.utts[i], ch.h_argmax.p + at, n * sizeof(int));
+                else std::memcpy(s.argmax.data() + i, ch.h_argmax.p + at, n * sizeof(int));
+                i = j + 1;
+            }
         }
         SR_HIP(hipStreamSynchronize(ctx().copy));              // (pieces without utterances still queued their empty copies)
         s.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        // this pass's device time per byte against the link's (55 GB/s, what page-locked copies reach on this platform): everything
+        // but the first piece's upload is kernels when rho >= 1, and when it is not the estimate only has to stay below 1
+        if (total > 0 && n_chunks > 1) {
+            const double link_s = (double)total * sizeof(int16_t) / 55e9;
+            const double first = link_s * (double)(s.offsets[s.chunk[0].u1]) / (double)total;
+            const double rho_seen = std::max(0.0, s.seconds - first) / link_s;
+            const bool change = s.schedule ? rho_seen < 2.5 : rho_seen >= 3.5;
+            s.votes = change ? s.votes + 1 : 0;
+            if (s.votes >= 2) {
+                s.schedule ^= 1;
+                s.votes = 0;
+            }
+            s.rho_samples = total;
+        }
     } catch (const std::exception &e) {
         s.error = e.what();
         drain();
@@ -441,20 +491,13 @@ int sr_multi_predict_pcm(SRMulti *m, const int16_t *pcm, const int64_t *sample_o
                             host_pinned(pcm + sample_offsets[n_utt] - 1);
         std::vector<std::thread> th;
         for (auto &s : m->slots) s.error.clear();
-        for (auto *s : active) th.emplace_back(run_slot, m, std::ref(*s), pcm, sample_offsets, nd, flags, pinned);
+        // (every slot writes its utterances' rows into the caller's arrays itself: disjoint rows)
+        for (auto *s : active) th.emplace_back(run_slot, m, std::ref(*s), pcm, sample_offsets, nd, flags, pinned, sums_out, argmax_out);
         for (auto &t : th) t.join();
         for (auto &s : m->slots)
             if (!s.error.empty()) fail("device %d: %s", s.device, s.error.c_str());
-        const int S = m->n_models;
-        for (size_t k = 0; k < m->slots.size(); k++) {
-            const auto &s = m->slots[k];
-            for (size_t i = 0; i < s.utts.size(); i++) {
-                const int u = s.utts[i];
-                if (sums_out) std::memcpy(sums_out + (size_t)u * S, s.sums.data() + i * S, sizeof(double) * S);
-                if (argmax_out) argmax_out[u] = s.argmax[i];
-            }
-            if (slot_seconds_out) slot_seconds_out[k] = s.seconds;
-        }
+        for (size_t k = 0; k < m->slots.size(); k++)
+            if (slot_seconds_out) slot_seconds_out[k] = m->slots[k].seconds;
         return 0;
     } catch (const std::exception &e) {
         set_error("%s", e.what());
