@@ -894,6 +894,14 @@ def compact(result, blocks_file=None):
                    "frame_ll_from_pcm_max_rel": _r(pf.get("max_rel"), 3), "frame_ll_from_pcm_frames": pf.get("frames"),
                    "mfcc_max_abs": _r(mf.get("max_abs_diff_vs_oracle"), 3), "mfcc_mean_abs": _r(mf.get("mean_abs_diff_vs_oracle"), 3),
                    "steps_bit_identical": par.get("last_two_steps_bit_identical")},
+        # this box under its power cap (csrc/probe.hip): what the matrix pipe sustains with operands in registers / fed from LDS with
+        # random bits, the clock it holds meanwhile, and the scoring kernel's executed rate against the fed figure -- boxes differ by
+        # 3-6 %, this is what normalises them
+        "clock": {"mfma_sustained_tflops": _r((rf.get("sustained_mfma") or {}).get("executed_tflops"), 4),
+                  "mfma_streamed_tflops": _r((rf.get("sustained_mfma_streamed") or {}).get("executed_tflops"), 4),
+                  "mhz_sustained": _r((rf.get("sustained_mfma") or {}).get("clock_mhz"), 4),
+                  "mhz_streamed": _r((rf.get("sustained_mfma_streamed") or {}).get("clock_mhz"), 4),
+                  "kernel_over_streamed": _r((rf.get("sustained_mfma_streamed") or {}).get("frac_executed_of_sustained"), 3)},
         "from_host_pcm_ms_per_step": _r(result.get("from_host_pcm_ms_per_step")),
         "mfcc_ms_per_step": _r((result.get("kernel_ms_per_step") or {}).get("mfcc_frames")),
         "blocks_file": os.path.basename(blocks_file) if blocks_file else None,
@@ -1097,6 +1105,8 @@ def main():
     hbm = _lib.hbm_copy_gbps(1 << 30, 10)
     # what the matrix pipe sustains on this box under its power cap: a kernel of v_mfma_f32_32x32x16_f16 chains only (csrc/probe.hip)
     sustained = _lib.mfma_peak_probe(60.0)
+    # ... and on chains FED as the scoring kernel feeds them: a fresh A fragment from LDS per MFMA, random operand bits (probe mode 1)
+    streamed = _lib.mfma_streamed_probe(60.0)
     kt1 = kt
     score_s = (kt1["gmm_score"]["ms_per_step"] + kt1["gmm_score_ref_prepass"]["ms_per_step"]) * 1e-3
     result = {
@@ -1152,6 +1162,14 @@ def main():
                 "peak assumes 2.4 GHz; under the socket power cap a matrix-only kernel holds ~1.55 GHz, so this is the ceiling any MFMA kernel "
                 "longer than a few ms has on this box; the scoring kernel's parts cost time in proportion to their energy "
                 "(profiles/r03_h2p_parts.txt). `frac` above stays algorithmic flops / nominal peak."}
+    rf["sustained_mfma_streamed"] = {
+        "executed_tflops": streamed[0], "clock_mhz": streamed[1], "frac_of_nominal_peak": streamed[0] / MFMA16_PEAK_TFLOPS,
+        "frac_executed_of_sustained": (rf["executed_16bit_tflops"] / streamed[0]) if rf.get("executed_16bit_tflops") and streamed[0] > 0 else None,
+        "note": "the same chains with every MFMA's A fragment re-read from LDS (8 KiB images of random finite fp16 bit patterns), 8 random B "
+                "fragments resident, chains of 8 links (sr_mfma_streamed_probe, ~60 ms): the matrix pipe + the LDS feed + operands whose bits "
+                "toggle, nothing else -- no LDS-DMA stream, no exponentials, no barriers.  The ceiling a kernel of the scoring kernel's shape "
+                "has on this box under its power cap; sustained_mfma above (operands held in registers for the whole launch) is a load no "
+                "real kernel presents."}
     if strong is not None:
         result["configs[3]_strong_scaling"] = strong
     if one_process is not None:

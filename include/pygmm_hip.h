@@ -288,6 +288,11 @@ void sr_kmeans_fast_stats(long *passes, long *rechecked);
  * throughput this device sustains under its power cap (MI355X: ~1.6 PFLOP/s at ~1.55 GHz against the 2.5 PFLOP/s that
  * 2.4 GHz would give).  Either pointer may be NULL.  0 on success. */
 int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz);
+/* The same chains fed the way the scoring kernels feed them: a fresh A fragment read from LDS for every MFMA (8 KiB parameter
+ * images, random finite fp16 bit patterns), 8 random B fragments resident in registers, chains of 8 links -- the ceiling of a
+ * kernel of that shape under the power cap (the probe above holds both operands in registers for the whole launch, a load no
+ * real kernel presents).  Either pointer may be NULL.  0 on success. */
+int sr_mfma_streamed_probe(double ms_target, double *tflops, double *mhz);
 /* Name of the scoring kernel variant the last scoring call launched (for bench / logs). */
 const char *sr_last_score_kernel(void);
 /* Which statistics kernel the last EM / MAP iteration of this process ran: 0 none yet, 1 vector ALU, 2 fp64 matrix cores,

@@ -31,7 +31,7 @@ EXT_SYMBOLS = [
     "sr_last_score_kernel", "sr_last_em_stats_engine", "sr_ltsd_num_windows", "sr_ltsd_noise_spectrum", "sr_ltsd_compute", "sr_stream_create", "sr_stream_submit", "sr_stream_collect", "sr_stream_free",
     "sr_multi_create", "sr_multi_free", "sr_multi_slots", "sr_multi_slot_device", "sr_multi_predict_pcm",
     "sr_hbm_copy_gbps", "sr_reference_rand_sample", "sr_flush_stats", "sr_host_register", "sr_host_unregister",
-    "sr_mfma_peak_probe", "sr_kmeans_fast_stats",
+    "sr_mfma_peak_probe", "sr_mfma_streamed_probe", "sr_kmeans_fast_stats",
 ]
 
 SR_CLAMP_COMPAT = 1
@@ -131,6 +131,7 @@ def lib():
         "sr_last_em_stats_engine": (C.c_int, []),
         "sr_flush_stats": (None, [C.POINTER(C.c_long)] * 3),
         "sr_mfma_peak_probe": (i32, [C.c_double, dp, dp]),
+        "sr_mfma_streamed_probe": (i32, [C.c_double, dp, dp]),
         "sr_kmeans_fast_stats": (None, [C.POINTER(C.c_long)] * 2),
         "sr_host_register": (i32, [vp, C.c_size_t]),
         "sr_host_unregister": (i32, [vp]),
@@ -266,6 +267,14 @@ def mfma_peak_probe(ms_target: float = 50.0):
     device, for about ms_target milliseconds: what the matrix pipe sustains under the socket's power cap (csrc/probe.hip)."""
     t, f = C.c_double(0.0), C.c_double(0.0)
     check(lib().sr_mfma_peak_probe(C.c_double(ms_target), C.byref(t), C.byref(f)), "sr_mfma_peak_probe")
+    return float(t.value), float(f.value)
+
+
+def mfma_streamed_probe(ms_target: float = 50.0):
+    """The same, with the chains fed as the scoring kernel feeds them: a fresh A fragment from LDS for every MFMA, random operand
+    bits (csrc/probe.hip, mode 1)."""
+    t, f = C.c_double(0.0), C.c_double(0.0)
+    check(lib().sr_mfma_streamed_probe(C.c_double(ms_target), C.byref(t), C.byref(f)), "sr_mfma_streamed_probe")
     return float(t.value), float(f.value)
 
 

@@ -814,6 +814,14 @@ int sr_mfma_peak_probe(double ms_target, double *tflops, double *mhz) {
     SR_CATCH(-1)
 }
 
+int sr_mfma_streamed_probe(double ms_target, double *tflops, double *mhz) {
+    SR_TRY
+    if (!(ms_target > 0.0) || ms_target > 2000.0) fail("ms_target must be in (0, 2000]");
+    mfma_peak_probe(ms_target, tflops, mhz, 1);
+    return 0;
+    SR_CATCH(-1)
+}
+
 int sr_reference_rand_sample(int *out, int count) {
     SR_TRY
     if (!out || count < 0) fail("bad arguments");

@@ -117,7 +117,7 @@ void profile_prewarm();          // grows the runtime's event/signal pools once,
 void profile_reset();
 void profile_get(int kind, double *ms, long *launches);
 // probe.hip: executed fp16 MFMA TFLOP/s and shader clock of a kernel that does nothing but v_mfma_f32_32x32x16_f16 on every SIMD
-void mfma_peak_probe(double ms_target, double *tflops, double *mhz);
+void mfma_peak_probe(double ms_target, double *tflops, double *mhz, int mode = 0);
 
 // Bumped by every device (re)allocation and every upload through DevBuf: a captured hipGraph holds
 // raw pointers into, and depends on the contents of, the library's cached workspaces, so it is

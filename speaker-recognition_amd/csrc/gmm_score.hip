@@ -811,7 +811,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             if (use_h2s) {
                 // Round 4: when the grid is a handful of rounds, WHICH handful matters more than having many workgroups: a
                 // workgroup is a frame prologue (about three (block, mixture tile) steps' worth; scripts/debug/h2s_small_one.py
-                // with the H2S_EXP build: 0.12 of 0.78 ms at 64 utterances x 300 frames) plus its blocks, and the chip runs
+                // with a round-4 build that left the kernel after the prologue: 0.12 of 0.78 ms at 64 utterances x 300 frames) plus its blocks, and the chip runs
                 // ceil(workgroups / resident) rounds of the longest one.  64 x 300 frames against 14 blocks: 14 groups = 700
                 // workgroups = 3 rounds of (prologue + 1 block); 5 groups = 250 workgroups = 1 round of (prologue + 3 blocks).
                 const int n_blocks = (int)set.h2s.blocks.size();

@@ -30,9 +30,6 @@
 // online log-sum-exp (running maximum, rescaling), a wave runs the two one after the other, and what hides the one behind the
 // other is MORE waves per SIMD (five 4-wave workgroups = 5 per SIMD) -- worth more than the third of the L2 -> LDS stream the
 // wide shape saves.  (The shared-sigma kernel's epilogue is 32 instructions with no maximum: there the wide shape wins.)
-#ifndef SPLIT_EXP
-#define SPLIT_EXP 0        // measurement builds (scripts/debug/exp_lib.sh): 1 = leave after the frame prologue
-#endif
 #include "lse.hpp"
 #include "score.hpp"
 #include "split_prologue.hpp"
@@ -120,22 +117,6 @@ void gmm_score_split_kernel(const float *__restrict__ X, const TileDesc *__restr
         if (zmax >= 255.0f) atomicOr(oor_flag, 1);
     }
 
-#if SPLIT_EXP & 1
-    {
-        uint32_t chk = 0;
-#pragma unroll
-        for (int ft = 0; ft < FT; ft++)
-#pragma unroll
-            for (int ks = 0; ks < KS; ks++)
-#pragma unroll
-                for (int pi = 0; pi < P; pi++) {
-                    const uint4 u = __builtin_bit_cast(uint4, breg[ft][ks][pi]);
-                    chk ^= u.x ^ u.y ^ u.z ^ u.w;
-                }
-        if (chk == 0x12345678u) partial[0] = 1.0;
-        return;
-    }
-#endif
     float m[FT], ssum[FT];
 #pragma unroll
     for (int ft = 0; ft < FT; ft++) {

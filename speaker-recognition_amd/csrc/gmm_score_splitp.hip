@@ -60,12 +60,8 @@ __host__ __device__ constexpr bool splitp_fits(int ks, int parts, int waves) {
     return splitp_lds_bytes(ks, parts, waves) <= (160 * 1024 - 512) / (waves > 8 ? 1 : 2);
 }
 
-// Parts-off builds for profiles/r04_splitp_parts.txt (scripts/debug/exp_lib.sh gmm_score_splitp.hip SPLITP_OFF mask; results are wrong by
-// construction, only the time means something): 1 no log-sum-exp update, 2 no model close, 4 no LDS-DMA behind the prologue,
-// 8 no fragment reads in the loop, 16 no MFMA
-#ifndef SPLITP_OFF
-#define SPLITP_OFF 0
-#endif
+// (The parts-off measurement builds of round 4 -- the kernel with its log-sum-exp update, model close, LDS-DMA, fragment reads or
+// MFMAs compiled out, profiles/r04_splitp.txt -- were macro hooks in this file until round 6; `git show 951632a:` has them.)
 constexpr int SLAB_M = 16;          // models per slab flush
 constexpr int SLAB_STRIDE = 33;     // floats per slab row (32 frames + 1: the 4-lanes-per-model read is conflict-free)
 constexpr int EPI_OPS = 59;         // operations of one chunk's log-sum-exp update (see epi_op)
@@ -252,10 +248,6 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
         slab_n = 0;
     };
     auto close_model = [&]() {
-        if (SPLITP_OFF & 2) {
-            model_next++;
-            return;
-        }
         const float ll = lse_close2(st.m, st.ssum, other_half(st.m), other_half(st.ssum), a.clamp);
         if (hh == 0) {
             if (valid && frame_ll) frame_ll[(int64_t)model_next * a.n_frames + tile_start + col] = ll;
@@ -305,14 +297,12 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
             constexpr int u = decltype(U)::value;
             constexpr int ks = u / NPROD, pr = u % NPROD;
             constexpr int f = (ci * KS + ks) & 1;
-            if constexpr (pr == 0 && !(SPLITP_OFF & 8)) {
+            if constexpr (pr == 0) {
 #pragma unroll
                 for (int pi = 0; pi < P; pi++) F[f ^ 1][pi] = ks + 1 < KS ? here[((ks + 1) * P + pi) * 64] : next[pi * 64];
             }
-            if constexpr (!(SPLITP_OFF & 16))
-                cur = SC::mfma(__builtin_bit_cast(frag, F[f][SC::AI[pr]]), breg[ks][SC::BI[pr]], u == 0 ? zero16 : cur);
-            if constexpr (!(SPLITP_OFF & 1))
-                static_for<epi_before(NM, u), epi_before(NM, u + 1)>([&](auto OP) { epi_op<decltype(OP)::value>(st, prev); });
+            cur = SC::mfma(__builtin_bit_cast(frag, F[f][SC::AI[pr]]), breg[ks][SC::BI[pr]], u == 0 ? zero16 : cur);
+            static_for<epi_before(NM, u), epi_before(NM, u + 1)>([&](auto OP) { epi_op<decltype(OP)::value>(st, prev); });
             // (the update's results are only USED behind the chain -- by a branch, at that: without a use here the optimiser
             // sinks the whole update out of the slots, whatever the scheduling fences say)
             if constexpr (epi_before(NM, u) != epi_before(NM, u + 1))
@@ -326,7 +316,7 @@ void gmm_score_splitp_kernel(const float *__restrict__ X, const TileDesc *__rest
         if (s > 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of stage s + 1 (issued a stage ago)
             __syncthreads();
-            if (!(SPLITP_OFF & 4) && s + 2 < n_stages) stage_load(std::integral_constant<int, decltype(RB)::value + 2>{}, s + 2);
+            if (s + 2 < n_stages) stage_load(std::integral_constant<int, decltype(RB)::value + 2>{}, s + 2);
         }
         static_for<0, G>([&](auto CI) {
             const int i = s * G + decltype(CI)::value;

@@ -28,6 +28,8 @@ def test_compact_line_is_short_and_complete(tmp_path, capsys):
     full["scaling_efficiency_vs_rank0_alone"] = 0.98765432101234
     full["from_host_pcm_ms_per_step"] = 1234.56789012345
     full["parity"]["per_frame_ll_from_pcm"] = {"max_rel": 1.23456789e-5, "frames": 10 ** 7}
+    for k in ("sustained_mfma", "sustained_mfma_streamed"):
+        full["roofline"][k] = {"executed_tflops": 1712.3456789, "clock_mhz": 1634.56789, "frac_executed_of_sustained": 0.87654321}
     out = tmp_path / "blocks.json"
     bench.emit(full, str(out))
     cap = capsys.readouterr()
@@ -42,6 +44,7 @@ def test_compact_line_is_short_and_complete(tmp_path, capsys):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in line["cpu_baseline"], k
     assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["clock"]["mfma_streamed_tflops"] == 1712.0 and line["clock"]["kernel_over_streamed"] == 0.877
     assert line["vs_baseline"] is None and line["roofline"]["bound"] in ("hbm", "mfma")
     # nothing is lost: the full record is in the blocks file (and on stderr)
     assert json.load(open(out))["configs"].keys() == full["configs"].keys()
