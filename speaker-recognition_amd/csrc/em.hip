@@ -130,6 +130,128 @@ void em_stats_kernel(const float *__restrict__ X, int64_t n_frames, int dim,
     }
 }
 
+// Rows wider than MAX_REG_DIM (the reference has no limit, gmm.cc:40-51): the same two phases with the D loop cut into slices of
+// WIDE_DC dimensions, CB records (32 mixtures) at a time.  Phase A (lane = frame): the records' slice in LDS, the lane's slice of
+// its row from global memory, CB x KB running distances in registers across the slices -> 32 responsibilities per frame into LDS.
+// Phase B (thread = dimension d, 8 mixtures at a time): sweeps the tile's frames -- x[i][d] straight from global memory,
+// consecutive threads consecutive addresses -- in frame order, as em_stats_kernel does.  Same slabs, same reduction.
+constexpr int EMW_JB = 8;
+__global__ __launch_bounds__(256, 2)
+void em_stats_wide_kernel(const float *__restrict__ X, int64_t n_frames, int dim, int dp,
+                          const float4 *__restrict__ params, const float *__restrict__ center, int n_records,
+                          const float *__restrict__ mean_f32 /* [K_pad][dp] */, const float *__restrict__ frame_ll,
+                          float *__restrict__ slabs /* [grid][K_pad][2*dp+1] */, int n_tiles) {
+    constexpr int DC = WIDE_DC, RUN = 2 * DC;
+    __shared__ float4 rec_s[CB * RUN];
+    __shared__ float gs[CB * KB][256];
+    const int tid = threadIdx.x;
+    const int REC = 2 * dp + 1;
+    const int n_dc = dp / DC;
+    const int K_pad = n_records * KB;
+    float *slab = slabs + (size_t)blockIdx.x * K_pad * REC;
+    const int rec_per = ((n_records + (int)gridDim.y - 1) / (int)gridDim.y + CB - 1) / CB * CB;
+    const int r_begin = (int)blockIdx.y * rec_per, r_end = min(n_records, r_begin + rec_per);
+    if (r_begin >= r_end) return;              // (whole workgroup, before any barrier)
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t frame = (int64_t)tile * 256 + tid;
+        const bool valid = frame < n_frames;
+        const int cnt = (int)min((int64_t)256, n_frames - (int64_t)tile * 256);
+        const float *xrow = X + (valid ? frame : 0) * dim;
+        float lse2 = 0.f;
+        bool live = false;
+        if (valid) {
+            const float ll = frame_ll[frame];
+            live = ll >= EM_MINLOG;            // underflowed frames carry no responsibility (gmm.cc:482-498)
+            lse2 = ll * LOG2E_F;
+        }
+        for (int r0 = r_begin; r0 < r_end; r0 += CB) {
+            const int nr = min(CB, r_end - r0);
+            float acc[CB][KB];
+#pragma unroll
+            for (int r = 0; r < CB; r++)
+#pragma unroll
+                for (int j = 0; j < KB; j++) acc[r][j] = 0.f;
+            for (int dc = 0; dc < n_dc; dc++) {
+                __syncthreads();               // previous slice's readers / previous phase B done
+                for (int i = tid; i < nr * RUN; i += 256)
+                    rec_s[i] = params[(size_t)(r0 + i / RUN) * REC + dc * RUN + (i % RUN)];
+                float x[DC];
+                const int d0 = dc * DC;
+#pragma unroll
+                for (int d = 0; d < DC; d++) x[d] = (d0 + d < dim) ? xrow[d0 + d] - center[d0 + d] : 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < CB; r++) {
+                    if (r < nr) {
+#pragma unroll
+                        for (int d = 0; d < DC; d++) {
+                            const float4 p0 = rec_s[r * RUN + 2 * d];
+                            const float4 p1 = rec_s[r * RUN + 2 * d + 1];
+                            const float t0 = fmaf(x[d], p0.x, p0.y);
+                            const float t1 = fmaf(x[d], p0.z, p0.w);
+                            const float t2 = fmaf(x[d], p1.x, p1.y);
+                            const float t3 = fmaf(x[d], p1.z, p1.w);
+                            acc[r][0] = fmaf(t0, t0, acc[r][0]);
+                            acc[r][1] = fmaf(t1, t1, acc[r][1]);
+                            acc[r][2] = fmaf(t2, t2, acc[r][2]);
+                            acc[r][3] = fmaf(t3, t3, acc[r][3]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < CB; r++) {
+                if (r < nr) {
+                    const float4 cc = params[(size_t)(r0 + r) * REC + 2 * dp];
+                    gs[r * KB + 0][tid] = live ? __builtin_amdgcn_exp2f(cc.x - acc[r][0] - lse2) : 0.f;
+                    gs[r * KB + 1][tid] = live ? __builtin_amdgcn_exp2f(cc.y - acc[r][1] - lse2) : 0.f;
+                    gs[r * KB + 2][tid] = live ? __builtin_amdgcn_exp2f(cc.z - acc[r][2] - lse2) : 0.f;
+                    gs[r * KB + 3][tid] = live ? __builtin_amdgcn_exp2f(cc.w - acc[r][3] - lse2) : 0.f;
+                }
+            }
+            __syncthreads();
+            const float *xt = X + (int64_t)tile * 256 * dim;
+            for (int d = tid; d < dim; d += 256) {
+                for (int j0 = 0; j0 < nr * KB; j0 += EMW_JB) {
+                    float mu[EMW_JB], sd[EMW_JB], sdd[EMW_JB];
+#pragma unroll
+                    for (int jj = 0; jj < EMW_JB; jj++) {
+                        mu[jj] = j0 + jj < nr * KB ? mean_f32[(size_t)(r0 * KB + j0 + jj) * dp + d] : 0.f;
+                        sd[jj] = 0.f;
+                        sdd[jj] = 0.f;
+                    }
+                    for (int i = 0; i < cnt; i++) {
+                        const float xv = xt[(size_t)i * dim + d];
+#pragma unroll
+                        for (int jj = 0; jj < EMW_JB; jj++) {
+                            const float gam = gs[j0 + jj][i];
+                            const float dv = xv - mu[jj];
+                            const float gd = gam * dv;
+                            sd[jj] += gd;
+                            sdd[jj] = fmaf(gd, dv, sdd[jj]);
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < EMW_JB; jj++) {
+                        if (j0 + jj < nr * KB) {
+                            float *dst = slab + (size_t)(r0 * KB + j0 + jj) * REC;
+                            dst[d] += sd[jj];
+                            dst[dp + d] += sdd[jj];
+                        }
+                    }
+                }
+            }
+            if (tid < nr * KB) {
+                float sn = 0.f;
+                for (int i = 0; i < cnt; i++) sn += gs[tid][i];
+                slab[(size_t)(r0 * KB + tid) * REC + 2 * dp] += sn;
+            }
+        }
+        __syncthreads();                       // gs is rewritten by the next tile
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The statistics on the fp64 matrix cores (round 3).  sum_i g_ik [x_i | x_i^2 | 1] is a product
 // Gamma^T [K x N] . Y [N x (2D+1)], and v_mfma_f64_16x16x4_f64 accumulates it in float64 from operands that are exact
@@ -708,7 +830,8 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     sync_stream();
 
     const int n_tiles = (int)((n + 255) / 256);
-    const int grid = std::min(n_tiles, ctx().n_cu * 4);
+    // (wide rows: a slab is K x (2 D + 1) floats per workgroup column -- one per CU, the records cut along gridDim.y instead)
+    const int grid = std::min(n_tiles, ctx().n_cu * (dim > MAX_REG_DIM ? 1 : 4));
     auto &w = ews();
 
     double last_ll = -std::numeric_limits<double>::max();
@@ -781,8 +904,15 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
             SR_HIP(hipMemsetAsync(w.slabs.p, 0, (size_t)grid * n_elem * sizeof(float), ctx().stream));
             {
                 ScopedKernelTimer t(T_ESTEP);
-                dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p,
-                               n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
+                if (DP > MAX_REG_DIM) {
+                    const int gy = std::max(1, std::min((n_records + CB - 1) / CB, (4 * ctx().n_cu + grid - 1) / grid));
+                    hipLaunchKernelGGL(em_stats_wide_kernel, dim3(grid, gy), dim3(256), 0, ctx().stream, feat.data.p, (int64_t)n, dim, DP,
+                                       reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p, n_records, w.mean_f32.p,
+                                       sres.d_frame_ll, w.slabs.p, n_tiles);
+                } else {
+                    dispatch_stats(DP, feat.data.p, n, dim, reinterpret_cast<const float4 *>(set.d_params.p), set.d_center0.p,
+                                   n_records, w.mean_f32.p, sres.d_frame_ll, w.slabs.p, n_tiles, grid);
+                }
             }
             SR_HIP(hipGetLastError());
             hipLaunchKernelGGL(em_reduce_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0,

@@ -65,17 +65,20 @@ __device__ __forceinline__ double remez5_ftz(double x) {
 
 // One wave per frame of a noted (tile, model) pair; lane l takes mixtures l, l + 64, ...
 // grid = (pairs of this batch, ceil(frames per tile / 4)), 4 waves per workgroup; exact_out[pair][frame in tile].
-template <int ORDER>
+// The frame's centred row sits in LDS as float64 (dynamic: 4 waves x dim doubles); rows too wide for that (XG) are
+// re-formed from global memory at every use -- the same values, the reference has no limit on dim (gmm.cc:40-51).
+constexpr int FLUSH_LDS_MAX_DIM = 1024;
+template <int ORDER, bool XG>
 __global__ __launch_bounds__(256)
 void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict__ center,
                             const float *__restrict__ params, const FlushModel *__restrict__ models,
                             const TileDesc *__restrict__ tiles, const int2 *__restrict__ pairs, int dim, int dp,
                             int frames_per_tile, int64_t n_frames, float band_hi, float *__restrict__ exact_out,
                             float *__restrict__ frame_ll) {
-    __shared__ double xs_all[4][MAX_DIM];
+    extern __shared__ double xs_all[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    double *xs = xs_all[wave];
+    double *xs = xs_all + (size_t)wave * (XG ? 0 : dim);
     const double SQRT_HALF_LOG2E = 0.84932180028801907;        // sqrt(log2(e) / 2)
     const double LN2 = 0.69314718055994530942;
     const double SQRT_2_PI = 2.5066282746310002;               // gmm.cc:22
@@ -86,8 +89,11 @@ void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict
     const int j = blockIdx.y * 4 + wave;                        // frame inside the tile
     if (j >= tile.count) return;                                // (whole wave; waves only meet through their own xs slab)
     const int64_t row = tile.start + j;
-    for (int d = lane; d < dim; d += 64) xs[d] = (double)X[row * dim + d] - (double)center[d];
-    wave_sync();
+    if (!XG) {
+        for (int d = lane; d < dim; d += 64) xs[d] = (double)X[row * dim + d] - (double)center[d];
+        wave_sync();
+    }
+    auto xv = [&](int d) -> double { return XG ? (double)X[row * dim + d] - (double)center[d] : xs[d]; };
     const FlushModel fm = models[pr.y];
     // ---- phase 1: the frame's value in the log domain (float64, full-product underflow rule of lse.hpp: what the
     //      engines compute, 2 FMAs per mixture and dimension).  Most frames of a noted tile are ordinary ones that
@@ -101,7 +107,7 @@ void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict
         if (!(c > NEG_BIG)) continue;
         double q = 0.0;
         for (int d = 0; d < dim; d++) {
-            const double t = xs[d] * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
+            const double t = xv(d) * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
             q += t * t;
         }
         vmax = fmax(vmax, (double)c - q);
@@ -115,7 +121,7 @@ void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict
         if (!(c > NEG_BIG)) continue;
         double q = 0.0;
         for (int d = 0; d < dim; d++) {
-            const double t = xs[d] * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
+            const double t = xv(d) * (double)rec[d * 8 + jj * 2] + (double)rec[d * 8 + jj * 2 + 1];
             q += t * t;
         }
         const double v = (double)c - q;
@@ -146,7 +152,7 @@ void gmm_flush_exact_kernel(const float *__restrict__ X, const float *__restrict
             const double s = (double)rec[d * 8 + jj * 2];
             const double m = (double)rec[d * 8 + jj * 2 + 1];
             const double sig = SQRT_HALF_LOG2E / s;
-            const double t = xs[d] * s + m;
+            const double t = xv(d) * s + m;
             const double b = ftz(-(t * t) * LN2);              // -d^2 / (2 sigma^2)
             const double ex = remez5_ftz(b);
             log2w += log2(SQRT_2_PI * sig);
@@ -292,12 +298,17 @@ static void flush_evaluate(SRModelSet &set, SRBatch &feat, const TileTable &tt, 
     for (size_t base = 0; base < n_pairs; base += per_batch) {
         const size_t n = std::min(per_batch, n_pairs - base);
         const dim3 grid((unsigned)n, (unsigned)((fpt + 3) / 4));
-#define SR_FLUSH_LAUNCH(ORDER)                                                                                            \
-        hipLaunchKernelGGL(gmm_flush_exact_kernel<ORDER>, grid, dim3(256), 0, ctx().stream, feat.data.p, set.d_center0.p,  \
+#define SR_FLUSH_LAUNCH(ORDER, XG)                                                                                        \
+        hipLaunchKernelGGL((gmm_flush_exact_kernel<ORDER, XG>), grid, dim3(256), (XG) ? 0 : (size_t)4 * feat.dim * sizeof(double),   \
+                           ctx().stream, feat.data.p, set.d_center0.p,                                                     \
                            set.d_params.p, reinterpret_cast<const FlushModel *>(set.d_flush_models.p), tt.d_tiles.p,       \
                            d_list + base, feat.dim, set.host.dp, fpt, feat.n_rows,                                         \
                            (float)(-708.396418532264 + set.host.flush_band), fw.exact.p, d_frame_ll)
-        if (flush_order_option() == 1) SR_FLUSH_LAUNCH(1); else SR_FLUSH_LAUNCH(2);
+        if (feat.dim > FLUSH_LDS_MAX_DIM) {
+            if (flush_order_option() == 1) SR_FLUSH_LAUNCH(1, true); else SR_FLUSH_LAUNCH(2, true);
+        } else {
+            if (flush_order_option() == 1) SR_FLUSH_LAUNCH(1, false); else SR_FLUSH_LAUNCH(2, false);
+        }
 #undef SR_FLUSH_LAUNCH
         hipLaunchKernelGGL(gmm_flush_tile_sum_kernel, dim3((unsigned)n), dim3(64), 0, ctx().stream, fw.exact.p, tt.d_tiles.p,
                            d_list + base, fpt, fw.tile_sum.p + base);

@@ -228,13 +228,16 @@ std::string gmm_format_text(const GMM &g) {
     return s;
 }
 
-// 8..64: every engine; 80..128: the vector-ALU engine with one frame per lane (the matrix-core layouts stop at 64)
+// 8..64: every engine; 80..128: the vector-ALU engine with one frame per lane (the matrix-core layouts stop at 64);
+// wider rows: whole slices of WIDE_DC dimensions for the D-chunked kernels (gmm_score_wide_kernel, em_stats_wide_kernel) --
+// the reference has no limit (gmm.cc:40-51), MAX_DIM only keeps a corrupt model file from asking for terabytes
 static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64, 80, 96, 128};
 
 int pick_padded_dim(int dim) {
     for (int d : kDims)
         if (d >= dim) return d;
-    fail("feature dim %d > %d is not instantiated in this build", dim, MAX_DIM);
+    if (dim <= MAX_DIM) return (dim + WIDE_DC - 1) / WIDE_DC * WIDE_DC;
+    fail("feature dim %d > %d", dim, MAX_DIM);
 }
 
 PackedModels pack_models(const std::vector<const GMM *> &models) {
@@ -279,6 +282,7 @@ PackedModels pack_models(const std::vector<const GMM *> &models) {
         pm.model_chunk_begin.push_back((int)pm.chunks.size());
         total_f4 += (size_t)n_rec * rec_f4;
     }
+    if (total_f4 >= ((size_t)1 << 32)) fail("model set of %zu parameter records of 16 bytes: chunk offsets are 32-bit", total_f4);
     pm.params.assign(total_f4 * 4, 0.0f);
     std::vector<double> lift(pm.n_models, 0.0);             // per model: max_k sum_d max(0, -ln sigma_kd)
     host_parallel_for(pm.n_models, (size_t)models[0]->nr_mixtures * pm.dim, [&](int s, int) {

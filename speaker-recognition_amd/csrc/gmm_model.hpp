@@ -56,9 +56,11 @@ struct ChunkDesc {
     int32_t pad;
 };
 
-constexpr int MAX_DIM = 128;        // largest feature dimension any kernel is instantiated for
+constexpr int MAX_REG_DIM = 128;    // largest feature dimension a lane keeps whole in registers (gmm_score_kernel<DP,...>)
+constexpr int WIDE_DC = 64;         // wider rows go through the kernels slice by slice of this many dimensions
+constexpr int MAX_DIM = 1 << 16;    // sanity bound only (a corrupt model file); the reference has none (gmm.cc:40-51)
 constexpr int MAX_MATRIX_DIM = 64;  // largest one the matrix-core engines are packed for
-int pick_padded_dim(int dim);  // smallest instantiated kernel dim >= dim; throws if > MAX_DIM
+int pick_padded_dim(int dim);  // <= MAX_REG_DIM: smallest instantiated kernel dim >= dim; above: whole slices of WIDE_DC; throws if > MAX_DIM
 
 struct PackedModels {
     int n_models = 0;

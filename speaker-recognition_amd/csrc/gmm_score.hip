@@ -233,6 +233,149 @@ void gmm_score_kernel(const float *__restrict__ X, const TileDesc *__restrict__ 
     }
 }
 
+// Rows wider than MAX_REG_DIM (the reference has no limit, gmm.cc:40-51): the same direct form, same records, same lane = frame,
+// with the D loop cut into slices of WIDE_DC dimensions.  A step = (chunk of <= CB records of one model, slice): the slice's
+// parameters -- n_records runs of 2 WIDE_DC float4 inside the record-major layout -- land in LDS by LDS-DMA one step ahead, the
+// lane fetches its row's slice (256 B of its own row; the tile's rows stay in L2 between steps), and the CB x KB running
+// distances stay in registers across the chunk's slices; constants, log-sum-exp update and the model close follow the last
+// slice exactly as above.  Any dim: the slice count is a run-time value.
+__global__ __launch_bounds__(256, 3)
+void gmm_score_wide_kernel(const float *__restrict__ X, const TileDesc *__restrict__ tiles,
+                           const float4 *__restrict__ params, const float *__restrict__ center,
+                           const ChunkDesc *__restrict__ chunks, const int *__restrict__ group_chunk_begin,
+                           double *__restrict__ partial, float *__restrict__ frame_ll, int64_t n_frames, int dim, int dp,
+                           int n_models, int clamp, int n_groups, int n_tiles, float band_hi) {
+    constexpr int DC = WIDE_DC;
+    constexpr int RUN = 2 * DC;              // float4 per record and slice
+    constexpr int SLICE_F4 = CB * RUN;
+    constexpr int PF = SLICE_F4 / 256;
+    static_assert(RUN % 64 == 0 && SLICE_F4 % 256 == 0, "an LDS-DMA instruction stays inside one record's run");
+    __shared__ float4 lds_a[SLICE_F4];
+    __shared__ float4 lds_b[SLICE_F4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_lo = blockIdx.x & 7;      // XCD-aware order, as gmm_score_kernel
+    const int q = blockIdx.x >> 3;
+    const int g = q % n_groups;
+    const int tile_id = (q / n_groups) * 8 + tile_lo;
+    if (tile_id >= n_tiles) return;
+    const TileDesc tile = tiles[tile_id];
+    const int chunk_begin = group_chunk_begin[g];
+    const int chunk_end = group_chunk_begin[g + 1];
+    const int rec_f4 = 2 * dp + 1;
+    const int n_dc = dp / DC;
+
+    auto stage = [&](float4 *dst, const ChunkDesc cd, int dc) {
+        const float4 *src = params + cd.offset_f4 + dc * RUN;
+        const int n4 = cd.n_records * RUN;
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int base = (i * 4 + wave) * 64;      // wave-uniform; record base / RUN, offset base % RUN + lane inside its run
+            if (base < n4)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + (size_t)(base / RUN) * rec_f4 + (base % RUN) + lane),
+                    (__attribute__((address_space(3))) void *)(dst + base), 16, 0, 0);
+        }
+    };
+    stage(lds_a, chunks[chunk_begin], 0);
+
+    const bool valid = tid < tile.count;
+    const int64_t row = tile.start + (valid ? tid : 0);
+    const float *xrow = X + row * dim;
+    float m = NEG_BIG, ssum = 0.0f;
+    const float drop_thr = clamp ? LSE_MINLOG2 : -3.0e38f;
+    float acc[CB][KB];
+    dma_publish_barrier();
+
+    auto do_step = [&](const float4 *cur, float4 *other, int c, int dc) __attribute__((always_inline)) {
+        const ChunkDesc cd = chunks[c];
+        {
+            const int dcn = dc + 1 < n_dc ? dc + 1 : 0;
+            const int cn = dcn ? c : c + 1;
+            if (cn < chunk_end) stage(other, chunks[cn], dcn);
+        }
+        float x[DC];
+        const int d0 = dc * DC;
+        if (d0 + DC <= dim) {                // wave-uniform
+#pragma unroll
+            for (int d = 0; d < DC; d++) x[d] = xrow[d0 + d] - center[d0 + d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < DC; d++) x[d] = (d0 + d < dim) ? xrow[d0 + d] - center[d0 + d] : 0.0f;
+        }
+        if (dc == 0) {
+#pragma unroll
+            for (int r = 0; r < CB; r++)
+#pragma unroll
+                for (int j = 0; j < KB; j++) acc[r][j] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < CB; r++) {
+            if (r < cd.n_records) {          // wave-uniform
+                const float4 *rec = cur + r * RUN;
+#pragma unroll
+                for (int d = 0; d < DC; d++) {
+                    const float4 p0 = rec[2 * d];
+                    const float4 p1 = rec[2 * d + 1];
+                    const float t0 = fmaf(x[d], p0.x, p0.y);
+                    const float t1 = fmaf(x[d], p0.z, p0.w);
+                    const float t2 = fmaf(x[d], p1.x, p1.y);
+                    const float t3 = fmaf(x[d], p1.z, p1.w);
+                    acc[r][0] = fmaf(t0, t0, acc[r][0]);
+                    acc[r][1] = fmaf(t1, t1, acc[r][1]);
+                    acc[r][2] = fmaf(t2, t2, acc[r][2]);
+                    acc[r][3] = fmaf(t3, t3, acc[r][3]);
+                }
+            }
+        }
+        if (dc == n_dc - 1) {
+#pragma unroll
+            for (int r = 0; r < CB; r++) {
+                if (r < cd.n_records) {
+                    const float4 cc = params[cd.offset_f4 + (size_t)r * rec_f4 + 2 * dp];      // wave-uniform address
+                    const float v0 = cc.x - acc[r][0], v1 = cc.y - acc[r][1], v2 = cc.z - acc[r][2], v3 = cc.w - acc[r][3];
+                    const float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                    const float mn = fmaxf(m, mx);
+                    // (the reference's sub-DBL_MIN terms are exactly 0: lse.hpp; select on exp2's argument as gmm_score_kernel)
+                    const float e0 = __builtin_amdgcn_exp2f(v0 >= drop_thr ? v0 - mn : LSE_NEG_BIG);
+                    const float e1 = __builtin_amdgcn_exp2f(v1 >= drop_thr ? v1 - mn : LSE_NEG_BIG);
+                    const float e2 = __builtin_amdgcn_exp2f(v2 >= drop_thr ? v2 - mn : LSE_NEG_BIG);
+                    const float e3 = __builtin_amdgcn_exp2f(v3 >= drop_thr ? v3 - mn : LSE_NEG_BIG);
+                    ssum = fmaf(ssum, __builtin_amdgcn_exp2f(m - mn), (e0 + e1) + (e2 + e3));
+                    m = mn;
+                }
+            }
+            if (cd.model_done >= 0) {
+                const int s = cd.model_done;
+                const float ll = lse_close1(m, ssum, clamp);
+                double mine = 0.0;
+                bool hot = false;
+                if (valid) {
+                    mine = (double)ll;
+                    if (frame_ll) frame_ll[(int64_t)s * n_frames + row] = ll;
+                    hot = ll < band_hi;
+                }
+                m = NEG_BIG;
+                ssum = 0.0f;
+                mine = wave_sum_f64(mine);
+                if (__builtin_amdgcn_ballot_w64(hot) != 0) mine = SR_FLUSH_POISON;
+                if (lane == 0) partial[((int64_t)tile_id * n_models + s) * 4 + wave] = mine;
+            }
+        }
+        dma_publish_barrier();
+    };
+
+    int c = chunk_begin, dc = 0;
+    while (c < chunk_end) {
+        do_step(lds_a, lds_b, c, dc);
+        if (++dc == n_dc) { dc = 0; c++; }
+        if (c >= chunk_end) break;
+        do_step(lds_b, lds_a, c, dc);
+        if (++dc == n_dc) { dc = 0; c++; }
+    }
+}
+
 // Per utterance: add the tile/wave partials in a fixed order (deterministic), then the
 // reference's argmax -- first maximum wins (gmmset.py:62-64, `max(enumerate(scores), key=...)`).
 // A (tile, model) whose partial is SR_FLUSH_POISON holds a frame in the band where the reference's flushes of partial
@@ -1019,10 +1162,18 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_models = S;
             a.clamp = clamp_mode;
             a.band_hi = fp.band_hi;
-            snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
-                     (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");
             ScopedKernelTimer t(T_SCORE);
-            dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
+            if (DP > MAX_REG_DIM) {
+                snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_wide_kernel (vector ALU, %d slices of %d dims)", DP / WIDE_DC, WIDE_DC);
+                dim3 grid((unsigned)((int64_t)G * ((tt.n_tiles + 7) / 8) * 8));
+                hipLaunchKernelGGL(gmm_score_wide_kernel, grid, dim3(256), 0, ctx().stream, a.X, a.tiles, a.params, a.center, a.chunks,
+                                   a.group_chunk_begin, a.partial, a.frame_ll, a.n_frames, a.dim, DP, a.n_models, a.clamp, G, tt.n_tiles,
+                                   a.band_hi);
+            } else {
+                snprintf(g_last_kernel, sizeof(LastKernel::name), "gmm_score_kernel<%d,%d,%s> (vector ALU)", DP, F,
+                         (opt.packed >= 0 && F >= 2) ? "packed" : "scalar");
+                dispatch(a, DP, F, opt.packed >= 0 && F >= 2, tt.n_tiles, G);
+            }
         }
         SR_HIP(hipGetLastError());
         if (uploaded) sync_stream();   // first call with this grouping only; the copy source is the workspace's own vector

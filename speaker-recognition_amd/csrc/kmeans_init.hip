@@ -152,23 +152,27 @@ void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const do
     if ((long)blockIdx.x * KM_PP * 256 >= n_work) return;         // (list mode: the grid is sized for the worst case)
     for (int c0 = c_begin; c0 < c_end; c0 += KM_CH) {
         const int nc = min(KM_CH, c_end - c0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < KM_CH * dim; e += 256) {
-            const int j = e / dim, d = e - j * dim;
-            csd[d * KM_CH + j] = j < nc ? C[(size_t)(c0 + j) * dim + d] : 0.0;
-        }
-        __syncthreads();
         double acc[KM_PP][KM_CH];
 #pragma unroll
         for (int p = 0; p < KM_PP; p++)
 #pragma unroll
             for (int j = 0; j < KM_CH; j++) acc[p][j] = 0.0;
+        // (rows wider than DIM_MAX -- the reference has no limit -- take the chunk's centres DIM_MAX dimensions at a time; the
+        // running sums go on in dimension order, so the distances are still the reference's bit for bit)
+        for (int d0 = 0; d0 < dim; d0 += DIM_MAX) {
+        const int dn = min(DIM_MAX, dim - d0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < KM_CH * dn; e += 256) {
+            const int j = e / dn, d = e - j * dn;
+            csd[d * KM_CH + j] = j < nc ? C[(size_t)(c0 + j) * dim + d0 + d] : 0.0;
+        }
+        __syncthreads();
 #pragma unroll
         for (int d = 0; d < DIM_MAX; d++) {
-            if (d < dim) {
+            if (d < dn) {
                 double xv[KM_PP];
 #pragma unroll
-                for (int p = 0; p < KM_PP; p++) xv[p] = XREG ? (double)x[p][XREG ? d : 0] : (double)xsrc[p][d];
+                for (int p = 0; p < KM_PP; p++) xv[p] = XREG ? (double)x[p][XREG ? d : 0] : (double)xsrc[p][d0 + d];
 #pragma unroll
                 for (int j2 = 0; j2 < KM_CH / 2; j2++) {
                     const km_d2 c = cs[d * (KM_CH / 2) + j2];
@@ -181,6 +185,7 @@ void kmeans_assign_kernel(const float *__restrict__ X, long n, int dim, const do
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (keeps the next dimensions' LDS reads from being hoisted: registers)
             }
+        }
         }
 #pragma unroll
         for (int p = 0; p < KM_PP; p++)

@@ -283,8 +283,8 @@ def test_streaming_shape_short_windows(built_lib, oracle_built):
 def test_edge_shapes_and_errors(built_lib, oracle_built):
     """K = 1, K not a multiple of the 4- / 32-mixture packing, the widest dim of the matrix-core engines
     (64), dims that need zero padding (D=5 -> 8, D=20 -> 24), wide rows (65, 84 = MFCC + LPC with both
-    deltas, 128: vector-ALU engine only), zero-weight mixtures, many tiny utterances; dim > 128 and dim
-    mismatches are refused with a message (no silent truncation)."""
+    deltas, 128: vector-ALU engine only), zero-weight mixtures, many tiny utterances; dim mismatches
+    are refused with a message (no silent truncation)."""
     from speaker_recognition_amd import _lib, synth
     from speaker_recognition_amd.core import Batch, ModelSet
     from speaker_recognition_amd.pygmm import GMM
@@ -319,14 +319,67 @@ def test_edge_shapes_and_errors(built_lib, oracle_built):
     off = np.concatenate([[0], np.cumsum(lens)])
     want0 = np.array([ll0[off[i]:off[i + 1]].sum() for i in range(3000)])
     assert np.max(np.abs(sums[:, 0] - want0) / np.maximum(1, np.abs(want0))) < 1e-5
-    # refused shapes
-    with pytest.raises(_lib.SRError, match="128"):
-        ModelSet([GMM.from_arrays(*synth.synth_gmm(4, 129, 1))])
+    # refused shapes (dim > 128 is served since round 6: test_wide_rows_beyond_128_dims_vs_oracle; what is left is a sanity bound)
+    with pytest.raises(_lib.SRError, match="65536"):
+        ModelSet([GMM.from_arrays(*synth.synth_gmm(1, 65537, 1))])
     g13 = GMM.from_arrays(*synth.synth_gmm(4, 13, 1))
     with pytest.raises(_lib.SRError, match="dim"):
         g13.score(np.zeros((10, 12), np.float32))
     with pytest.raises(_lib.SRError, match="dim"):
         ModelSet([g13, GMM.from_arrays(*synth.synth_gmm(4, 12, 1))])
+
+
+def test_wide_rows_beyond_128_dims_vs_oracle(built_lib, oracle_built):
+    """The reference has no limit on the feature dimension (src/gmm/src/gmm.cc:40-51).  Rows wider than a lane keeps in
+    registers (128) go through gmm_score_wide_kernel: the same direct form with the D loop cut into slices of 64 dimensions.
+    D = 129 (one dimension into the third slice), 200, 300, 512 (whole slices), 1100 (beyond the LDS row
+    of the partial-product kernel): per-frame LL incl. the clamp on outlier frames, sums, argmax, ragged utterances, model
+    groups, odd mixture counts, a dead mixture; the legacy single-model ABI on the same rows."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    go = oracle_built
+    floor32 = np.float32(np.log(1e-15))
+    for D, K, S in ((129, 9, 3), (200, 33, 4), (300, 64, 3), (512, 7, 2), (1100, 5, 2)):
+        models = [synth.synth_gmm(K if s != 1 else K + 3, D, 700 + D + s) for s in range(S)]
+        if D >= 512:
+            # sigma ~ U(0.2, 1.5) puts a 512-dim density below DBL_MIN for every frame (-1.15 nats per dim): tighter mixtures
+            # keep the frames scoreable -- and put all of them in the band of the reference's partial-product flushes
+            # (gmm_flush.hip; at D = 1100 its rows no longer fit LDS)
+            models = [(w, mu, np.vectorize(lambda v: float("%g" % v))(sg * 0.45)) for w, mu, sg in models]
+        w, mu, sg = models[0]
+        w = w.copy()
+        w[K // 2] = 0.0                                  # a dead mixture: contributes exactly nothing
+        models[0] = (w, mu, sg)
+        lens = [0, 1, 255, 256, 257, 40, 600]
+        utts = [synth.draw_frames(models[u % S], n, 300 + u, outlier_frac=0.02 if n > 100 else 0.0) for u, n in enumerate(lens)]
+        X = np.concatenate(utts).astype(np.float64)
+        want = np.stack([go.score_batch(go.GMMParams(*m), X) for m in models])
+        off = np.concatenate([[0], np.cumsum(lens)])
+        ms = ModelSet([GMM.from_arrays(*m) for m in models])
+        for G in (0, 1, S):
+            _lib.set_option("score_model_groups", G)
+            sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True)
+            assert "gmm_score_wide_kernel" in _lib.last_score_kernel()
+            clamped = want == np.log(1e-15)
+            assert np.array_equal(fll == floor32, clamped), (D, G)
+            assert ll_close(fll[~clamped], want[~clamped]) < TOL, (D, G, ll_close(fll[~clamped], want[~clamped]))
+            for u, n in enumerate(lens):
+                ws = np.array([want[s, off[u]:off[u + 1]].sum() for s in range(S)])
+                if n == 0:
+                    assert arg[u] == -1 and np.all(sums[u] == 0)
+                else:
+                    assert np.max(np.abs(sums[u] - ws) / np.maximum(1, np.abs(ws))) < 1e-5, (D, u)
+                    assert arg[u] == int(np.argmax(ws)), (D, u)
+        _lib.set_option("score_model_groups", 0)
+        one = GMM.from_arrays(*models[1])
+        ll = one.score(X[:300])
+        assert ll_close(ll, want[1, :300]) < TOL
+        # bit-identical reruns, and an utterance alone = the same utterance inside the batch
+        sums2, arg2 = ms.score(Batch.from_features(utts))
+        assert np.array_equal(sums, sums2) and np.array_equal(arg, arg2)
+        alone, _ = ms.score(Batch.from_features([utts[6]]))
+        assert np.array_equal(alone[0], sums[6])
 
 
 def test_engine_selection_and_split_bf16_accuracy(built_lib, oracle_built):

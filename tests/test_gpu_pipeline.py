@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("D", [13, 84])
+@pytest.mark.parametrize("D", [13, 84, 200, 300])
 def test_em_and_map_iteration_vs_oracle(built_lib, oracle_built, D):
-    """One EM iteration and one MAP iteration from identical starting parameters (13 dims, and the wide rows of
-    MFCC + LPC with both deltas: 84 dims, vector-ALU engine and the looped statistics roles)."""
+    """One EM iteration and one MAP iteration from identical starting parameters (13 dims; the wide rows of
+    MFCC + LPC with both deltas: 84 dims, vector-ALU engine and the looped statistics roles; 200 and 300 dims: rows
+    wider than a lane's registers, the D-sliced kernels -- the reference has no limit, gmm.cc:40-51)."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.pygmm import GMM
     go = oracle_built
@@ -244,7 +245,7 @@ def test_kmeans_initialiser_on_the_device_equals_its_restatement(built_lib):
     from oracle import init_oracle as io
     from speaker_recognition_amd.pygmm import GMM
     rng = np.random.default_rng(3)
-    for n, K, D, conc, seed in ((30011, 96, 13, 37, 11), (9001, 40, 39, 64, 5), (5000, 8, 20, 3, 2)):
+    for n, K, D, conc, seed in ((30011, 96, 13, 37, 11), (9001, 40, 39, 64, 5), (5000, 8, 20, 3, 2), (3001, 20, 200, 5, 4)):
         cent = rng.normal(0, 3, (K, D))
         X = (cent[rng.integers(0, K, n)] + rng.normal(0, 1, (n, D))).astype(np.float32)
         g = GMM(nr_mixture=K, nr_iteration=0, init_with_kmeans=1, seed=seed, concurrency=conc)
