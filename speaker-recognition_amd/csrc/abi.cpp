@@ -499,6 +499,19 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     if (b->kind != SRBatch::PCM16) fail("sr_batch_update_pcm needs an int16 PCM batch");
     if (n_samples != b->n_rows) fail("sample count %lld does not match the batch (%lld)", (long long)n_samples, (long long)b->n_rows);
     b->bind_device();
+    if ((size_t)n_samples * sizeof(int16_t) <= ((size_t)4 << 20) && n_samples > 0) {
+        // a serving decision's worth of PCM: through the batch's page-locked copy, transfer left in flight (batch.hpp) -- the
+        // stream synchronisation this call used to end with was a sixth of a single-utterance decision (round 6)
+        if (!b->stage_done.e) SR_HIP(hipEventCreateWithFlags(&b->stage_done.e, hipEventDisableTiming));
+        else if (hipEventQuery(b->stage_done.e) != hipSuccess) SR_HIP(hipEventSynchronize(b->stage_done.e));
+        b->h_stage.ensure((size_t)n_samples);
+        std::memcpy(b->h_stage.p, pcm, (size_t)n_samples * sizeof(int16_t));
+        b->pcm16.ensure((size_t)n_samples);
+        g_devbuf_epoch++;                       // (contents changed: a captured graph that depends on them is re-captured, as upload())
+        SR_HIP(hipMemcpyAsync(b->pcm16.p, b->h_stage.p, (size_t)n_samples * sizeof(int16_t), hipMemcpyHostToDevice, ctx().stream));
+        SR_HIP(hipEventRecord(b->stage_done.e, ctx().stream));
+        return 0;
+    }
     b->pcm16.upload(pcm, (size_t)n_samples);
     sync_stream();
     return 0;
@@ -611,7 +624,9 @@ static void predict_unpipelined(SRMfcc *m, SRModelSet *set, SRBatch *pcm, int nd
                                 int flags) {
     SRBatch *feat_ws = &per_device<SRBatch>();   // reused across steps: the serving loop allocates nothing
     mfcc_extract_batch(*m, *pcm, nd, 1, *feat_ws);
-    const ScoreResult r = score_device(*set, *feat_ws, false, flags);
+    // (small result sets land in host memory by themselves: SCORE_HOST_DELIVER, score.hpp)
+    const int deliver = (sums_out && argmax_out && host_deliverable((size_t)pcm->n_utt, (size_t)set->host.n_models)) ? SCORE_HOST_DELIVER : 0;
+    const ScoreResult r = score_device(*set, *feat_ws, false, flags | deliver);
     if (!fetch_results(*set, *feat_ws, flags, r, sums_out, argmax_out, nullptr)) {
         // a frame left the fp16 engine's range: score the batch again on the fp32-grade engines
         const ScoreResult r2 = score_device(*set, *feat_ws, false, flags | SCORE_PRECISE);

@@ -47,6 +47,11 @@ struct SRBatch {
     sr::DevBuf<int16_t> pcm16;
     sr::DevBuf<float> data;         // f32 PCM or features [n_rows][dim]
     std::vector<std::unique_ptr<sr::TileTable>> tile_tables;
+    // sr_batch_update_pcm of a small batch (a serving decision's PCM): the samples go through this page-locked copy and the
+    // transfer is left in flight on the stream -- the caller's buffer is free when the call returns, the host never waits;
+    // `stage_done` says when the staging area may be overwritten by the next update
+    sr::PinnedBuf<int16_t> h_stage;
+    sr::EventHolder stage_done;
 
     sr::TileTable &tiles_for(int frames_per_tile);
     // binds an empty batch to the calling thread's device / refuses one that lives elsewhere

@@ -176,14 +176,41 @@ struct PinnedBuf {
     PinnedBuf() = default;
     PinnedBuf(const PinnedBuf &) = delete;
     PinnedBuf &operator=(const PinnedBuf &) = delete;
+    PinnedBuf(PinnedBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    PinnedBuf &operator=(PinnedBuf &&o) noexcept {
+        if (this != &o) {
+            if (p && !gpu_runtime_lost()) (void)hipHostFree(p);
+            p = o.p; n = o.n; o.p = nullptr; o.n = 0;
+        }
+        return *this;
+    }
     ~PinnedBuf() { if (p && !gpu_runtime_lost()) (void)hipHostFree(p); }
-    void ensure(size_t count) {
+    // (flags: hipHostMallocCoherent | hipHostMallocMapped for memory a kernel writes and the host polls)
+    void ensure(size_t count, unsigned flags = hipHostMallocDefault) {
         if (count <= n) return;
         if (p && !gpu_runtime_lost()) (void)hipHostFree(p);
         p = nullptr;
         n = 0;
-        SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), hipHostMallocDefault));
+        SR_HIP(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), flags));
         n = count;
+    }
+};
+
+// An event owned by a movable object (created on first use, timing disabled).
+struct EventHolder {
+    hipEvent_t e = nullptr;
+    EventHolder() = default;
+    EventHolder(const EventHolder &) = delete;
+    EventHolder &operator=(const EventHolder &) = delete;
+    EventHolder(EventHolder &&o) noexcept : e(o.e) { o.e = nullptr; }
+    EventHolder &operator=(EventHolder &&o) noexcept {
+        if (this != &o) { drop(); e = o.e; o.e = nullptr; }
+        return *this;
+    }
+    ~EventHolder() { drop(); }
+    void drop() {
+        if (e && !gpu_runtime_lost()) (void)hipEventDestroy(e);
+        e = nullptr;
     }
 };
 

@@ -387,9 +387,16 @@ void gmm_score_wide_kernel(const float *__restrict__ X, const TileDesc *__restri
 // round 4 one thread per model walked ALL the tiles, which for the one long utterance of an E-step (400 k frames = 12 500
 // tiles, one model) was 1.7 ms of dependent loads behind a 0.6 ms scoring kernel.
 constexpr int FIN_LDS_DOUBLES = 4096;
+struct FinalizeDelivery {      // SCORE_HOST_DELIVER (score.hpp); host == nullptr: off
+    DeliverHeader *host;
+    int *counters;             // the pass's counters: [0] saturation flag, [1] flush count, [2] this kernel's ticket, [4 ...]
+    int n_counters;
+    unsigned seq;
+};
 __global__ __launch_bounds__(256)
 void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n_models,
-                         int per_tile, double *sums, int *argmax, int2 *flush_list, int *flush_count, int flush_cap) {
+                         int per_tile, double *sums, int *argmax, int2 *flush_list, int *flush_count, int flush_cap,
+                         FinalizeDelivery dl) {
     __shared__ double seg_sum[FIN_LDS_DOUBLES];
     const int u = blockIdx.x;
     const int tb = utt_tile_begin[u], te = utt_tile_begin[u + 1];
@@ -453,6 +460,30 @@ void gmm_finalize_kernel(const double *partial, const int *utt_tile_begin, int n
         __syncthreads();
     }
     if (threadIdx.x == 0) argmax[u] = (te > tb && si[0] != 0x7fffffff) ? si[0] : -1;
+    if (dl.host == nullptr) return;
+    // ---- the last workgroup to get here delivers the pass: results and counters to host memory, counters cleared ----
+    __shared__ int s_last;
+    __threadfence();                                       // this workgroup's sums / argmax / list entries before its ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&dl.counters[2], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int U = (int)gridDim.x;
+    double *h_sums = reinterpret_cast<double *>(dl.host + 1);
+    int *h_arg = reinterpret_cast<int *>(h_sums + (size_t)U * n_models);
+    for (int i = threadIdx.x; i < U * n_models; i += 256)
+        h_sums[i] = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < U; i += 256) h_arg[i] = __hip_atomic_load(&argmax[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        dl.host->oor = __hip_atomic_load(&dl.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dl.host->n_flush = __hip_atomic_load(&dl.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                       // (the counters are read: clear them for the next pass)
+    for (int i = threadIdx.x; i < dl.n_counters; i += 256) dl.counters[i] = 0;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&dl.host->seq, dl.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Hybrid sets: LL = ln(exp(LL_a) + exp(LL_b)) per frame and model, the per-tile float64 sums for gmm_finalize_kernel, and
@@ -529,6 +560,13 @@ struct ScoreWorkspace {
     DevBuf<float> hy_a, hy_b;            // hybrid sets: per-frame LL of the two sub-sets
     DevBuf<int2> flush_list;             // (tile, model) pairs in the partial-product band (lse.hpp, gmm_flush.hip)
     size_t flush_min_cap = 0;            // set after an overflow: the next pass gets a list of that length
+    // SCORE_HOST_DELIVER: the page-locked landing area, the last sequence number handed out, and whether the last pass's finalize
+    // left `clean_n` counters at `clean_p` cleared (nothing else writes them between passes)
+    PinnedBuf<char> deliver;
+    void *deliver_dev = nullptr;         // the device's view of it
+    unsigned deliver_seq = 0;
+    const int *clean_p = nullptr;
+    size_t clean_n = 0;
 };
 static ScoreWorkspace &ws() { return per_device<ScoreWorkspace>(); }   // one per device, leaked on purpose
 
@@ -929,7 +967,22 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
     bool used_oor = false;
     const size_t n_counters = 4 + 2 * set.h2s.blocks.size();      // (shared-sigma engine: exception entries and items per block)
     w.counters.ensure(n_counters);
-    SR_HIP(hipMemsetAsync(w.counters.p, 0, n_counters * sizeof(int), ctx().stream));     // the pass's counters, all at once
+    // (a delivering finalize cleared them behind itself; only a delivering pass -- never one being captured into a graph -- relies on it)
+    if (!((flags & SCORE_HOST_DELIVER) && w.clean_p == w.counters.p && w.clean_n >= n_counters))
+        SR_HIP(hipMemsetAsync(w.counters.p, 0, n_counters * sizeof(int), ctx().stream));     // the pass's counters, all at once
+    w.clean_p = nullptr;
+    FinalizeDelivery dl{nullptr, nullptr, 0, 0u};
+    if ((flags & SCORE_HOST_DELIVER) && !want_frame_ll && !frame_ll_dst && host_deliverable((size_t)feat.n_utt, (size_t)S)) {
+        if (!w.deliver.p) {
+            w.deliver.ensure(sizeof(DeliverHeader) + HOST_DELIVER_MAX_BYTES + 64, hipHostMallocCoherent | hipHostMallocMapped);
+            std::memset(w.deliver.p, 0, w.deliver.n);
+            SR_HIP(hipHostGetDevicePointer(&w.deliver_dev, w.deliver.p, 0));
+        }
+        dl.host = reinterpret_cast<DeliverHeader *>(w.deliver_dev);
+        dl.counters = w.counters.p;
+        dl.n_counters = (int)n_counters;
+        dl.seq = ++w.deliver_seq ? w.deliver_seq : ++w.deliver_seq;      // (0 is "nothing yet")
+    }
     const FlushPass fp = prepare_flush(set, tt.n_tiles, flags);
     // 0 off, 1 the reference's clamp, 2 the same with "all terms underflowed" reported as -inf (a half of a hybrid set)
     const int clamp_mode = (flags & 1) ? ((flags & SCORE_NO_FLUSH) ? 2 : 1) : 0;
@@ -1182,10 +1235,16 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream,
                            w.partial.p, tt.d_utt_tile_begin.p, S, (use_split || use_shared || use_h2s) ? 1 : 4, w.sums_p(n_sums), w.argmax_p(n_sums),
-                           fp.list, fp.count, fp.cap);
+                           fp.list, fp.count, fp.cap, dl);
     }
     SR_HIP(hipGetLastError());
     ScoreResult r;
+    if (dl.host && U > 0) {
+        r.h_deliver = reinterpret_cast<const volatile DeliverHeader *>(w.deliver.p);
+        r.deliver_seq = dl.seq;
+        w.clean_p = w.counters.p;
+        w.clean_n = n_counters;
+    }
     r.d_sums = w.sums_p(n_sums);
     r.d_argmax = w.argmax_p(n_sums);
     r.d_frame_ll = (want_frame_ll && tt.n_tiles > 0) ? (frame_ll_dst ? frame_ll_dst : w.frame_ll.p) : nullptr;
@@ -1231,7 +1290,8 @@ static ScoreResult score_hybrid(SRModelSet &set, SRBatch &feat, bool want_frame_
     if (U > 0) {
         ScopedKernelTimer t(T_FINALIZE);
         hipLaunchKernelGGL(gmm_finalize_kernel, dim3((unsigned)U), dim3(256), 0, ctx().stream, w.partial.p,
-                           tt.d_utt_tile_begin.p, S, 1, w.sums_p(n_sums), w.argmax_p(n_sums), fp.list, fp.count, fp.cap);
+                           tt.d_utt_tile_begin.p, S, 1, w.sums_p(n_sums), w.argmax_p(n_sums), fp.list, fp.count, fp.cap,
+                           FinalizeDelivery{nullptr, nullptr, 0, 0u});
         SR_HIP(hipGetLastError());
     }
     snprintf(g_last_kernel, sizeof(LastKernel::name), "hybrid: %d ill-conditioned mixtures on the vector ALU + %.150s", set.hy_bad_mixtures, good_name);
@@ -1264,6 +1324,44 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
     auto &st = staging();
     ScoreResult r = r_in;
     const size_t U = (size_t)feat.n_utt, S = (size_t)set.host.n_models, n_frames = (size_t)feat.n_rows;
+    struct ResetCap {                       // an enlarged band list is for this batch only
+        bool armed = false;
+        ~ResetCap() { if (armed) ws().flush_min_cap = 0; }
+    } reset_cap;
+    if (r.h_deliver) {
+        // SCORE_HOST_DELIVER: the pass's last workgroup wrote everything into page-locked host memory and released `seq`.
+        // Poll for it (a wake-up from hipStreamSynchronize costs more than the kernels' tail); now and then ask the stream --
+        // a faulted queue must not leave this thread spinning.
+        const volatile DeliverHeader *h = r.h_deliver;
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == r.deliver_seq) break;
+            if ((spins & 0xfff) == 0) {
+                const hipError_t e = hipStreamQuery(ctx().stream);
+                if (e == hipSuccess) {
+                    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == r.deliver_seq) break;
+                    fail("scoring pass finished without delivering its results (sequence %u, found %u)", r.deliver_seq, h->seq);
+                }
+                if (e != hipErrorNotReady) SR_HIP(e);
+            }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (r.d_oor && h->oor != 0) return false;
+        const int n_flush = r.d_flush_count ? h->n_flush : 0;
+        double *h_sums = const_cast<double *>(reinterpret_cast<const volatile double *>(h + 1));
+        int *h_arg = reinterpret_cast<int *>(h_sums + U * S);
+        if (n_flush == 0 || n_flush <= r.flush_cap) {
+            if (n_flush) flush_resolve_host(set, feat, *r.tiles, r.d_flush_list, n_flush, h_sums, h_arg);
+            if (sums_out) std::memcpy(sums_out, h_sums, U * S * sizeof(double));
+            if (argmax_out) std::memcpy(argmax_out, h_arg, U * sizeof(int));
+            return true;
+        }
+        // more pairs than the list holds: the pass again with a list of that length, through the general path below
+        ws().flush_min_cap = (size_t)n_flush;
+        reset_cap.armed = true;
+        r = score_device(set, feat, false, flags & ~SCORE_HOST_DELIVER);
+    }
     st.oor.ensure(2);
     const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
     const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
@@ -1309,9 +1407,7 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
         if (n_flush > r.flush_cap) {
             // more pairs than the list holds (the counter kept counting): the pass again with a list of that length
             ws().flush_min_cap = (size_t)n_flush;
-            struct Reset {                      // the enlarged list is for this batch only
-                ~Reset() { ws().flush_min_cap = 0; }
-            } reset_after;
+            reset_cap.armed = true;
             const bool own = r.d_frame_ll && r.d_frame_ll != ws().frame_ll.p;
             r = score_device(set, feat, r.d_frame_ll != nullptr, flags, own ? const_cast<float *>(r.d_frame_ll) : nullptr);
             SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
@@ -1339,7 +1435,9 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
 
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags) {
-    const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags);
+    // (small result sets land in host memory by themselves: SCORE_HOST_DELIVER, score.hpp)
+    const int deliver = (!frame_ll_out && sums_out && argmax_out && host_deliverable((size_t)feat.n_utt, (size_t)set.host.n_models)) ? SCORE_HOST_DELIVER : 0;
+    const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags | deliver);
     if (fetch_results(set, feat, flags, r, sums_out, argmax_out, frame_ll_out)) return;
     // a frame left the fp16 engine's range: the whole batch again on the fp32-grade engines
     const ScoreResult r2 = score_device(set, feat, frame_ll_out != nullptr, flags | SCORE_PRECISE);

@@ -132,6 +132,7 @@ struct H2sArgs {
 
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
+    int plan_inline;              // the exception pass forms its plan itself (no h2s_plan_kernel launch in front of it)
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
 
@@ -920,11 +921,10 @@ __device__ __forceinline__ int *h2s_plan_starts(const H2sArgs &a, int blk) {
     return reinterpret_cast<int *>(a.exc_list + (size_t)a.n_blocks * a.n_tiles) + (size_t)blk * (a.n_tiles + 1);
 }
 
+constexpr int H2S_PLAN_INLINE_MAX_TILES = 1024;
 // One wave per block: walks the block's entries in list order and opens a new item whenever the next tile's frames do not fit the
-// current item's 32 columns.  starts[i] = first entry of item i, starts[n_items] = count; n_items behind the counts.
-__global__ __launch_bounds__(64)
-void h2s_plan_kernel(const H2sArgs a) {
-    const int blk = blockIdx.x, lane = threadIdx.x;
+// current item's 32 columns.  starts[i] = first entry of item i, starts[n_items] = count; returns n_items (wave-uniform).
+__device__ __forceinline__ int h2s_plan_block(const H2sArgs &a, int blk, int lane) {
     const int count = min(a.exc_count[blk], a.n_tiles);
     int *starts = h2s_plan_starts(a, blk);
     const int2 *list = a.exc_list + (size_t)blk * a.n_tiles;
@@ -942,10 +942,17 @@ void h2s_plan_kernel(const H2sArgs a) {
             fill += p;
         }
     }
-    if (lane == 0) {
-        starts[n_items] = count;
-        a.exc_count[a.n_blocks + blk] = n_items;
-    }
+    if (lane == 0) starts[n_items] = count;
+    return n_items;
+}
+
+// ... as a kernel of its own in front of the exception pass: n_items behind the counts.  (Small batches -- a serving decision is ten
+// tiles -- skip this launch: `plan_inline`, every workgroup of the exception pass then forms its block's plan itself, all of them
+// the same values.)
+__global__ __launch_bounds__(64)
+void h2s_plan_kernel(const H2sArgs a) {
+    const int n_items = h2s_plan_block(a, blockIdx.x, threadIdx.x);
+    if (threadIdx.x == 0) a.exc_count[a.n_blocks + blockIdx.x] = n_items;
 }
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) {
@@ -975,7 +982,20 @@ void gmm_score_h2s_online_kernel(const H2sArgs a) {
     const int hh = lane >> 5;
     const int gy = (int)gridDim.x / a.n_blocks;            // workgroups per block
     const int blk = (int)blockIdx.x / gy, y = (int)blockIdx.x - blk * gy;
-    const int n_items = a.exc_count[a.n_blocks + blk];
+    int n_items;
+    if (a.plan_inline) {
+        if (a.exc_count[blk] == 0) return;                  // (the usual case: nothing listed)
+        __shared__ int s_items;
+        if (wave == 0) {
+            const int n = h2s_plan_block(a, blk, lane);
+            if (lane == 0) s_items = n;
+        }
+        __threadfence();                                    // (this workgroup reads the starts it wrote itself)
+        __syncthreads();
+        n_items = s_items;
+    } else {
+        n_items = a.exc_count[a.n_blocks + blk];
+    }
     if (y * WAVES >= n_items) return;                       // (the usual case: nothing listed)
     const int *starts = h2s_plan_starts(a, blk);
     const int2 *list = a.exc_list + (size_t)blk * a.n_tiles;
@@ -1145,6 +1165,7 @@ static int launch_h2s(const H2sLaunch &l) {
     a.n_tiles = l.n_tiles;
     a.log2_k = l.log2_k;
     a.force_exc = l.force_exc;
+    a.plan_inline = l.n_tiles <= H2S_PLAN_INLINE_MAX_TILES;
     a.band_hi = l.band_hi;
     // long grids in launches of ~H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups (see the kernel)
     constexpr int TILES_WG = MS ? 1 : WAVES * COLS;
@@ -1192,7 +1213,7 @@ static int launch_h2s(const H2sLaunch &l) {
     // the exception pass: the plan (one wave per block cuts its list into items of <= 32 listed frames), then 4-wave workgroups over
     // the items (a couple of resident ones per block and CU's worth of the chip; with nothing listed -- the usual case -- they
     // leave at once)
-    hipLaunchKernelGGL(h2s_plan_kernel, dim3((unsigned)l.n_blocks), dim3(64), 0, ctx().stream, a);
+    if (!a.plan_inline) hipLaunchKernelGGL(h2s_plan_kernel, dim3((unsigned)l.n_blocks), dim3(64), 0, ctx().stream, a);
     const int gy = std::max(1, (2 * ctx().n_cu) / std::max(1, l.n_blocks));
     hipLaunchKernelGGL((gmm_score_h2s_online_kernel<KQF, KLF>), dim3((unsigned)(l.n_blocks * gy)), dim3(256), 0, ctx().stream, a);
     return n_launches;

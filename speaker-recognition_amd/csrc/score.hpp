@@ -48,6 +48,20 @@ constexpr double F16_MAX_COEF = 30000.0;
 constexpr int SCORE_PRECISE = 0x200;
 // internal: leave the partial-product band alone (the two halves of a hybrid set: their merge looks at the merged value)
 constexpr int SCORE_NO_FLUSH = 0x400;
+// Small result sets of callers that fetch them right away (fetch_results): gmm_finalize_kernel's last workgroup writes sums, argmax
+// and the pass's two counters into page-locked host memory and releases a sequence number the host polls for -- no device-to-host
+// copies, no stream synchronisation -- and clears the pass's counters for the next pass (no memset in front of it).
+constexpr int SCORE_HOST_DELIVER = 0x800;
+constexpr size_t HOST_DELIVER_MAX_BYTES = (size_t)64 << 10;
+inline bool host_deliverable(size_t n_utt, size_t n_models) {
+    return n_utt > 0 && n_utt * n_models * sizeof(double) + n_utt * sizeof(int) <= HOST_DELIVER_MAX_BYTES;
+}
+// what the last workgroup leaves in host memory: this header, then double sums[U][S], then int argmax[U]
+struct DeliverHeader {
+    int oor, n_flush;
+    unsigned seq;
+    int pad;
+};
 
 struct MfmaLaunch {
     const float *X;
@@ -136,6 +150,9 @@ struct ScoreResult {
     const int2 *d_flush_list = nullptr;
     int flush_cap = 0;
     const TileTable *tiles = nullptr;  // the tile table the pass ran on
+    // SCORE_HOST_DELIVER honoured: where the results arrive (page-locked host memory) and the sequence number that says they have
+    const volatile DeliverHeader *h_deliver = nullptr;
+    unsigned deliver_seq = 0;
 };
 
 // Scores every utterance of `feat` against every model of `set`; leaves results on the device.

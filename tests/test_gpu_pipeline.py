@@ -375,6 +375,16 @@ def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, orac
     assert ok(s_fused) and np.array_equal(a_fused, np.argmax(want, axis=1))
     s_again, a_again = ex.predict_batch(ms, batch, nd=0)
     assert np.array_equal(s_again, s_fused) and np.array_equal(a_again, a_fused)
+    # the band list overflowing (capacity 1) on the paths that complete HOST copies of the results: the fused step (results
+    # delivered into page-locked memory by the pass itself, round 6) and the multi-slot predictor's pieces
+    _lib.set_option("flush_list_cap", 1)
+    try:
+        s_cap, a_cap = ex.predict_batch(ms, batch, nd=0)
+        assert np.array_equal(s_cap, s_fused) and np.array_equal(a_cap, a_fused)
+        s_mc, a_mc = MultiPredictor(gm, fs, n_slots=2).predict(list(pcm), nd=0)
+        assert np.array_equal(s_mc, s_fused) and np.array_equal(a_mc, a_fused)
+    finally:
+        _lib.set_option("flush_list_cap", 0)
     # (graph, delay): with a delay the host is held back in front of the stream capture until the plain pass before it has finished
     # on the device -- the order in which a host-side clear of the tick's flags during capture lost "frames in the band" (a race that
     # failed this test once in ~10 full-suite runs before the clear moved in front of the tick, csrc/stream.cpp)
@@ -394,6 +404,42 @@ def test_band_frames_through_fused_pipelined_and_streaming_paths(built_lib, orac
     s_m, a_m = mp_.predict(list(pcm), nd=0)
     assert np.array_equal(s_m, s_fused) and np.array_equal(a_m, a_fused)
     assert _lib.flush_stats()[0] >= calls0 + 5
+
+
+def test_update_pcm_leaves_the_transfer_in_flight_and_the_callers_buffer_free(built_lib):
+    """sr_batch_update_pcm of a serving-size batch returns without waiting for the device (round 6): the samples were copied to
+    the batch's page-locked staging area, so the caller may overwrite its buffer at once; two updates in a row wait for the
+    first transfer to leave the staging area; results equal those of a freshly built batch, bit for bit.  Also: a result set too
+    large for host delivery (> 64 KiB) takes the copying path and gives the same bits for its first rows."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    fs = 16000
+    ex = MfccExtractor(fs)
+    ubm = synth.synth_gmm(64, 39, 3)
+    ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + [synth.synth_map_speaker(ubm, 40 + s) for s in range(19)]])
+    a = synth.synth_speech(1, 1.5, fs)
+    b = synth.synth_speech(2, 1.5, fs)[:len(a)]
+    want_a = ex.predict_batch(ms, Batch.from_pcm([a]), nd=2)
+    want_b = ex.predict_batch(ms, Batch.from_pcm([b]), nd=2)
+    assert not np.array_equal(want_a[0], want_b[0])
+    batch = Batch.from_pcm([b])
+    for i in range(20):
+        src, want = ((a, want_a), (b, want_b))[i & 1]
+        buf = src.copy()
+        batch.update_pcm(buf)
+        buf[:] = 12345                              # the caller's buffer is its own again
+        if i % 5 == 4:
+            batch.update_pcm(((b, a)[i & 1]).copy())   # an update nobody scored ...
+            batch.update_pcm(src.copy())               # ... and the one that counts, right behind it
+        sums, arg = ex.predict_batch(ms, batch, nd=2)
+        assert np.array_equal(sums, want[0]) and np.array_equal(arg, want[1]), i
+    # 500 utterances x 20 models x 8 bytes > 64 KiB: results by device-to-host copy
+    clips = [a[:8000], b[:8000]] * 250
+    big = ex.predict_batch(ms, Batch.from_pcm(clips), nd=2)
+    small = ex.predict_batch(ms, Batch.from_pcm(clips[:2]), nd=2)
+    assert np.array_equal(big[0][:2], small[0]) and np.array_equal(big[1][:2], small[1])
+    assert np.array_equal(big[0][::2], np.repeat(small[0][:1], 250, axis=0))
 
 
 def test_serving_stream_double_buffered_equals_synchronous(built_lib):
