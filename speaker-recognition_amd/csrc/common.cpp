@@ -4,7 +4,6 @@
 #include <climits>
 #include <mutex>
 
-#include <mutex>
 #include <new>
 
 #include <pthread.h>

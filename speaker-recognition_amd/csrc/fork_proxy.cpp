@@ -234,6 +234,24 @@ void reply_status(Reader &r) {
     if (status != 0) fail("%s", msg.c_str());
 }
 
+// SIGTERM, then a BOUNDED wait: a helper stuck in an uninterruptible driver call (or stopped) must not hang the worker that drops
+// it -- with its helper record's mutex held -- so after ~0.5 s it is killed outright and reaped (no zombie either way).
+static void reap_helper(pid_t pid) {
+    (void)::kill(pid, SIGTERM);
+    int st = 0;
+    for (int i = 0; i < 100; i++) {
+        const pid_t r = ::waitpid(pid, &st, WNOHANG);
+        if (r == pid || (r < 0 && errno != EINTR)) return;
+        ::usleep(5000);
+    }
+    (void)::kill(pid, SIGKILL);
+    for (int i = 0; i < 200; i++) {                 // (SIGKILL cannot be ignored; a D-state process still takes its time)
+        const pid_t r = ::waitpid(pid, &st, WNOHANG);
+        if (r == pid || (r < 0 && errno != EINTR)) return;
+        ::usleep(5000);
+    }
+}
+
 void start_helper(Helper &h) {
     // (a grandchild inherits its parent's Helper record: the socket in it belongs to the parent's conversation)
     if (h.fd >= 0 && h.owner_pid != (long)getpid()) {
@@ -288,9 +306,7 @@ void start_helper(Helper &h) {
     } catch (...) {
         ::close(h.fd);
         h.fd = -1;
-        (void)::kill(pid, SIGTERM);
-        int st = 0;
-        (void)::waitpid(pid, &st, 0);
+        reap_helper(pid);
         h.pid = -1;
         throw;
     }
@@ -301,9 +317,7 @@ void drop_helper(Helper &h) {
     h.fd = -1;
     if (h.pid > 0 && h.owner_pid == (long)getpid()) {
         // the helper leaves on end-of-file; it is told to as well in case it is stuck in a request, then reaped (no zombie)
-        (void)::kill(h.pid, SIGTERM);
-        int st = 0;
-        (void)::waitpid(h.pid, &st, 0);
+        reap_helper((pid_t)h.pid);
     }
     h.pid = -1;
     h.sent.clear();

@@ -663,7 +663,7 @@ void upload_model_set(SRModelSet &s) {
     if (s.hy_bad) upload_model_set(*s.hy_bad);
 }
 
-// The expanded-form (matrix-core) layout is packed lazily: only sets that take that engine pay.
+// is the set inside the split-fp16 shared-sigma engine's range?
 static bool h2s_ok(const PackedH2Shared &p) {
     return !p.params.empty() && p.amp <= F16_MAX_AMP && p.pad_waste <= MFMA_MAX_PAD_WASTE &&
            p.sigma_ratio <= F16_MAX_SIGMA_RATIO && p.coef_max <= F16_MAX_COEF;
@@ -1366,6 +1366,7 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
     const size_t fll_n = (frame_ll_out && r.d_frame_ll) ? S * n_frames : 0;
     const bool stage_fll = fll_n > 0 && fll_n * sizeof(float) <= ((size_t)64 << 20);
     const int *h_argmax = nullptr;            // where the staged argmax values are (behind the sums when they came in one copy)
+    bool rescored = false;
     for (;;) {
         st.oor.p[0] = st.oor.p[1] = 0;
         // (the workspace keeps the two counters, and the argmax values behind the sums, side by side: one copy each)
@@ -1405,21 +1406,24 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
         int n_flush = st.oor.p[1];
         if (n_flush == 0) break;
         if (n_flush > r.flush_cap) {
-            // more pairs than the list holds (the counter kept counting): the pass again with a list of that length
+            // more pairs than the list holds (the counter kept counting): the pass again with a list of that length -- and ITS
+            // sums, argmax and count staged afresh (the loop's top), so that nothing below depends on the two passes having
+            // left the same bits in the same places
+            if (rescored) fail("partial-product band: %d (tile, model) pairs noted, list of %d", n_flush, r.flush_cap);
+            rescored = true;
             ws().flush_min_cap = (size_t)n_flush;
             reset_cap.armed = true;
             const bool own = r.d_frame_ll && r.d_frame_ll != ws().frame_ll.p;
             r = score_device(set, feat, r.d_frame_ll != nullptr, flags, own ? const_cast<float *>(r.d_frame_ll) : nullptr);
-            SR_HIP(hipMemcpyAsync(st.oor.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
-            sync_stream();
-            n_flush = st.oor.p[1];
-            if (n_flush > r.flush_cap) fail("partial-product band: %d (tile, model) pairs noted, list of %d", n_flush, r.flush_cap);
+            continue;
         }
         if (!fll_n && sums_out && argmax_out && U) {
             // Sums and argmax are already here: complete the HOST copies (one more wait for the tiles' exact sums; what sr_multi's
             // pieces do) instead of patching the device's and copying everything a second time -- two waits, two uploads, two
             // kernels and a copy of all U x S sums less per call.
-            // The device-resident sums stay unpatched: nobody reads them after this call.
+            // Invariant: the staged sums, the staged argmax and the list all come from the SAME pass `r` (an overflow re-score
+            // restarts the loop and stages its own).  The device-resident d_sums / d_argmax stay UNPATCHED on this branch --
+            // they are the workspace's, valid until the next scoring call, and nothing reads them after this one returns.
             flush_resolve_host(set, feat, *r.tiles, r.d_flush_list, n_flush, st.sums.p, const_cast<int *>(h_argmax));
             break;
         }
@@ -1448,7 +1452,9 @@ void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argm
 
 // Work items of the pipelined shared-sigma kernel over a 32-frame tile table: tiles in order, every full one an item of its own, the
 // ragged tails (1000-frame utterances leave 8 of 32 columns: 2.3 % of the pass's MFMAs on dead frames) packed greedily, in order,
-// up to four and up to 32 columns to an item, placed where the first of them stood.
+// up to four and up to 32 columns to an item, all packed items together at the END of the list (pack_tail_tiles, gmm_model.hpp).
+// The table is padded with empty items to whole rounds of H2P_ROUND_ITEMS = 8 workgroups x 12 waves: the kernel reads
+// (tiles + n_tiles)[unit] for every unit of a launched round without a bound of its own.
 namespace sr {
 void ensure_work_table(TileTable &tt, bool pack_tails) {
     if ((tt.n_work > 0 && tt.work_packed == pack_tails) || tt.n_tiles == 0) return;
@@ -1461,7 +1467,7 @@ void ensure_work_table(TileTable &tt, bool pack_tails) {
     for (size_t i = 0; i < items.size(); i++) work[i] = make_int4(items[i].t[0], items[i].t[1], items[i].t[2], items[i].t[3]);
     tt.n_work = (int)work.size();
     tt.work_packed = pack_tails;
-    work.resize(((work.size() + 95) / 96) * 96, make_int4(-1, -1, -1, -1));      // whole rounds of 8 workgroups x 12 waves
+    work.resize(((work.size() + H2P_ROUND_ITEMS - 1) / H2P_ROUND_ITEMS) * H2P_ROUND_ITEMS, make_int4(-1, -1, -1, -1));
     std::vector<TileDesc> both(tt.h_tiles);
     both.resize(tt.h_tiles.size() + work.size());
     std::memcpy(both.data() + tt.h_tiles.size(), work.data(), work.size() * sizeof(int4));

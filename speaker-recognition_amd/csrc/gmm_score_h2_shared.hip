@@ -133,6 +133,8 @@ struct H2sArgs {
     float log2_k;                 // log2 of the mixture count (bounds largest term >= LL - log2 K)
     int force_exc;                // testing: every workgroup of the main pass defers to the ONLINE pass
     int plan_inline;              // the exception pass forms its plan itself (no h2s_plan_kernel launch in front of it)
+    int n_units;                  // what h2s_wg_assignment hands out: 32-frame tiles, or -- pipelined kernel -- work items (the padded
+                                  // count of ensure_work_table: every unit of a launched workgroup is readable)
     float band_hi;                // below it a frame goes to the partial-product path (lse.hpp): by way of the ONLINE pass
 };
 
@@ -153,7 +155,7 @@ __device__ __forceinline__ bool h2s_wg_assignment(const H2sArgs &a, int tiles_wg
         t = (q / a.n_groups) * 8 + wg_lo;
     }
     tile0 = a.tile_base + t * tiles_wg;
-    return tile0 < a.n_tiles && t < a.n_wg;
+    return tile0 < a.n_units && t < a.n_wg;
 }
 
 // Close of one block's models for one 32-frame tile (both main kernels): the offset form is only trusted well inside fp32's
@@ -1172,6 +1174,8 @@ static int launch_h2s(const H2sLaunch &l) {
     const int resident = ctx().n_cu * (WAVES > 4 ? 1 : h2s_waves_per_eu(KQF, KLF, COLS, WAVES, MS));
     if (PIN && l.n_work <= 0) fail("the pipelined shared-sigma kernel needs its work table behind the tile table (ensure_work_table)");
     const int n_wg = ((PIN ? l.n_work : l.n_tiles) + TILES_WG - 1) / TILES_WG;
+    a.n_units = PIN ? (l.n_work + H2P_ROUND_ITEMS - 1) / H2P_ROUND_ITEMS * H2P_ROUND_ITEMS : l.n_tiles;
+    static_assert(!PIN || H2P_ROUND_ITEMS % TILES_WG == 0, "a workgroup's work items never straddle the table's padding");
     // (the 12-wave form has one workgroup per CU sweeping the stream: nothing drifts apart, 1 / 3 / 5 / 9 / 18 launches
     // per configs[2] pass all take 0.281-0.283 s -- one launch)
     int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)

@@ -92,6 +92,7 @@ struct SharedLaunch {
     float band_hi = -__builtin_inff();
 };
 void launch_score_bx3_shared(const SharedLaunch &a, int KQ, int KL);
+constexpr int H2P_ROUND_ITEMS = 96;     // the pipelined kernel's work table is padded to whole rounds of 8 workgroups x 12 waves
 struct H2sLaunch {
     const float *X;
     const TileDesc *tiles;
