@@ -539,13 +539,20 @@ def block_serving_small(_lib, ex, base, ms, S, K, hbm):
         cat = np.concatenate(clips)
         batch = Batch.from_pcm(clips)
         lat = []
-        for i in range(130):
-            if i == 30:
-                _lib.profile_reset()
-            t0 = time.perf_counter()
+        out_bufs = (np.zeros((U, S)), np.full(U, -1, np.int32))
+        _lib.profile_enable(False)                          # (the HIP-event pairs around every kernel are ~20 us of a 140 us decision)
+        try:
+            for i in range(230):
+                t0 = time.perf_counter()
+                batch.update_pcm(cat)
+                sums, arg = ex.predict_batch(ms, batch, nd=ND, out=out_bufs)
+                lat.append((time.perf_counter() - t0) * 1e3)
+        finally:
+            _lib.profile_enable(True)
+        _lib.profile_reset()
+        for i in range(30):                                 # ... and the kernels' own times from a few calls with them
             batch.update_pcm(cat)
-            sums, arg = ex.predict_batch(ms, batch, nd=ND)
-            lat.append((time.perf_counter() - t0) * 1e3)
+            sums, arg = ex.predict_batch(ms, batch, nd=ND, out=out_bufs)
         ms_k, n_k = _lib.profile_get(_lib.T_SCORE)
         ms_r, _ = _lib.profile_get(_lib.T_SCORE_REF)
         ms_m, _ = _lib.profile_get(_lib.T_MFCC)
@@ -697,13 +704,17 @@ def block_cfg2_from_host(_lib, gm, cat, off, sums_resident, arg_resident):
     try:
         mp_ = MultiPredictor(gm, FS, n_slots=1, **MFCC_KW)
         f = lambda: mp_.predict_concat(cat, off, nd=ND)
-        f()
+        first = []
+        for _ in range(2):                                  # the first two calls of a shape are not the steady state: buffers, tables, and a
+            t0 = time.perf_counter()                        # second call whose uploads the runtime still runs behind each piece's kernels
+            f()
+            first.append(1e3 * (time.perf_counter() - t0))
         el, (s2, a2) = timed(f, 0, 3)
         del mp_
     finally:
         _lib.host_unregister(cat)
     return {"workload": "configs[2] headline step from page-locked HOST PCM (%.2f GB per call), one slot" % (cat.nbytes / 1e9),
-            "ms_per_step": 1e3 * el / 3, "pcie_floor_ms": cat.nbytes / 55e9 * 1e3,
+            "ms_per_step": 1e3 * el / 3, "first_two_calls_ms": first, "pcie_floor_ms": cat.nbytes / 55e9 * 1e3,
             "argmax_equal_resident": bool(np.array_equal(a2, arg_resident)), "sums_bit_identical_resident": bool(np.array_equal(s2, sums_resident))}
 
 

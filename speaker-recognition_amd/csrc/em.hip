@@ -676,7 +676,7 @@ static void dispatch_stats(int DP, const float *X, int64_t n, int dim, const flo
 #define SR_CASE(V) case V: launch_stats<V>(X, n, dim, params, center, n_records, mean_f32, frame_ll, slabs, n_tiles, grid); break;
     switch (DP) {
         SR_CASE(8) SR_CASE(13) SR_CASE(16) SR_CASE(24) SR_CASE(26) SR_CASE(32) SR_CASE(34)
-        SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64) SR_CASE(80) SR_CASE(96) SR_CASE(128)
+        SR_CASE(39) SR_CASE(40) SR_CASE(48) SR_CASE(56) SR_CASE(64) SR_CASE(80) SR_CASE(96)
         default: fail("no EM kernel for padded dim %d", DP);
     }
 #undef SR_CASE

@@ -228,10 +228,10 @@ std::string gmm_format_text(const GMM &g) {
     return s;
 }
 
-// 8..64: every engine; 80..128: the vector-ALU engine with one frame per lane (the matrix-core layouts stop at 64);
+// 8..64: every engine; 80, 96: the vector-ALU engine with one frame per lane (the matrix-core layouts stop at 64);
 // wider rows: whole slices of WIDE_DC dimensions for the D-chunked kernels (gmm_score_wide_kernel, em_stats_wide_kernel) --
 // the reference has no limit (gmm.cc:40-51), MAX_DIM only keeps a corrupt model file from asking for terabytes
-static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64, 80, 96, 128};
+static const int kDims[] = {8, 13, 16, 24, 26, 32, 34, 39, 40, 48, 56, 64, 80, 96};
 
 int pick_padded_dim(int dim) {
     for (int d : kDims)

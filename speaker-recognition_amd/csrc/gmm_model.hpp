@@ -56,7 +56,9 @@ struct ChunkDesc {
     int32_t pad;
 };
 
-constexpr int MAX_REG_DIM = 128;    // largest feature dimension a lane keeps whole in registers (gmm_score_kernel<DP,...>)
+constexpr int MAX_REG_DIM = 96;     // largest feature dimension a lane keeps whole in registers (gmm_score_kernel<DP,...>); beyond it the
+                                    // D-sliced kernels are the faster ones (scripts/debug/wide_ab.py, round 6: D = 100 3.20 -> 1.97 ms,
+                                    // D = 128 2.63 -> 1.84 ms on 200 k frames x 16 x 64; D = 96 1.56 against 1.95: stays)
 constexpr int WIDE_DC = 64;         // wider rows go through the kernels slice by slice of this many dimensions
 constexpr int MAX_DIM = 1 << 16;    // sanity bound only (a corrupt model file); the reference has none (gmm.cc:40-51)
 constexpr int MAX_MATRIX_DIM = 64;  // largest one the matrix-core engines are packed for

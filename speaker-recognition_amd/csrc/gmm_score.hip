@@ -589,7 +589,11 @@ static FlushPass prepare_flush(const SRModelSet &set, int n_tiles, int flags) {
     w.flush_list.ensure(cap);
     fp.list = w.flush_list.p;
     fp.count = w.flush_count_p();          // (cleared with the pass's other counters by score_device)
-    fp.cap = (int)std::min<size_t>(score_options().flush_list_cap > 0 ? cap : w.flush_list.n, 0x7fffffff);
+    // (the capacity the pass is told is a function of ITS size, not of what the workspace happens to hold: a caller that sets a
+    // piece's list aside -- multi.cpp -- then sizes its copy once; told the workspace's size, the small pieces of sr_multi's SECOND
+    // call found a list grown by the first call's large piece, reallocated theirs under the pipeline and cost configs[2]'s second
+    // from-host call 60 ms, round 6)
+    fp.cap = (int)std::min<size_t>(cap, 0x7fffffff);
     fp.band_hi = (float)(-708.396418532264 + set.host.flush_band);
     return fp;
 }
@@ -634,7 +638,6 @@ static void dispatch(const ScoreArgs &a, int DP, int F, bool pk, int n_tiles, in
         case 64: dispatch_f<64>(a, F, pk, n_tiles, n_groups); break;
         case 80: dispatch_f<80>(a, F, pk, n_tiles, n_groups); break;
         case 96: dispatch_f<96>(a, F, pk, n_tiles, n_groups); break;
-        case 128: dispatch_f<128>(a, F, pk, n_tiles, n_groups); break;
         default: fail("no scoring kernel for padded dim %d", DP);
     }
 }

@@ -125,15 +125,19 @@ __device__ __forceinline__ double ln_pos_f32(float e) {
     double r = (double)__builtin_amdgcn_rcpf((float)den);
     r = fma(r, fma(-den, r, 1.0), r);
     const double s = (md - 1.0) * r, s2 = s * s;
-    double p = 1.0 / 15.0;
-    p = fma(p, s2, 1.0 / 13.0);
-    p = fma(p, s2, 1.0 / 11.0);
-    p = fma(p, s2, 1.0 / 9.0);
-    p = fma(p, s2, 1.0 / 7.0);
-    p = fma(p, s2, 1.0 / 5.0);
-    p = fma(p, s2, 1.0 / 3.0);
+    // (the coefficients as scalar registers formed HERE: left to itself the compiler hoists them out of the frame loop into 16 vector
+    // registers held across the transform -- the run-time-length variant then spilled)
+    double c15 = 1.0 / 15.0, c13 = 1.0 / 13.0, c11 = 1.0 / 11.0, c9 = 1.0 / 9.0, c7 = 1.0 / 7.0, c5 = 1.0 / 5.0, c3 = 1.0 / 3.0, ln2 = 0.69314718055994530942;
+    asm volatile("" : "+s"(c15), "+s"(c13), "+s"(c11), "+s"(c9), "+s"(c7), "+s"(c5), "+s"(c3), "+s"(ln2));
+    double p = c15;
+    p = fma(p, s2, c13);
+    p = fma(p, s2, c11);
+    p = fma(p, s2, c9);
+    p = fma(p, s2, c7);
+    p = fma(p, s2, c5);
+    p = fma(p, s2, c3);
     p = fma(p, s2, 1.0);
-    return fma((double)ex, 0.69314718055994530942, 2.0 * s * p);
+    return fma((double)ex, ln2, 2.0 * s * p);
 }
 
 constexpr int F64_WIN_BYTES = 4160;               // 520 float64 window taps in LDS (frames of <= 512 samples)
@@ -324,7 +328,15 @@ void mfcc_frames_fft2048_f64_kernel(const PcmT *__restrict__ pcm, const int64_t 
         for (int ps = 0; ps < 4; ps++) {
             const int len = mr.pass_len[ps];
             const float4 *mv4 = reinterpret_cast<const float4 *>(s_melval + mr.pass_base[ps]) + lane;
-            const float4 *pp4 = reinterpret_cast<const float4 *>(pbuf + m_c0[ps]) + m_part;
+            int c0v = m_c0[ps];
+            if constexpr (MP == 0) {
+                // (the run-time-length variant is one register over: its sweep starts are re-read per frame -- L1 -- through an
+                // opaque index instead of held across the transform)
+                int bl = 16 * ps + m_bl;
+                asm volatile("" : "+v"(bl));
+                c0v = mr.col0[bl];
+            }
+            const float4 *pp4 = reinterpret_cast<const float4 *>(pbuf + c0v) + m_part;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             if constexpr (MP != 0) {
 #pragma unroll

@@ -205,7 +205,22 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // (2.5 / 7.5 / 22.5 / 67.5 %) once two passes in a row on a batch of about this size measured rho >= 3.5; back to equal
         // pieces when two in a row measure < 2.5.  Pieces are whole utterances and an utterance's results do not depend on the batch
         // around it: the bits are the same for any cut.
-        if (s.rho_samples > 0 && !(total > s.rho_samples / 2 && total < s.rho_samples * 2)) s.schedule = s.votes = 0;
+        // The FIRST pass on a batch of this size starts from an estimate (the measured adaptation took four calls to settle --
+        // two equal-piece passes, one that allocated the new pieces' buffers, one more -- 350 / 337 / 454 / 335 ms before 276 on
+        // configs[2]): device seconds per frame from the set's arithmetic at the rate its engine class sustains, against the
+        // link's seconds per frame.  configs[2]: 16.7 Mflop per frame / 700 TFLOP/s + MFCC 2.7 ns = 26.5 ns against 5.8 ns of
+        // link: 4.6; configs[1]: 0.93.  The votes below correct a wrong guess.
+        if (s.rho_samples == 0 || !(total > s.rho_samples / 2 && total < s.rho_samples * 2)) {
+            const SRModelSet &set = *s.set;
+            double mixtures = 0.0;                         // of all models together (padded to whole records of KB)
+            for (const ChunkDesc &cd : set.host.chunks) mixtures += (double)cd.n_records * KB;
+            const double flops = mixtures * (4.0 * set.host.dim + 6.0);          // per frame
+            const double rate = !set.h2s.params.empty() ? 700e12 : (!set.h2.params.empty() || !set.bx3.params.empty() || !set.shared.params.empty()) ? 350e12 : 60e12;
+            const double dev_s = flops / rate + 2.7e-9;
+            const double link_s = (double)m->mfcc->frame_shift * sizeof(int16_t) / 55e9;
+            s.schedule = dev_s / link_s >= 3.5 ? 1 : 0;
+            s.votes = 0;
+        }
         const double rho = s.schedule ? MULTI_GROWTH : 1.0;
         const int want_n = s.schedule ? 4 : want;
         const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want_n, U), total / ((int64_t)1 << 20)));
