@@ -33,7 +33,10 @@
 using namespace sr;
 
 constexpr int MULTI_CHUNKS = 8;         // a slot's utterances are uploaded and scored in up to this many pieces
-constexpr int MULTI_DEFAULT_PIECES = 6; // ... and in this many (6 equal pieces measured best: profiles/r04)
+constexpr int MULTI_DEFAULT_PIECES = 8; // ... and in this many when copy and kernels are about as long: eight, each 1.1 x the one before
+constexpr double MULTI_MILD_GROWTH = 1.1;   // (round 6, configs[1] from page-locked PCM, 12 calls each in one session: 6 equal pieces 7.4-7.8 ms,
+                                        // 8 equal 7.3-7.5, 8 x 1.1 7.13-7.30, 8 x 1.2 7.26-7.43, 8 x 1.3 7.5-7.6, 5 x 1.25 7.8-7.9, 4 x 1.5 8.4-8.6:
+                                        // the kernels of a piece -- 1.15 ms against its 0.95 ms of link time -- are the longer leg by a little)
 constexpr double MULTI_GROWTH = 3.0;    // kernel-bound slots (run_slot): every piece this many times everything before it
 std::atomic<int> &multi_merge_option() {     // sr_set_option("multi_merge_same_device", 0 | 1)
     static std::atomic<int> v{1};
@@ -221,7 +224,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
             s.schedule = dev_s / link_s >= 3.5 ? 1 : 0;
             s.votes = 0;
         }
-        const double rho = s.schedule ? MULTI_GROWTH : 1.0;
+        const double rho = s.schedule ? MULTI_GROWTH : MULTI_MILD_GROWTH;
         const int want_n = s.schedule ? 4 : want;
         const int n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want_n, U), total / ((int64_t)1 << 20)));
         double cum[MULTI_CHUNKS + 1];                    // cumulative shares S_k, cum[n_chunks] = 1
