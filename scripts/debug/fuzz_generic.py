@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised check of the generic engines (vector ALU, split-bf16, split-fp16, automatic incl. the hybrid
-form) against the float64 oracle: random dims 1..64, K 1..200, 1..6 models of different sizes, weights with zeros,
+form) against the float64 oracle: random dims 1..64 (one case in four: 65..330, the wide rows of the vector engine and its D-sliced
+kernels, round 6), K 1..200, 1..6 models of different sizes, weights with zeros,
 shifted / scaled feature spaces, ragged utterances, far outliers, clamp on / off.  `fuzz_generic.py [cases] [seed]`"""
 import os
 import sys
@@ -21,11 +22,13 @@ worst = {}
 fails = 0
 for c in range(cases):
     D, S = int(rng.integers(1, 65)), int(rng.integers(1, 7))
+    if rng.random() < 0.25:
+        D = int(rng.integers(65, 331))
     shift = float(rng.choice([0.0, 0.0, 5.0, -40.0]))          # feature spaces away from the origin
     scale = float(rng.choice([1.0, 1.0, 0.05, 30.0]))
     models = []
     for s in range(S):
-        K = int(rng.integers(1, 201))
+        K = int(rng.integers(1, 201 if D <= 64 else 41))
         w, mu, sg = synth.synth_gmm(K, D, int(rng.integers(1 << 30)))
         w = w.copy()
         if K > 3 and rng.random() < 0.3:
@@ -45,7 +48,7 @@ for c in range(cases):
     compat = bool(rng.integers(2))
     want = np.stack([go.score_batch(go.GMMParams(*m), X, go.MODE_LOGSUMEXP, clamp_compat=compat) for m in models])
     ms = ModelSet([GMM.from_arrays(*m) for m in models])
-    for eng in (0, 1, 3, 5):
+    for eng in ((0, 1, 3, 5) if D <= 64 else (0, 1)):
         _lib.set_option("score_engine", eng)
         try:
             sums, arg, fll = ms.score(Batch.from_features(utts), frame_ll=True, clamp_compat=compat)
@@ -72,6 +75,11 @@ for c in range(cases):
         if err >= limit:
             amp = ms.info()["amp"]
             flag = "(forced engine on an ill-conditioned set, amp %.0f)" % amp if eng in (3, 5) and amp > 1000 else "!!"
+            # fp32 sums of D squares against a log-likelihood that happens to cancel to |LL| < 1: sqrt(D) half-ulps of a sum of
+            # ~0.72 D (log2 units) are 1e-4 absolute from D ~ 120 on -- the gate is relative to max(1, |LL|), the noise to the terms
+            jw = np.unravel_index(int(np.argmax(rel)), rel.shape)
+            if flag == "!!" and D > 64 and err < 3e-4 and abs(want[jw]) < 2.0:
+                flag = "(wide row, |LL| < 2: fp32 summation noise of %d terms)" % D
             if flag == "!!":
                 fails += 1
             print("  case %d D %d S %d shift %g scale %g clamp %d engine %d: err %.2e %s [%s]" % (c, D, S, shift, scale, compat, eng, err, flag, name[:50]))
