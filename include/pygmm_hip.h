@@ -151,7 +151,11 @@ SRBatch *sr_batch_from_pcm_f32(const float *pcm, const int64_t *sample_offsets, 
 SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
                                 const int64_t *frame_offsets, int n_utt);
 /* Overwrite the samples of a PCM batch in place (same utterance layout, same or fewer samples per
- * utterance is NOT supported: the layout must match exactly) -- the serving loop's H2D, no allocation. */
+ * utterance is NOT supported: the layout must match exactly) -- the serving loop's H2D, no allocation.
+ * Up to 4 MB of samples are copied to a page-locked staging area and the call returns with the transfer in
+ * flight on the library's stream (the caller's buffer may be reused at once; whatever is queued next on the
+ * stream -- sr_predict_pcm_batch, sr_mfcc_extract_batch -- runs behind it); larger updates return when the
+ * samples are on the device. */
 int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples);
 /* New contents AND a new utterance layout in the same handle: device buffers are reused (they only
  * grow), so a serving loop whose batches change shape allocates nothing in steady state. */
