@@ -146,14 +146,7 @@ void ensure_device() {
     g_ctx[d].n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].main, hipStreamNonBlocking));
     SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].aux, hipStreamNonBlocking));
-    {
-        // the copy stream at the HIGHEST priority: a queue of its own in front of the hardware scheduler, so that an upload's
-        // event marker never sits behind the compute stream's kernels (round 6: with three equal-priority streams the second
-        // from-host configs[2] call ran its uploads one behind each piece's kernels, 336 ms against 278)
-        int lo = 0, hi = 0;
-        SR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        SR_HIP(hipStreamCreateWithPriority(&g_ctx[d].copy, hipStreamNonBlocking, hi));
-    }
+    SR_HIP(hipStreamCreateWithFlags(&g_ctx[d].copy, hipStreamNonBlocking));
     g_ctx[d].stream = g_ctx[d].main;
     g_ready[d] = true;
 }
