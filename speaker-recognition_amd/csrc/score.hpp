@@ -53,8 +53,10 @@ constexpr int SCORE_NO_FLUSH = 0x400;
 // copies, no stream synchronisation -- and clears the pass's counters for the next pass (no memset in front of it).
 constexpr int SCORE_HOST_DELIVER = 0x800;
 constexpr size_t HOST_DELIVER_MAX_BYTES = (size_t)64 << 10;
+constexpr size_t HOST_DELIVER_MAX_UTTS = 256;      // every utterance's workgroup takes a ticket from ONE counter: 2000 utterances x 1 model
+                                                   // (16 KiB of results) lost 80 us per pass to that queue, more than the copies cost
 inline bool host_deliverable(size_t n_utt, size_t n_models) {
-    return n_utt > 0 && n_utt * n_models * sizeof(double) + n_utt * sizeof(int) <= HOST_DELIVER_MAX_BYTES;
+    return n_utt > 0 && n_utt <= HOST_DELIVER_MAX_UTTS && n_utt * n_models * sizeof(double) + n_utt * sizeof(int) <= HOST_DELIVER_MAX_BYTES;
 }
 // what the last workgroup leaves in host memory: this header, then double sums[U][S], then int argmax[U]
 struct DeliverHeader {

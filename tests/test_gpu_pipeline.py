@@ -434,10 +434,10 @@ def test_update_pcm_leaves_the_transfer_in_flight_and_the_callers_buffer_free(bu
             batch.update_pcm(src.copy())               # ... and the one that counts, right behind it
         sums, arg = ex.predict_batch(ms, batch, nd=2)
         assert np.array_equal(sums, want[0]) and np.array_equal(arg, want[1]), i
-    # either side of the delivery limit (U x (20 x 8 + 4) bytes against 64 KiB: 399 utterances land by themselves, 400 are copied),
-    # and well beyond it: every utterance's row equals the two-utterance batch's, bit for bit
+    # either side of the delivery limits (at most 256 utterances and 64 KiB of results land by themselves, more are copied), and
+    # well beyond them: every utterance's row equals the two-utterance batch's, bit for bit
     small = ex.predict_batch(ms, Batch.from_pcm([a[:8000], b[:8000]]), nd=2)
-    for n_utt in (399, 400, 1000):
+    for n_utt in (255, 256, 257, 1000):
         clips = ([a[:8000], b[:8000]] * ((n_utt + 1) // 2))[:n_utt]
         big = ex.predict_batch(ms, Batch.from_pcm(clips), nd=2)
         assert np.array_equal(big[0][:2], small[0]) and np.array_equal(big[1][:2], small[1]), n_utt
