@@ -24,7 +24,6 @@ def main():
     D, T = 39, 1000
     _lib.set_option("score_engine", int(os.environ.get("CFG3_ENGINE", 0)))   # before the set is packed
     _lib.set_option("score_h2s_force_exc", int(os.environ.get("CFG3_FORCE_EXC", 0)))
-    _lib.set_option("score_h2s_tiles_per_launch", int(os.environ.get("CFG3_TPL", 0)))
     _lib.set_option("score_h2s_shape", int(os.environ.get("CFG3_SHAPE", 0)))
     t0 = time.time()
     ubm = synth.synth_gmm(K, D, 99)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""MFCC kernel time (HIP events) on the cfg-1 audio, steady state: `time_mfcc.py [rounds] [waves_per_block]`."""
+"""MFCC kernel time (HIP events) on the cfg-1 audio, steady state: `time_mfcc.py [rounds]`."""
 import os
 import sys
 
@@ -14,8 +14,6 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 clips, _ = bench.build_workload(0, 1000, 1000)
 pcm = Batch.from_pcm(clips)
 ex = MfccExtractor(bench.FS, **bench.MFCC_KW)
-if len(sys.argv) > 2:
-    _lib.set_option("mfcc_waves_per_block", int(sys.argv[2]))
 _lib.profile_enable(True)
 ts = []
 for r in range(rounds):
@@ -23,4 +21,4 @@ for r in range(rounds):
     ex.extract_batch(pcm, nd=2)
     t, n = _lib.profile_get(_lib.T_MFCC)
     ts.append(t)
-print("waves/block %s " % (sys.argv[2] if len(sys.argv) > 2 else "default") + "mfcc kernel: first %.3f ms, steady median %.3f ms, min %.3f ms  [%s]" % (ts[0], float(np.median(ts[rounds // 2:])), min(ts), _lib.LIB_PATH))
+print("mfcc kernel: first %.3f ms, steady median %.3f ms, min %.3f ms  [%s]" % (ts[0], float(np.median(ts[rounds // 2:])), min(ts), _lib.LIB_PATH))

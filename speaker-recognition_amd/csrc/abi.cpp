@@ -757,9 +757,6 @@ int sr_set_option(const char *key, long value) {
                  "5 (split-fp16 matrix cores) or 6 (split-fp16, shared-sigma form); 2 was the fp32 matrix-core engine, removed in round 5 "
                  "(never selected: 1.45-1.8x slower than split-bf16 at the same accuracy)");
         score_options().engine = (int)value;
-    } else if (k == "score_h2s_tiles_per_launch") {
-        if (value < 0) fail("score_h2s_tiles_per_launch must be >= 0");
-        score_options().h2s_tiles_per_launch = (int)value;     // 32-frame tiles; rounded to whole rounds of 8 workgroups
     } else if (k == "score_h2s_shape") {
         if (value < 0 || value > 4)
             fail("score_h2s_shape must be 0 (automatic), 1 (4-wave workgroups), 2 (12-wave workgroups), 3 (12 waves, image loop pipelined inside the wave) "
@@ -795,8 +792,6 @@ int sr_set_option(const char *key, long value) {
         if (value < 0 || value > 2)
             fail("em_stats_engine must be 0 (automatic), 1 (vector ALU) or 2 (fp64 matrix cores, responsibilities on the vector ALU)");
         set_em_stats_engine((int)value);
-    } else if (k == "mfcc_waves_per_block") {
-        mfcc_set_waves_per_block((int)value);
     } else if (k == "multi_merge_same_device") {
         multi_merge_option().store(value != 0);
     } else if (k == "multi_numa_bind") {

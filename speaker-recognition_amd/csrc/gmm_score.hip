@@ -1124,7 +1124,6 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.n_tiles = tt.n_tiles;
             a.log2_k = (float)std::log2((double)h.n_tiles * MT);
             a.force_exc = opt.h2s_force_exc;
-            a.tiles_per_launch = opt.h2s_tiles_per_launch;
             a.shape = h2s_shape;
             if (h2s_shape == 2) {      // the pipelined kernel walks work items: ragged tail tiles share a wave
                 ensure_work_table(tt, opt.h2s_pack_tails != 0);

@@ -1178,8 +1178,7 @@ static int launch_h2s(const H2sLaunch &l) {
     static_assert(!PIN || H2P_ROUND_ITEMS % TILES_WG == 0, "a workgroup's work items never straddle the table's padding");
     // (the 12-wave form has one workgroup per CU sweeping the stream: nothing drifts apart, 1 / 3 / 5 / 9 / 18 launches
     // per configs[2] pass all take 0.281-0.283 s -- one launch)
-    int wg_per_launch = l.tiles_per_launch > 0 ? std::max(8, l.tiles_per_launch / TILES_WG / 8 * 8)
-                        : WAVES > 4 ? std::max(8, (n_wg + 7) / 8 * 8)
+    int wg_per_launch = WAVES > 4 ? std::max(8, (n_wg + 7) / 8 * 8)
                         : std::max(8, (H2S_ROUNDS_PER_LAUNCH * resident / std::max(1, l.n_groups)) / 8 * 8);
     int n_launches = 0;
     for (int base = 0; base < n_wg; base += wg_per_launch) {

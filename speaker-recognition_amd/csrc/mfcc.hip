@@ -899,12 +899,8 @@ static bool &mfcc_force_generic_flag() {
     return f;
 }
 bool mfcc_force_generic() { return mfcc_force_generic_flag(); }
-static int &mfcc_wpb_flag() {
-    static int v = 12;   // measured on cfg-1: 1.885 ms against 1.975 ms with 4 (scripts/time_mfcc.py)
-    return v;
-}
-int mfcc_waves_per_block() { return mfcc_wpb_flag(); }
-void mfcc_set_waves_per_block(int w) { mfcc_wpb_flag() = (w == 12) ? 12 : 4; }
+// (12-wave workgroups of the fp32 FFT-2048 kernel: the A/B against 4-wave ones was settled in round 2 and its switch went in round 6)
+int mfcc_waves_per_block() { return 12; }
 void mfcc_set_force_generic(bool on) { mfcc_force_generic_flag() = on; }
 
 struct MfccScratch {

@@ -36,7 +36,6 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
 void mfcc_set_force_generic(bool on);
 void mfcc_set_precision(int mode);       // 2: float64 spectrum / ln / DCT for every frame (default), 0: fp32 throughout
 int mfcc_precision();
-void mfcc_set_waves_per_block(int w);   // 4 or 12 waves per workgroup in the FFT-2048 kernel
 void lpc_extract_into(SRMfcc &m, SRBatch &pcm, const int64_t *d_frame_off, int64_t n_frames, int n_lpc,
                       float *out, int out_stride, int col_off);   // A/B: route FFT_SIZE 2048 through the generic LDS kernel
 // ltsd.hip: long-term spectral divergence (voice-activity front end)

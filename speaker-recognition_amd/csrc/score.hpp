@@ -16,7 +16,6 @@ struct ScoreOptions {
                                // 5 = split-fp16 (2 parts, 3 products) matrix-core kernel;
                                // 6 = split-fp16, shared-sigma form
     int mfma_ft = 0;           // 32-frame column tiles per wave in the 4-wave generic split kernels (0 = one)
-    int h2s_tiles_per_launch = 0;   // frame tiles per launch of the split-fp16 shared-sigma engine (0 = automatic)
     int h2s_shape = 0;         // workgroup shape of the split-fp16 shared-sigma engine: 0 = automatic; 1 = 4 waves (three
                                // workgroups per CU); 2 = 12 waves (one per CU, one copy of the stream in LDS); 3 = 12 waves with the
                                // image loop software-pipelined inside each wave (gmm_score_h2p_kernel)
@@ -115,7 +114,6 @@ struct H2sLaunch {
     int dim, n_models, n_mix_tiles, clamp, n_groups, n_tiles;
     float log2_k;
     int force_exc;
-    int tiles_per_launch;   // 0 = automatic (H2S_ROUNDS_PER_LAUNCH rounds of resident workgroups)
     int shape = 0;          // 0: 4-wave workgroups; 1: 12-wave workgroups (`tiles` = 32-frame tiles); 2: 12 waves, pipelined (gmm_score_h2p_kernel)
     float band_hi = -__builtin_inff();
 };
