@@ -54,7 +54,8 @@ struct SRMulti {
         int u0 = 0, u1 = 0;                 // range of the slot's utterances
         SRBatch feat;
         MfccScratch *scratch = nullptr;
-        PinnedBuf<double> h_sums;
+        PinnedBuf<double> h_sums;           // (+ room for the argmax values right behind the sums: they come in one copy, as they lie in the workspace)
+        int *h_arg = nullptr;               // where this pass's argmax values landed (behind the sums, or h_argmax)
         PinnedBuf<int> h_argmax, h_flags;   // h_flags: {a frame saturated the fp16 engine, (tile, model) pairs in the partial-product band}
         // the piece's list of (tile, model) pairs in the band, set aside on the device (the scoring workspace it was produced in
         // belongs to the next piece by then): what gmm_flush.hip re-evaluates when it is not empty
@@ -270,7 +271,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                     b.d_offsets.upload(b.offsets.data(), b.offsets.size());
                     sync_stream();
                 }
-                ch.h_sums.ensure((size_t)std::max(1, nu) * S);
+                ch.h_sums.ensure((size_t)std::max(1, nu) * S + ((size_t)std::max(1, nu) + 1) / 2);
                 ch.h_argmax.ensure((size_t)std::max(1, nu));
                 ch.h_flags.ensure(2);
                 ch.h_flags.p[0] = ch.h_flags.p[1] = 0;         // (nothing of this piece is in flight: the previous call waited for it)
@@ -299,19 +300,29 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
             SR_HIP(hipStreamWaitEvent(ctx().stream, ch.uploaded, 0));
             mfcc_extract_with(*m->mfcc, b, nd, 1, ch.feat, ch.scratch);
             const ScoreResult r = score_device(*s.set, ch.feat, false, flags);
-            if (r.d_oor) SR_HIP(hipMemcpyAsync(ch.h_flags.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            // (the pass's two counters and its sums + argmax lie side by side in the workspace: one copy each instead of two -- a copy
+            // is ~8 us on the stream, and eight pieces' small operations are what keeps the call above max(copy, kernels))
+            const bool flags_together = r.d_oor && r.d_flush_count == r.d_oor + 1;
+            if (flags_together) SR_HIP(hipMemcpyAsync(ch.h_flags.p, r.d_oor, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            else if (r.d_oor) SR_HIP(hipMemcpyAsync(ch.h_flags.p, r.d_oor, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
             ch.tiles = r.tiles;
             ch.flush_cap = 0;
             if (r.d_flush_count) {
                 // frames in the band of the reference's partial-product flushes are the NORMAL case on some workloads (synthetic
                 // speech against random models: ~2 k pairs per 10 M frames): keep what resolving them needs, a few MB device to device
-                SR_HIP(hipMemcpyAsync(ch.h_flags.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+                if (!flags_together) SR_HIP(hipMemcpyAsync(ch.h_flags.p + 1, r.d_flush_count, sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
                 ch.d_list.ensure((size_t)std::max(1, r.flush_cap));
                 ch.flush_cap = r.flush_cap;
                 SR_HIP(hipMemcpyAsync(ch.d_list.p, r.d_flush_list, (size_t)r.flush_cap * sizeof(int2), hipMemcpyDeviceToDevice, ctx().stream));
             }
-            SR_HIP(hipMemcpyAsync(ch.h_sums.p, r.d_sums, (size_t)nu * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
-            SR_HIP(hipMemcpyAsync(ch.h_argmax.p, r.d_argmax, (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+            if ((const void *)r.d_argmax == (const void *)(r.d_sums + (size_t)nu * S)) {
+                SR_HIP(hipMemcpyAsync(ch.h_sums.p, r.d_sums, (size_t)nu * S * sizeof(double) + (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+                ch.h_arg = reinterpret_cast<int *>(ch.h_sums.p + (size_t)nu * S);
+            } else {
+                SR_HIP(hipMemcpyAsync(ch.h_sums.p, r.d_sums, (size_t)nu * S * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+                SR_HIP(hipMemcpyAsync(ch.h_argmax.p, r.d_argmax, (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, ctx().stream));
+                ch.h_arg = ch.h_argmax.p;
+            }
             SR_HIP(hipEventRecord(ch.done, ctx().stream));
         }
         // ---- collect: one wait per piece, in order; the rare piece that needs the host is redone from its features
@@ -327,12 +338,13 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                 // pieces' kernels
                 std::lock_guard<std::recursive_mutex> lock(api_mutex());
                 StreamScope side(ctx().aux);
-                flush_resolve_host(*s.set, ch.feat, *ch.tiles, ch.d_list.p, ch.h_flags.p[1], ch.h_sums.p, ch.h_argmax.p);
+                flush_resolve_host(*s.set, ch.feat, *ch.tiles, ch.d_list.p, ch.h_flags.p[1], ch.h_sums.p, ch.h_arg);
             } else if (ch.h_flags.p[0] != 0 || ch.h_flags.p[1] != 0) {
                 // a frame saturated the fp16 engine, or the list overflowed: this piece again, synchronously, from its features
                 std::lock_guard<std::recursive_mutex> lock(api_mutex());
                 const int fl = flags | (ch.h_flags.p[0] != 0 ? SCORE_PRECISE : 0);
                 ScoreResult r = score_device(*s.set, ch.feat, false, fl);
+                ch.h_arg = ch.h_argmax.p;
                 if (!fetch_results(*s.set, ch.feat, fl, r, ch.h_sums.p, ch.h_argmax.p, nullptr)) {
                     r = score_device(*s.set, ch.feat, false, fl | SCORE_PRECISE);
                     fetch_results(*s.set, ch.feat, fl | SCORE_PRECISE, r, ch.h_sums.p, ch.h_argmax.p, nullptr);
@@ -345,8 +357,8 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                 const size_t n = (size_t)(j + 1 - i), at = (size_t)(i - ch.u0);
                 if (sums_out) std::memcpy(sums_out + (size_t)s.utts[i] * S, ch.h_sums.p + at * S, n * S * sizeof(double));
                 else std::memcpy(s.sums.data() + (size_t)i * S, ch.h_sums.p + at * S, n * S * sizeof(double));
-                if (argmax_out) std::memcpy(argmax_out + s.utts[i], ch.h_argmax.p + at, n * sizeof(int));
-                else std::memcpy(s.argmax.data() + i, ch.h_argmax.p + at, n * sizeof(int));
+                if (argmax_out) std::memcpy(argmax_out + s.utts[i], ch.h_arg + at, n * sizeof(int));
+                else std::memcpy(s.argmax.data() + i, ch.h_arg + at, n * sizeof(int));
                 i = j + 1;
             }
         }
