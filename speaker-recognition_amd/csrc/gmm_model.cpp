@@ -817,4 +817,59 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models) {
     return pm;
 }
 
+// ---- mel gather starts (see gmm_model.hpp) ----
+static const int kMelGroupBands[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
+
+int mel_sweep_extra_cycles(const int *start, const int *cnt, int n_bands, int pass) {
+    int extra = 0;
+    for (int g = 0; g < 4; g++) {
+        int slots[16] = {0}, worst = 1;
+        for (int i = 0; i < 4; i++) {
+            const int b = 16 * pass + kMelGroupBands[g][i];
+            if (b >= n_bands || cnt[b] <= 0) continue;
+            for (int q4 = 0; q4 < 4; q4++) worst = std::max(worst, ++slots[((start[b] >> 2) + q4) & 15]);
+        }
+        extra += worst - 1;
+    }
+    return extra;
+}
+
+void mel_sweep_starts(const int *col0, const int *cnt, int n_bands, const int pass_len[4], int *start) {
+    for (int b = 0; b < n_bands; b++) start[b] = col0[b] & ~3;
+    for (int ps = 0; ps < 4; ps++) {
+        const int Lp = pass_len[ps];
+        for (int g = 0; g < 4; g++) {
+            int bands[4], nb = 0;
+            for (int i = 0; i < 4; i++) {
+                const int b = 16 * ps + kMelGroupBands[g][i];
+                if (b < n_bands && cnt[b] > 0) bands[nb++] = b;
+            }
+            if (nb < 2) continue;
+            int kmax[4] = {0, 0, 0, 0};
+            for (int i = 0; i < nb; i++) {
+                const int b = bands[i], st0 = col0[b] & ~3;
+                while (kmax[i] < 15 && st0 - 4 * (kmax[i] + 1) >= 0 && col0[b] - (st0 - 4 * (kmax[i] + 1)) + cnt[b] <= Lp) kmax[i]++;
+            }
+            int best_cost = 1 << 30, best_k[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0};
+            for (;;) {
+                int slots[16] = {0}, worst = 0, pad = 0;
+                for (int i = 0; i < nb; i++) {
+                    const int sl = (((col0[bands[i]] & ~3) - 4 * k[i]) >> 2) & 15;
+                    for (int q4 = 0; q4 < 4; q4++) worst = std::max(worst, ++slots[(sl + q4) & 15]);
+                    pad += k[i];
+                }
+                const int cost = (worst - 1) * 1024 + pad;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    for (int i = 0; i < nb; i++) best_k[i] = k[i];
+                }
+                int i = 0;
+                while (i < nb && ++k[i] > kmax[i]) k[i++] = 0;
+                if (i == nb) break;
+            }
+            for (int i = 0; i < nb; i++) start[bands[i]] = (col0[bands[i]] & ~3) - 4 * best_k[i];
+        }
+    }
+}
+
 }  // namespace sr

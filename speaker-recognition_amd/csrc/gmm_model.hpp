@@ -171,6 +171,12 @@ PackedH2Shared pack_models_h2_shared(const std::vector<const GMM *> &models);
 // workgroups out of phase with the others of their XCD and the parameter stream out of its L2).  Host-only: tests/host/host_checks.cpp.
 struct WorkItem { int t[4]; };
 std::vector<WorkItem> pack_tail_tiles(const std::vector<int> &counts, int frames_per_tile, bool pack_tails);
+// Sweep starts of the MFCC kernels' mel gather (mfcc.hip: four lanes per band, one ds_read_b128 each per step, bands {0,3,5,6},
+// {1,2,4,7}, {8,11,13,14}, {9,10,12,15} of a pass of 16 served together over 16 slots of 16 bytes): start[b] <= col0[b], a multiple
+// of 4, >= 0, moved down only as far as the band's padded run still fits pass_len[b / 16]; per group the choice with the fewest extra
+// LDS cycles, then the least padding.  Host-only.
+void mel_sweep_starts(const int *col0, const int *cnt, int n_bands, const int pass_len[4], int *start);
+int mel_sweep_extra_cycles(const int *start, const int *cnt, int n_bands, int pass);      // extra LDS cycles per read instruction of that pass
 bool models_share_sigma_and_weights(const std::vector<const GMM *> &models);
 PackedBx3Shared pack_models_bx3_shared(const std::vector<const GMM *> &models);
 void split_bf16x3(float v, uint16_t out[3]);   // round-to-nearest-even hi/mid/lo parts

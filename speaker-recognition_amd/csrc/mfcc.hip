@@ -10,6 +10,7 @@
 // sparse row sweep with a wave64 shuffle reduction per band; constants are fp32 copies of
 // float64 tables built on the host exactly as the reference builds them.
 #include "batch.hpp"
+#include "gmm_model.hpp"
 #include "mfcc.hpp"
 #include "mfcc_dev.hpp"
 #include "wave_ops.hpp"
@@ -793,45 +794,8 @@ MfccDev upload_tables(SRMfcc &m) {
         // round 5 the starts avoided conflicts of a 32-lane / 8-window model that is not this instruction's: 4-6 extra cycles
         // per read in the first three passes of the 16 kHz bank, SQ_LDS_BANK_CONFLICT 7 % of the kernel's LDS cycles; now 2.)
         std::vector<int> start(64, 0), lead(64, 0);
-        {
-            static const int kGroupBands[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12, 15}};
-            for (int b = 0; b < B; b++) start[b] = col0[b] & ~3;
-            for (int ps = 0; ps < 4; ps++) {
-                const int Lp = t->pass_len[ps];                    // (from the unpadded runs above: never grown here)
-                for (int g = 0; g < 4; g++) {
-                    int bands[4], nb = 0;
-                    for (int i = 0; i < 4; i++) {
-                        const int b = 16 * ps + kGroupBands[g][i];
-                        if (b < B && cnt[b] > 0) bands[nb++] = b;
-                    }
-                    if (nb < 2) continue;
-                    int kmax[4] = {0, 0, 0, 0};
-                    for (int i = 0; i < nb; i++) {
-                        const int b = bands[i], st0 = col0[b] & ~3;
-                        while (kmax[i] < 15 && st0 - 4 * (kmax[i] + 1) >= 0 && col0[b] - (st0 - 4 * (kmax[i] + 1)) + cnt[b] <= Lp) kmax[i]++;
-                    }
-                    int best_cost = 1 << 30, best_k[4] = {0, 0, 0, 0}, k[4] = {0, 0, 0, 0};
-                    for (;;) {
-                        int slots[16] = {0}, worst = 0, pad = 0;
-                        for (int i = 0; i < nb; i++) {
-                            const int sl = (((col0[bands[i]] & ~3) - 4 * k[i]) >> 2) & 15;
-                            for (int q4 = 0; q4 < 4; q4++) worst = std::max(worst, ++slots[(sl + q4) & 15]);
-                            pad += k[i];
-                        }
-                        const int cost = (worst - 1) * 1024 + pad;
-                        if (cost < best_cost) {
-                            best_cost = cost;
-                            for (int i = 0; i < nb; i++) best_k[i] = k[i];
-                        }
-                        int i = 0;
-                        while (i < nb && ++k[i] > kmax[i]) k[i++] = 0;
-                        if (i == nb) break;
-                    }
-                    for (int i = 0; i < nb; i++) start[bands[i]] = (col0[bands[i]] & ~3) - 4 * best_k[i];
-                }
-            }
-            for (int b = 0; b < B; b++) lead[b] = cnt[b] ? col0[b] - start[b] : 0;
-        }
+        mel_sweep_starts(col0.data(), cnt.data(), B, t->pass_len, start.data());       // (gmm_model.cpp: host-only, under the sanitizers in tests/host)
+        for (int b = 0; b < B; b++) lead[b] = cnt[b] ? col0[b] - start[b] : 0;
         for (int ps = 0; ps < 4; ps++) t->pass_len[ps] = 0;
         for (int b = 0; b < B; b++)
             t->pass_len[b / 16] = std::max(t->pass_len[b / 16], ((lead[b] + cnt[b] + 15) / 16) * 16);

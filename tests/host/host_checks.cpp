@@ -1,4 +1,4 @@
-// Host-side checks of csrc/gmm_model.cpp, built by tests/test_host_sanitizers.py with -fsanitize=address,undefined (and once
+// Host-side checks of csrc/gmm_model.cpp (model packers, text format, tail packing, the MFCC kernels' mel sweep starts), built by tests/test_host_sanitizers.py with -fsanitize=address,undefined (and once
 // with -fsanitize=thread): the model packers (every layout, threaded and not), the text parser on mutated model texts, and
 // the printf / strtod-free number conversions against libc.  Test infrastructure: not part of lib/pygmm.so.
 #include "gmm_model.hpp"
@@ -193,12 +193,57 @@ static int check_tail_packing() {
     return 0;
 }
 
+// mel_sweep_starts: starts are multiples of 4, never negative, never above the band's first column, the padded run fits the pass
+// wherever the unshifted one did, and no group of bands served together conflicts more than with the unshifted starts; on the
+// reference's own 16 kHz / 50-filter bank shape (runs growing with the band index) the first three passes come down to 2 extra
+// cycles per read (round 5's choice: 4 / 6 / 4).
+static int check_mel_starts() {
+    std::mt19937 rng(11);
+    for (int round = 0; round < 300; round++) {
+        const int B = 1 + (int)(rng() % 64);
+        int col0[64] = {0}, cnt[64] = {0}, start[64] = {0}, naive[64] = {0}, pass_len[4] = {0, 0, 0, 0};
+        int c = (int)(rng() % 8);
+        for (int b = 0; b < B; b++) {
+            cnt[b] = (rng() % 20 == 0) ? 0 : 1 + (int)(rng() % (round % 3 == 0 ? 12 : 4 + 3 * b));
+            col0[b] = c;
+            c += 1 + (int)(rng() % (2 + cnt[b]));
+            naive[b] = col0[b] & ~3;
+            pass_len[b / 16] = std::max(pass_len[b / 16], ((cnt[b] + 15) / 16) * 16);
+        }
+        mel_sweep_starts(col0, cnt, B, pass_len, start);
+        for (int b = 0; b < B; b++) {
+            if (cnt[b] == 0) continue;
+            if (start[b] < 0 || (start[b] & 3) || start[b] > col0[b]) return 1;
+            const bool fitted = col0[b] - naive[b] + cnt[b] <= pass_len[b / 16];
+            if (fitted && col0[b] - start[b] + cnt[b] > pass_len[b / 16]) return 2;
+            if (!fitted && start[b] != naive[b]) return 3;
+        }
+        for (int ps = 0; ps < 4; ps++)
+            if (mel_sweep_extra_cycles(start, cnt, B, ps) > mel_sweep_extra_cycles(naive, cnt, B, ps)) return 4;
+    }
+    // the 16 kHz bank of MFCC.py's defaults: first columns and run lengths as tests/golden's melbank has them
+    const int col16k[50] = {1, 5, 10, 15, 20, 26, 31, 38, 44, 51, 58, 65, 73, 81, 90, 99, 108, 118, 129, 140, 152, 164, 177, 190, 204, 219, 235, 251, 268,
+                            286, 305, 325, 346, 368, 392, 416, 442, 468, 497, 526, 558, 590, 625, 661, 699, 739, 781, 825, 871, 920};
+    const int cnt16k[50] = {9, 10, 10, 11, 11, 12, 13, 13, 14, 14, 15, 16, 17, 18, 18, 19, 21, 22, 23, 24, 25, 26, 27, 29, 31, 32, 33, 35, 37, 39, 41, 43,
+                            46, 48, 50, 52, 55, 58, 61, 64, 67, 71, 74, 78, 82, 86, 90, 95, 100, 104};
+    const int len16k[4] = {32, 48, 96, 112};
+    int st[64] = {0};
+    mel_sweep_starts(col16k, cnt16k, 50, len16k, st);
+    for (int ps = 0; ps < 3; ps++)
+        if (mel_sweep_extra_cycles(st, cnt16k, 50, ps) > 2) return 5;
+    if (mel_sweep_extra_cycles(st, cnt16k, 50, 3) != 0) return 6;
+    for (int b = 0; b < 50; b++)
+        if (col16k[b] - st[b] + cnt16k[b] > len16k[b / 16]) return 7;          // the kernels' unrolled sweep lengths (mel_preset_steps) stand
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const bool big = argc > 1 && std::strcmp(argv[1], "threads") == 0;     // sizes at which the packers go multi-threaded
     int rc = big ? check_packers(150, 1024, 39) : (check_packers(17, 37, 13) | check_packers(31, 64, 39));
     if (rc) return printf("packers: %d\n", rc), 10 + rc;
     if (!big) {
         if ((rc = check_tail_packing())) return printf("tail packing: %d\n", rc), 40 + rc;
+        if ((rc = check_mel_starts())) return printf("mel starts: %d\n", rc), 60 + rc;
         if ((rc = check_parser(20000))) return printf("parser: %d\n", rc), 20 + rc;
         if ((rc = check_numbers(300000))) return printf("numbers: %d\n", rc), 30 + rc;
     }
