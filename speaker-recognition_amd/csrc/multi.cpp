@@ -201,13 +201,14 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
         // the per-piece launches do not add up (round 4's sweep, HISTORY.md section 5; page-locked PCM: 1 piece 11.3 ms, 2 8.7,
         // 4 7.5, 6 7.2, 8 7.25; a small-first / small-last shape, round 4's first attempt, 7.7)
         //
-        // Round 6: equal pieces are right when copy and kernels are about as long.  When the kernels are the longer leg by a
+        // Round 6: (nearly) equal pieces -- eight now, each MULTI_MILD_GROWTH x the one before: with the float64 feature stage a piece's
+        // kernels are the longer leg by a fifth -- are right when copy and kernels are about as long.  When the kernels are the longer leg by a
         // factor rho (configs[2]: 3.2 GB = 58 ms of link time under 280 ms of kernels, rho ~ 4.8) the only exposed copy is the
         // FIRST piece's, and a piece may be rho times everything before it without the device ever waiting for its bytes:
         // cumulative shares S_k = rho S_{k-1} + s_0, S_{n-1} = 1  =>  s_0 = (rho - 1) / (rho^n - 1).  Two shapes only (a new
-        // shape means new buffers and tables for every piece): equal pieces, and four pieces growing by MULTI_GROWTH = 3
-        // (2.5 / 7.5 / 22.5 / 67.5 %) once two passes in a row on a batch of about this size measured rho >= 3.5; back to equal
-        // pieces when two in a row measure < 2.5.  Pieces are whole utterances and an utterance's results do not depend on the batch
+        // shape means new buffers and tables for every piece): the balanced one above, and four pieces growing by MULTI_GROWTH = 3
+        // (2.5 / 7.5 / 22.5 / 67.5 %) once two passes in a row on a batch of about this size measured rho >= 3.5; back to the
+        // balanced one when two in a row measure < 2.5.  Pieces are whole utterances and an utterance's results do not depend on the batch
         // around it: the bits are the same for any cut.
         // The FIRST pass on a batch of this size starts from an estimate (the measured adaptation took four calls to settle --
         // two equal-piece passes, one that allocated the new pieces' buffers, one more -- 350 / 337 / 454 / 335 ms before 276 on
