@@ -11,7 +11,7 @@ from speaker_recognition_amd.pygmm import GMM
 ubm = synth.synth_gmm(512, 39, 99)
 ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + [synth.synth_map_speaker(ubm, 500 + s) for s in range(200)]])
 _lib.profile_enable(True)
-for U in (1, 2, 4, 8, 16, 32, 64, 128, 256):
+for U in (1, 2, 3, 4, 6, 8, 16, 32, 64):
     feats = Batch.from_features([synth.draw_frames(ubm, 300, 10 + u) for u in range(U)])
     out = []
     for shape in (1, 2, 3, 4):

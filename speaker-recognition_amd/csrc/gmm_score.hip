@@ -933,8 +933,11 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
         // with the block's models dealt to its four waves (gmm_score_h2_shared.hip).  Every such workgroup streams its block's
         // images for ONE tile, so beyond one workgroup per CU the stream (L2 / fabric, 6 TB/s measured) bounds it: 300 frames
         // 0.094 against 0.115 ms, 600 frames 0.123 against 0.114, 1200 frames 0.197 against 0.115 (scripts/ab_h2s_small.py)
+        // Round 6: with the images fetched straight into registers (gmm_score_h2m_kernel: no LDS stage to wait out) two such
+        // workgroups per CU run side by side -- 300 frames 0.074 ms, 600 and 900 frames 0.095 against 0.112 for the 4-wave shape,
+        // 1200 frames (a third workgroup per CU: a second round) 0.141 against 0.111.
         const int64_t ms_wgs = n32 * (int64_t)set.h2s.blocks.size();
-        const bool tiny = ms_wgs <= (int64_t)ctx().n_cu;
+        const bool tiny = ms_wgs <= (int64_t)ctx().n_cu * (h2s_msplit_direct(set.h2s.kqf, set.h2s.klf) ? 2 : 1);
         h2s_shape = opt.h2s_shape ? opt.h2s_shape - 1 : (tiny ? H2S_MSPLIT_SHAPE : wide ? H2S_PIPELINED_SHAPE : 0);
         if (h2s_shape == H2S_PIPELINED_SHAPE && !h2s_pipelined_available(set.h2s.kqf, set.h2s.klf)) h2s_shape = H2S_WIDE_SHAPE;
     }

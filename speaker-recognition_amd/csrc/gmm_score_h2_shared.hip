@@ -519,6 +519,148 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
     }
 }
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, class F>
+__device__ __forceinline__ void h2p_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        h2p_for<I + 1, N>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// gmm_score_h2m_kernel (round 6): the model-split shape of the smallest batches -- a serving decision is ten 32-frame tiles --
+// with every wave fetching ITS images straight into registers, two images ahead, instead of the workgroup staging all sixteen
+// through LDS.  What the LDS form (round 4: gmm_score_h2s_kernel<.., MS>) measured: 62 us of a 131 us decision, 140 workgroups
+// streaming 2 MB each -- and a two-tile workgroup that streams half as much per frame was SLOWER (0.109 against 0.080 ms): the
+// kernel waits out a round trip to the L2 / fabric per stage (64 stages per block, ~1 us each, one 32 KB stage in flight per
+// CU), not its bytes.  A wave needs only the quadratic image and its quarter of the fifteen linear ones (4.75 of 16 per
+// mixture tile); nothing but the quadratic image is shared, so the LDS bought one image in five and cost every wave the reads
+// of all sixteen plus 64 barriers.  Here: no LDS, no barriers in the image loop, two register sets of KM fragments refilled as
+// soon as their chain has issued (the compiler places the vmcnt waits: plain loads into registers), 2 x 4 waves x 8 KB in flight
+// per CU.  Same arithmetic in the same order as the LDS form (a (frame, model) value is formed by one lane over the mixture
+// tiles in order): same bits.
+constexpr int H2M_MAX_KLF = 9;        // two register sets of fragments fit up to here (D <= 45); the longest chains keep the LDS form
+template <int KQF, int KLF>
+__global__ __launch_bounds__(256, 2)
+void gmm_score_h2m_kernel(const H2sArgs a) {
+    constexpr int SB = SHARED_SB;
+    constexpr int KM = KQF > KLF ? KQF : KLF;
+    constexpr int IMG_U4 = KM * 64;
+    constexpr int STRIDE_U4 = (1 + SB) * IMG_U4;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31;
+    const int hh = lane >> 5;
+    if (tid == 0) s_bad = 0;                                   // (published by the barrier of the first close)
+
+    int g, tile0;
+    if (!h2s_wg_assignment(a, 1, g, tile0)) return;
+    const int blk_begin = a.group_block_begin[g];
+    const int blk_end = a.group_block_begin[g + 1];
+    const bool has = tile0 < a.n_tiles;
+    const TileDesc tile = a.tiles[has ? tile0 : a.n_tiles - 1];
+    const bool valid = has && col < tile.count;
+    const int64_t row = tile.start + (valid ? col : 0);
+    // the quadratic-half frame fragments: the same for the four waves (one tile), used once per 4-5 images -- in LDS (KQF KiB),
+    // written by wave 0, not in 4 x KQF registers per lane (with them the kernel spilled 7 dwords: a reload in the image loop
+    // waits for the prefetches in flight)
+    __shared__ uint4 s_bq[KQF * 64];
+    f16x8 bl[KLF];
+    float zmax = 0.0f;
+    {
+        f16x8 bq[KQF];
+        h2s_build_b<KQF>(bq, a.X + row * a.dim, a.center, a.scale, a.q_desc, hh, true, zmax);
+        if (wave == 0) {
+#pragma unroll
+            for (int ks = 0; ks < KQF; ks++) s_bq[ks * 64 + lane] = __builtin_bit_cast(uint4, bq[ks]);
+        }
+    }
+    h2s_build_b<KLF>(bl, a.X + row * a.dim, a.center, a.scale, a.l_desc, hh, false, zmax);
+    __syncthreads();
+    const float off = a.ref_ll[row] * H2S_LOG2E;
+    if (zmax >= 255.0f) atomicOr(a.oor_flag, 1);
+    const float safe_ll2 = a.clamp ? fmaxf(LSE_MINLOG2 + LSE_NEAR + a.log2_k, a.band_hi * H2S_LOG2E + 1.0f) : -3.0e38f;
+    const f32x16 zero1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (int blk = blk_begin; blk < blk_end; blk++) {
+        const SharedBlock sb = a.blocks[blk];
+        const uint4 *base = a.params + sb.offset_u4 + lane;
+        float ssum4[4] = {0.0f, 0.0f, 0.0f, 0.0f};             // this wave's models wave, wave + 4, wave + 8, wave + 12
+        uint4 fr[2][KM];
+        f32x16 qacc = zero1;
+        // image j of a mixture tile for this wave: 0 = the quadratic one, j >= 1 = linear image of model wave + 4 (j - 1)
+        auto img_at = [&](int t, int j) { return base + (size_t)t * STRIDE_U4 + (size_t)(j == 0 ? 0 : 1 + wave + 4 * (j - 1)) * IMG_U4; };
+        auto load = [&](uint4 (&dst)[KM], const uint4 *at, int kn) {
+#pragma unroll
+            for (int ks = 0; ks < KM; ks++)
+                if (ks < kn) dst[ks] = at[ks * 64];
+        };
+        // PT images per mixture tile (5 for waves 0-2, 4 for wave 3), NT tiles per call: PT * NT steps, step u on register set u & 1
+        // (two tiles of five make an even count, so a call always starts on set 0), set u & 1 refilled with step u + 2's image
+        auto run = [&](auto pt_c, auto nt_c, int t0) __attribute__((always_inline)) {
+            constexpr int PT = decltype(pt_c)::value, NT = decltype(nt_c)::value;
+            h2p_for<0, PT * NT>([&](auto uc) {
+                constexpr int U = decltype(uc)::value, TT = U / PT, J = U % PT, SET = U & 1;
+                f32x16 acc;
+                if constexpr (J == 0) {
+                    acc = zero1;
+#pragma unroll
+                    for (int ks = 0; ks < KQF; ks++)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[SET][ks]), __builtin_bit_cast(f16x8, s_bq[ks * 64 + lane]), acc, 0, 0, 0);
+                } else {
+                    acc = qacc;
+#pragma unroll
+                    for (int ks = 0; ks < KLF; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fr[SET][ks]), bl[ks], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {   // the image two steps on, into the set whose chain has just issued
+                    constexpr int U2 = U + 2;
+                    if constexpr (U2 < PT * NT) {
+                        load(fr[SET], img_at(t0 + U2 / PT, U2 % PT), (U2 % PT) == 0 ? KQF : KLF);
+                    } else {
+                        constexpr int J2 = U2 - PT * NT;               // 0 or 1: of the tile after this call's
+                        if (t0 + NT < a.n_mix_tiles) load(fr[SET], img_at(t0 + NT, J2), J2 == 0 ? KQF : KLF);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (J == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[r] -= off;
+                    qacc = acc;
+                } else {
+                    float e0 = 0.0f, e1 = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        e0 += __builtin_amdgcn_exp2f(acc[r]);
+                        e1 += __builtin_amdgcn_exp2f(acc[r + 1]);
+                    }
+                    ssum4[J - 1] += e0 + e1;
+                    asm volatile("" : "+v"(ssum4[J - 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                (void)TT;
+            });
+        };
+        load(fr[0], img_at(0, 0), KQF);
+        load(fr[1], img_at(0, 1), KLF);
+        int t = 0;
+        if (wave < 3) {
+            for (; t + 2 <= a.n_mix_tiles; t += 2) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 2>{}, t);
+            if (t < a.n_mix_tiles) run(std::integral_constant<int, 5>{}, std::integral_constant<int, 1>{}, t);
+        } else {
+            for (; t + 2 <= a.n_mix_tiles; t += 2) run(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, t);
+            if (t < a.n_mix_tiles) run(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{}, t);
+        }
+        float ssum[SB];
+#pragma unroll
+        for (int si = 0; si < SB; si++) ssum[si] = ssum4[si >> 2];          // (its own models: si = wave + 4 k; the others are not read)
+        h2s_close_block<true>(a, sb, blk, ssum, off, valid, has, tile0, row, lane, hh, safe_ll2, wave, &s_bad);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // gmm_score_h2p_kernel (round 3): the 12-wave form with the image loop software-pipelined INSIDE each wave.  What the
 // dispatcher takes for large batches (score_h2s_shape = 3 forces it): 6.5-8.5 % faster than the plain 12-wave kernel above.
@@ -561,13 +703,6 @@ void gmm_score_h2s_kernel(const H2sArgs a) {
 // Barrier B_S sits in front of image (S, 1): stage S + 1 has landed (each wave waits for its own pieces, then the barrier), the
 // fragments of (S + 1, 0) are read during (S, 1); the slot of stage S is free (its last reads were issued during (S, 0)) and takes
 // the LDS-DMA of stage S + 3.
-template <int I, int N, class F>
-__device__ __forceinline__ void h2p_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        h2p_for<I + 1, N>(f);
-    }
-}
 // exps of a 16-value epilogue issued in slots <= u of a KN-slot chain (none in slot 0; all after the chain when KN = 1)
 __host__ __device__ constexpr int h2p_cum(int kn, int u) { return kn <= 1 ? 0 : u <= 0 ? 0 : u >= kn - 1 ? 16 : (16 * u + (kn - 1) / 2) / (kn - 1); }
 // (every exp has a slot, the counts never decrease, and a chain of 5+ MFMAs never asks a slot for more than the 4 that the
@@ -1194,7 +1329,10 @@ static int launch_h2s(const H2sLaunch &l) {
         a.rows8 = (n + 7) / 8;
         a.n_wg = n;
         a.group_major = l.n_groups > 1;
-        constexpr size_t dyn = (BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0) + (MS ? sizeof(uint4) : 0);
+        // (the model-split shape: gmm_score_h2m_kernel, fragments straight into registers, where two sets of them fit; the LDS form
+        // of round 4 for the longest chains -- D = 46 .. 48 -- whose two sets spill)
+        constexpr bool M_DIRECT = MS && KLF <= H2M_MAX_KLF;
+        constexpr size_t dyn = M_DIRECT ? 0 : (BQ_LDS ? (size_t)WAVES * KQF * 64 * sizeof(uint4) : 0) + (MS ? sizeof(uint4) : 0);
         if constexpr (dyn > 0) {
             static bool attr_set[MAX_DEVICES] = {};
             if (!attr_set[ctx().device]) {
@@ -1209,6 +1347,8 @@ static int launch_h2s(const H2sLaunch &l) {
         }
         if constexpr (PIN)
             hipLaunchKernelGGL((gmm_score_h2p_kernel<KQF, KLF>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
+        else if constexpr (M_DIRECT)
+            hipLaunchKernelGGL((gmm_score_h2m_kernel<KQF, KLF>), grid, dim3(WAVES * 64), 0, ctx().stream, a);
         else
             hipLaunchKernelGGL((gmm_score_h2s_kernel<KQF, KLF, COLS, WAVES, MS>), grid, dim3(WAVES * 64), dyn, ctx().stream, a);
     }
@@ -1227,6 +1367,7 @@ static int launch_h2s(const H2sLaunch &l) {
 int h2s_resident_per_cu(int kqf, int klf, int shape) { return (shape == 0 || shape == 3) ? h2s_waves_per_eu(kqf, klf, 1, 4, shape == 3) : 1; }
 int h2s_tiles_per_wg(int shape) { return shape == 0 ? 4 : shape == 3 ? 1 : 12; }
 bool h2s_pipelined_available(int kqf, int klf) { return h2p_fits(kqf, klf); }
+bool h2s_msplit_direct(int kqf, int klf) { (void)kqf; return klf <= H2M_MAX_KLF; }
 
 // returns the number of launches of the main kernel the pass was cut into
 int launch_score_h2_shared(const H2sLaunch &l, int KQF, int KLF) {

@@ -120,6 +120,7 @@ struct H2sLaunch {
 int launch_score_h2_shared(const H2sLaunch &a, int KQF, int KLF);
 int h2s_resident_per_cu(int kqf, int klf, int shape);   // workgroups the kernel variant keeps resident per CU
 int h2s_tiles_per_wg(int shape);                        // 32-frame tiles a workgroup of that shape takes
+bool h2s_msplit_direct(int kqf, int klf);               // shape 3 runs as gmm_score_h2m_kernel (images straight into registers) for these chain lengths
 bool h2s_pipelined_available(int kqf, int klf);         // shape 2 (12 waves, image loop software-pipelined inside each wave) exists for these chain lengths
 // Minimum set size for the shared-sigma engine (blocks of SHARED_SB models; smaller sets would be
 // mostly phantom models).
