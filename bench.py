@@ -480,6 +480,42 @@ def block_published_em(_lib):
             "vs_reference_16_threads": 70.0 / dt, "published_hardware": "unstated (2013 laptop/desktop class): not a like-for-like number"}
 
 
+def block_logged_predict(_lib):
+    """The reference's own logged prediction run (log/final/final-log/nperson-newg-mix-t5.log:85-90, driver src/test/test-nperson.py:133-146):
+    80 speakers, 50 test fragments of 5 s each (8 kHz, 32 / 16 ms frames: 311 frames), 32-mixture models on 34-dim features -- 378 s through
+    pygmm on a multiprocessing.Pool, 53.6 s with scikit-learn (nperson-sklearn-mix-t5.log:85-90), hardware unstated.  Here: the same shape
+    through the same surface (GMMSet.predict on host feature matrices: upload + one fused pass + argmax back), features drawn from the
+    models, every call from HOST memory; and the reference's per-utterance loop (predict_one: a launch per utterance) beside it."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.gmmset import GMMSet
+    from speaker_recognition_amd.pygmm import GMM
+    S, K, D, per, T = 80, 32, 34, 50, 311
+    raw = [synth.synth_gmm(K, D, 300 + s) for s in range(S)]
+    gs = GMMSet(gmm_order=K)
+    for s, m in enumerate(raw):
+        gs._append(s, GMM.from_arrays(*m))
+    utts, truth = [], []
+    for s in range(S):
+        X = synth.draw_frames(raw[s], per * T, 900 + s)
+        for u in range(per):
+            utts.append(X[u * T:(u + 1) * T])
+            truth.append(s)
+    gs.predict(utts[:64])                                             # warm-up: packed set, code objects
+    t0 = time.perf_counter()
+    pred = gs.predict(utts)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    one = [gs.predict_one(x) for x in utts[:400]]
+    dt_one = (time.perf_counter() - t0) * (len(utts) / 400.0)
+    return {"workload": "reference's logged predict run: %d speakers x %d fragments x %d frames, %d mixtures x %d dims (nperson-newg-mix-t5.log:85-90)"
+                        % (S, per, T, K, D),
+            "frames": len(utts) * T, "seconds_batch": dt, "frames_per_s_all_models": len(utts) * T / dt,
+            "seconds_per_utterance_loop": dt_one, "correct": int(sum(int(p == t) for p, t in zip(pred, truth))), "of": len(utts),
+            "loop_agrees_with_batch": bool(one == pred[:400]), "kernel": _lib.last_score_kernel(),
+            "reference_logged_seconds": {"pygmm + multiprocessing": 378.2, "scikit-learn + multiprocessing": 53.6},
+            "vs_reference_pygmm": 378.2 / dt, "published_hardware": "unstated: not a like-for-like number"}
+
+
 def block_multi_slot(_lib, ex, base):
     """The one-process multi-GPU path (sr_multi_predict_pcm: a host thread + model replica per slot, PCM from HOST memory
     in every call, uploaded and scored in up to 8 pieces without a host wait in between) on the configs[1] workload with 1 and
@@ -1291,6 +1327,7 @@ def main():
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
                          ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
                          ("reference_published_em", lambda: block_published_em(_lib)),
+                         ("reference_logged_predict", lambda: block_logged_predict(_lib)),
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),
                          ("sr_multi_predict_pcm_host_pcm", lambda: block_multi_slot(_lib, ex, base)),
                          ("north_star_256x39", lambda: block_point256(_lib, hbm, preq)),

@@ -1136,7 +1136,7 @@ ScoreResult score_device(SRModelSet &set, SRBatch &feat, bool want_frame_ll, int
             a.band_hi = fp.band_hi;
             snprintf(g_last_kernel, sizeof(LastKernel::name),
                      "%s<%d,%d,%s> (shared sigma: quadratic half once per %d models; split-fp16 MFMA, "
-                     "3 products as one contraction; reference-offset log-sum-exp)", h2s_shape == 2 ? "gmm_score_h2p_kernel" : "gmm_score_h2s_kernel",
+                     "3 products as one contraction; reference-offset log-sum-exp)", h2s_shape == 2 ? "gmm_score_h2p_kernel" : (h2s_shape == 3 && h2s_msplit_direct(h.kqf, h.klf)) ? "gmm_score_h2m_kernel" : "gmm_score_h2s_kernel",
                      h.kqf, h.klf, h2s_shape == 2 ? "waves=12, pipelined in the wave" : h2s_shape == 1 ? "waves=12" : h2s_shape == 3 ? "waves=4 on one tile, models split" : "waves=4", SHARED_SB);
             ScopedKernelTimer t(T_SCORE);
             const int n_launches = launch_score_h2_shared(a, h.kqf, h.klf);

@@ -168,6 +168,12 @@ def test_no_hot_kernel_spills(built_lib):
     assert len(piped) >= 12
     for name, r in piped.items():
         assert r["scratch"] == 0 and r["occupancy"] >= 3, (name, r)
+    # the model-split shape of a serving decision with its images straight in registers (round 6): two sets of fragments and nothing
+    # in scratch (a reload in the image loop waits for the prefetches in flight), two workgroups per CU
+    direct = {n: r for n, r in h2s.items() if "gmm_score_h2m_kernel" in n}
+    assert len(direct) >= 12
+    for name, r in direct.items():
+        assert r["scratch"] == 0 and r["occupancy"] >= 2, (name, r)
     mf = _kernel_resources("mfcc")
     head = [r for n, r in mf.items() if "mfcc_frames_fft2048_kernelIsLi4ELi1ELi12ELi16E" in n]
     assert len(head) == 1 and head[0]["scratch"] == 0 and head[0]["occupancy"] >= 3, head

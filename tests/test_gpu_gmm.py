@@ -19,7 +19,7 @@ def _gmm(g, c):
 
 def is_h2(name):
     """the split-fp16 shared-sigma engine, in any of its workgroup shapes"""
-    return "gmm_score_h2s_kernel" in name or "gmm_score_h2p_kernel" in name
+    return "gmm_score_h2s_kernel" in name or "gmm_score_h2p_kernel" in name or "gmm_score_h2m_kernel" in name
 
 
 SHAPE_NAME = {1: "waves=4>", 2: "waves=12>", 3: "pipelined in the wave>", 4: "models split>"}     # score_h2s_shape -> last_score_kernel()
