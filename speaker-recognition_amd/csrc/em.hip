@@ -755,18 +755,46 @@ void burn_reference_rand(int count);
 // the vector engine by itself while the model is outside that layout's range (collapsed variances early in a fit).
 static void pack_em_set(SRModelSet &set, const GMM &gmm) {
     if (gmm.dim <= MAX_MATRIX_DIM && score_options().engine == 0) {
-        // (the two layouts are independent functions of the model: side by side on two host threads, 1.35 -> 0.9 ms at K = 2048 x 39)
-        auto split = std::async(std::launch::async, [&gmm] { return pack_models_split({&gmm}, SPLIT_BF16X3); });
-        set.host = pack_models({&gmm});
-        set.bx3 = split.get();
+        // (the two layouts are independent functions of the model: side by side on two host threads, 1.35 -> 0.9 ms at K = 2048 x 39;
+        // a speaker-sized model -- 16 x 13: microseconds of packing -- is not worth the ~40 us a thread costs to start)
+        if ((size_t)gmm.nr_mixtures * gmm.dim >= 8192) {
+            auto split = std::async(std::launch::async, [&gmm] { return pack_models_split({&gmm}, SPLIT_BF16X3); });
+            set.host = pack_models({&gmm});
+            set.bx3 = split.get();
+        } else {
+            set.host = pack_models({&gmm});
+            set.bx3 = pack_models_split({&gmm}, SPLIT_BF16X3);
+        }
     } else {
         set.host = pack_models({&gmm});
+        set.bx3 = PackedSplit();
     }
+}
+
+// A fit's packed sets are RECYCLED (train_em): a re-packed set keeps its device buffers, so both of its layouts go up here, into
+// the allocations of the iteration before last, behind one wait -- upload_model_set + ensure_bx3_layout on a fresh SRModelSet were
+// six hipMalloc, two waits and, when the set of the previous iteration died, six hipFree (each one a device synchronisation) per
+// iteration: most of a 16-mixture speaker model's 0.16 ms per iteration.
+// (What else a set caches on the device survives a re-pack unchanged: the group tables are keyed by their content, and the per-model
+// record table of gmm_flush.hip is a function of the mixture count and the dimension, which a fit does not change.)
+static void upload_em_set(SRModelSet &s) {
+    ensure_device();
+    s.d_params.upload(s.host.params.data(), s.host.params.size());
+    s.d_center0.upload(s.host.center.data(), s.host.center.size());
+    s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
+    if (!s.bx3.params.empty()) {       // (what ensure_bx3_layout would do on first use: it sees the buffers filled and returns)
+        s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
+        s.d_bx3_chunks.upload(s.bx3.chunks.data(), s.bx3.chunks.size());
+        s.d_bx3_center.upload(s.bx3.center.data(), s.bx3.center.size());
+    }
+    sync_stream();
+    s.device = ctx().device;
 }
 
 struct EmWorkspace {
     DevBuf<float> slabs, mean_f32;
     DevBuf<double> stats, slabs64;
+    PinnedBuf<double> h_stats;        // where an iteration's sums land on the host
 };
 static int &em_stats_engine_option() {
     static int v = 0;       // 0 = automatic (fp64 matrix cores where instantiated; responsibilities on the 16-bit ones where the model allows), 1 = the vector-ALU form always, 2 = fp64 matrix cores with the responsibilities on the vector ALU (round 3's)
@@ -839,26 +867,38 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool trace = param.verbosity >= 2;                 // phase times of every iteration on stdout
     std::shared_ptr<SRModelSet> carried;
+    // the fit's own packed sets, recycled (upload_em_set): at most two are alive at a time -- the one an E-step reads and the one the
+    // total log-likelihood of every second iteration is taken under, which the next E-step then reads
+    std::vector<std::shared_ptr<SRModelSet>> spare;
+    auto take_set = [&]() {
+        if (spare.empty()) return std::make_shared<SRModelSet>();
+        std::shared_ptr<SRModelSet> p = std::move(spare.back());
+        spare.pop_back();
+        return p;
+    };
     for (; it < param.nr_iteration; it++) {
         // ---- E-step ----
         const double t0 = now();
         // (the model as the previous iteration left it is already packed and resident when that iteration computed its total
         // log-likelihood: every second one, gmm.cc:622-623)
         std::shared_ptr<SRModelSet> set_owner = std::move(carried);
+        carried.reset();
         bool fresh = !set_owner;
+        bool own = true;                   // (the UBM handle's set is not this fit's to recycle)
         if (fresh && ubm && it == 0) {
             // MAP: the first E-step runs on the UBM's own parameters (gmm_replace_with, gmmubm.cc:29-38), the same for every
             // speaker enrolled from it -- its handle's packed set serves them all (K = 2048: 1.5 ms of packing per speaker)
             set_owner = single_model_set(ubm);
             fresh = false;
+            own = false;
         }
         if (fresh) {
-            set_owner = std::make_shared<SRModelSet>();
+            set_owner = take_set();
             pack_em_set(*set_owner, gmm);
         }
         SRModelSet &set = *set_owner;
         const double t1 = now();
-        if (fresh) upload_model_set(set);
+        if (fresh) upload_em_set(set);
         if (trace) sync_stream();
         const double t2 = now();
         const int DP = set.host.dp;
@@ -919,14 +959,15 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
                                ctx().stream, w.slabs.p, grid, (int)n_elem, w.stats.p);
         }
         SR_HIP(hipGetLastError());
-        std::vector<double> stats(n_elem);
-        w.stats.download(stats.data(), n_elem);
+        w.h_stats.ensure(n_elem);
+        double *const stats = w.h_stats.p;
+        w.stats.download(stats, n_elem);
         sync_stream();
         if (use_mfma) {
             // T1 = sum g x, T2 = sum g x^2, N = sum g  ->  the centred sums the M-step below works on, about the fp32 mean
             // the vector form centres on: sum g (x - m) = T1 - N m, sum g (x - m)^2 = T2 - 2 m T1 + N m^2 (float64)
             for (int k = 0; k < K; k++) {
-                double *st = stats.data() + (size_t)k * REC;
+                double *st = stats + (size_t)k * REC;
                 const double N = st[2 * DP];
                 for (int d = 0; d < dim; d++) {
                     const double m = (double)(float)gmm.mean[(size_t)k * dim + d];
@@ -953,7 +994,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
                 sync_stream();
                 const double SQRT_2_PI = 2.5066282746310002, MINLOG = -708.396418532264;
                 for (int k : weak) {
-                    double *st = stats.data() + (size_t)k * REC;
+                    double *st = stats + (size_t)k * REC;
                     for (int e = 0; e < REC; e++) st[e] = 0.0;
                     const double *mu = gmm.mean.data() + (size_t)k * dim, *sg = gmm.sigma.data() + (size_t)k * dim;
                     double c = gmm.weights[k] > 0 ? std::log(gmm.weights[k]) : -INFINITY;
@@ -1014,6 +1055,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
             }
         }
         gmm.drop_single();
+        if (own) spare.push_back(std::move(set_owner));       // (the E-step's kernels ended before the sums came back)
         if (trace)
             printf("iter %d: pack %.2f ms, upload %.2f ms, posteriors' denominators %.2f ms, statistics %.2f ms, M-step %.2f ms\n", it,
                    (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
@@ -1030,10 +1072,10 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
             printf("model dumped to %s ...\n", dump_file);
         }
         // total log-likelihood under the updated model (gmm.cc:631-641), reference clamp on
-        carried = std::make_shared<SRModelSet>();
+        carried = take_set();
         SRModelSet &set2 = *carried;
         pack_em_set(set2, gmm);
-        upload_model_set(set2);
+        upload_em_set(set2);
         double ll = 0.0;
         score_batch_set(set2, feat, &ll, nullptr, nullptr, SR_CLAMP_COMPAT | SCORE_PRECISE);
         if (param.verbosity >= 1) printf("iter %d: ll %lf\n", it, ll);
