@@ -484,8 +484,8 @@ def block_logged_predict(_lib):
     """The reference's own logged prediction run (log/final/final-log/nperson-newg-mix-t5.log:85-90, driver src/test/test-nperson.py:133-146):
     80 speakers, 50 test fragments of 5 s each (8 kHz, 32 / 16 ms frames: 311 frames), 32-mixture models on 34-dim features -- 378 s through
     pygmm on a multiprocessing.Pool, 53.6 s with scikit-learn (nperson-sklearn-mix-t5.log:85-90), hardware unstated.  Here: the same shape
-    through the same surface (GMMSet.predict on host feature matrices: upload + one fused pass + argmax back), features drawn from the
-    models, every call from HOST memory; and the reference's per-utterance loop (predict_one: a launch per utterance) beside it."""
+    through the same surface (GMMSet.predict on a list of float64 host feature matrices: conversion, upload, one fused pass, argmax
+    back), features drawn from the models, every call from HOST memory; and the reference's per-utterance loop (predict_one: a launch per utterance) beside it."""
     from speaker_recognition_amd import synth
     from speaker_recognition_amd.gmmset import GMMSet
     from speaker_recognition_amd.pygmm import GMM
@@ -498,7 +498,7 @@ def block_logged_predict(_lib):
     for s in range(S):
         X = synth.draw_frames(raw[s], per * T, 900 + s)
         for u in range(per):
-            utts.append(X[u * T:(u + 1) * T])
+            utts.append(X[u * T:(u + 1) * T].astype(np.float64))      # (what feature extraction returns: float64, MFCC.py:69-79)
             truth.append(s)
     gs.predict(utts[:64])                                             # warm-up: packed set, code objects
     t0 = time.perf_counter()

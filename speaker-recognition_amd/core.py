@@ -49,10 +49,16 @@ class Batch:
     def from_features(cls, X, offsets=None) -> "Batch":
         """``X``: [n, dim] matrix with ``offsets`` [U+1], or a list of [T_u, dim] matrices."""
         if offsets is None and isinstance(X, (list, tuple)):
-            mats = [_lib.f32_matrix(x) for x in X]
+            if X and all(isinstance(x, np.ndarray) and x.ndim == 2 for x in X):
+                # what feature extraction hands over -- float64 matrices (MFCC.py:69-79) -- converted WHILE they are gathered:
+                # one pass over the frames instead of a float32 copy per utterance and a second pass to join them
+                mats = X
+                X = np.concatenate(mats, axis=0, dtype=np.float32, casting="unsafe")
+            else:
+                mats = [_lib.f32_matrix(x) for x in X]
+                X = np.concatenate(mats, axis=0) if mats else np.zeros((0, 1), np.float32)
             offsets = np.zeros(len(mats) + 1, dtype=np.int64)
             offsets[1:] = np.cumsum([m.shape[0] for m in mats])
-            X = np.concatenate(mats, axis=0) if mats else np.zeros((0, 1), np.float32)
         X = _lib.f32_matrix(X)
         if offsets is None:
             offsets = np.array([0, X.shape[0]], dtype=np.int64)
