@@ -150,9 +150,11 @@ def executed_over_algorithmic(kname, S, K, D):
     alg = float(S) * K * (4 * D + 6)
     tiles = (K + 31) // 32
     mfma_flops = 2.0 * 32 * 32 * 16 / 32.0          # per frame column: one 32x32x16 MFMA covers 32 frames
-    if "h2s" in kname or "h2p" in kname:
+    if "h2s" in kname or "h2p" in kname or "h2m" in kname:
         kq, kl = (int(v) for v in kname.split("<")[1].split(">")[0].split(",")[:2])     # <KQF,KLF,waves=N>
         blocks = (S + 14) // 15
+        if "models split" in kname:     # a workgroup per (tile, block), its four waves each forming the quadratic half themselves
+            return blocks * tiles * (4 * kq + 15 * kl) * mfma_flops / alg
         if "h2p" in kname:      # the pipelined shape runs a block's images in stages of 4 and skips the stages that hold phantom models only
             last = S - 15 * (blocks - 1)
             images = 16 * (blocks - 1) + 4 * ((1 + last + 3) // 4)

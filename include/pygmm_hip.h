@@ -160,6 +160,10 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples);
 /* New contents AND a new utterance layout in the same handle: device buffers are reused (they only
  * grow), so a serving loop whose batches change shape allocates nothing in steady state. */
 int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_offsets, int n_utt);
+/* The same for a feature batch: new frames and a new utterance layout (any dim) in the handle's buffers -- what keeps the
+ * reference's per-utterance loop (gmmset.py:62-64, :95-99: one scoring call per utterance) free of allocations. */
+int sr_batch_reset_features(SRBatch *b, const float *X, int64_t n_frames, int dim,
+                            const int64_t *frame_offsets, int n_utt);
 void sr_batch_free(SRBatch *b);
 int sr_batch_num_utterances(SRBatch *b);
 int64_t sr_batch_num_rows(SRBatch *b);           /* samples (PCM) or frames (features) */

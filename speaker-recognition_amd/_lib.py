@@ -23,7 +23,7 @@ EXT_SYMBOLS = [
     "sr_device_name", "sr_device_numa_node", "sr_bind_thread_near_device", "sr_multi_slot_numa_node", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
     "sr_gmm_loads", "sr_score_frames_f32", "sr_modelset_create", "sr_modelset_free",
     "sr_modelset_size", "sr_modelset_info", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
-    "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_reset_pcm", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
+    "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_reset_pcm", "sr_batch_reset_features", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
     "sr_batch_dim", "sr_batch_offsets", "sr_batch_download", "sr_score_batch_set",
     "sr_mfcc_create", "sr_mfcc_set_lpc", "sr_mfcc_free", "sr_mfcc_frame_len", "sr_mfcc_frame_shift",
     "sr_mfcc_num_frames", "sr_mfcc_tables", "sr_mfcc_extract_batch", "sr_predict_pcm_batch",
@@ -106,6 +106,7 @@ def lib():
         "sr_batch_from_features": (vp, [fp, i64, i32, C.POINTER(i64), i32]),
         "sr_batch_update_pcm": (i32, [vp, C.POINTER(C.c_int16), i64]),
         "sr_batch_reset_pcm": (i32, [vp, C.POINTER(C.c_int16), C.POINTER(i64), i32]),
+        "sr_batch_reset_features": (i32, [vp, fp, i64, i32, C.POINTER(i64), i32]),
         "sr_batch_free": (None, [vp]),
         "sr_batch_num_utterances": (i32, [vp]),
         "sr_batch_num_rows": (i64, [vp]),

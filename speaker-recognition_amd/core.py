@@ -82,6 +82,14 @@ class Batch:
         check(lib().sr_batch_reset_pcm(self._h, cat.ctypes.data_as(C.POINTER(C.c_int16)), _lib.as_i64p(offsets),
                                        len(sigs)), "sr_batch_reset_pcm")
 
+    def reset_features(self, X) -> None:
+        """One [T, dim] matrix as the batch's single utterance, into the same device buffers (they only grow): what the
+        reference's per-utterance loop (gmmset.py:62-64) costs nothing but the upload with."""
+        X = _lib.f32_matrix(X)
+        offsets = np.array([0, X.shape[0]], dtype=np.int64)
+        check(lib().sr_batch_reset_features(self._h, _lib.as_fp(X), X.shape[0], X.shape[1], _lib.as_i64p(offsets), 1),
+              "sr_batch_reset_features")
+
     @property
     def n_utt(self) -> int:
         return lib().sr_batch_num_utterances(self._h)

@@ -493,6 +493,31 @@ SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
     SR_CATCH(nullptr)
 }
 
+int sr_batch_reset_features(SRBatch *b, const float *X, int64_t n_frames, int dim, const int64_t *frame_offsets, int n_utt) {
+    SR_TRY
+    if (!b || !frame_offsets) fail("null argument");
+    if (b->kind != SRBatch::FEATURES) fail("sr_batch_reset_features needs a feature batch");
+    if (n_frames < 0 || dim <= 0 || n_utt < 0) fail("bad batch shape");
+    if (frame_offsets[0] != 0 || frame_offsets[n_utt] != n_frames) fail("offsets must run from 0 to n");
+    for (int u = 0; u < n_utt; u++)
+        if (frame_offsets[u + 1] < frame_offsets[u]) fail("offsets must be non-decreasing");
+    if (n_frames > 0 && !X) fail("null X");
+    b->bind_device();
+    const bool same_layout = b->n_utt == n_utt && b->offsets.size() == (size_t)n_utt + 1 && std::equal(b->offsets.begin(), b->offsets.end(), frame_offsets);
+    b->n_utt = n_utt;
+    b->dim = dim;
+    b->n_rows = n_frames;
+    if (!same_layout) {
+        b->offsets.assign(frame_offsets, frame_offsets + n_utt + 1);
+        b->invalidate_tiles();
+        b->d_offsets.upload(b->offsets.data(), b->offsets.size());
+    }
+    b->data.upload(X, (size_t)n_frames * dim);       // device buffers only ever grow
+    sync_stream();
+    return 0;
+    SR_CATCH(-1)
+}
+
 int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     SR_TRY
     if (!b || !pcm) fail("null argument");
@@ -537,7 +562,7 @@ int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_off
     b->n_utt = n_utt;
     b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
     b->n_rows = n;
-    b->tile_tables.clear();
+    b->invalidate_tiles();
     b->pcm16.upload(pcm, (size_t)n);                 // device buffers only ever grow
     b->d_offsets.upload(b->offsets.data(), b->offsets.size());
     sync_stream();

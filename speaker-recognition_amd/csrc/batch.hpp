@@ -29,6 +29,10 @@ struct TileTable {
     DevBuf<TileDesc> d_tiles_work;
     int n_work = 0;
     bool work_packed = false;
+    // the batch changed its layout: rebuilt on next use INTO the same device buffers (SRBatch::tiles_for).  Dropping the table
+    // instead meant two or three hipFree -- each a device synchronisation -- and as many hipMalloc per call of a loop whose
+    // utterances differ in length (the reference's predict_one loop, gmmset.py:62-64; sr_batch_reset_pcm; mfcc_extract_batch)
+    bool stale = false;
 };
 
 void ensure_work_table(TileTable &tt, bool pack_tails);   // gmm_score.hip
@@ -54,6 +58,9 @@ struct SRBatch {
     sr::EventHolder stage_done;
 
     sr::TileTable &tiles_for(int frames_per_tile);
+    void invalidate_tiles() {       // after a change of `offsets`
+        for (auto &t : tile_tables) t->stale = true;
+    }
     // binds an empty batch to the calling thread's device / refuses one that lives elsewhere
     void bind_device() {
         // HIP's current device is per host thread: a thread that chose device d and whose first library call is one that

@@ -1482,10 +1482,23 @@ void ensure_work_table(TileTable &tt, bool pack_tails) {
 }  // namespace sr
 
 sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {
+    sr::TileTable *found = nullptr;
     for (auto &t : tile_tables)
-        if (t->frames_per_tile == frames_per_tile) return *t;
-    auto tt = std::make_unique<sr::TileTable>();
-    tt->frames_per_tile = frames_per_tile;
+        if (t->frames_per_tile == frames_per_tile) {
+            if (!t->stale) return *t;
+            found = t.get();
+        }
+    // (a stale table is rebuilt where it stands: the uploads below are on the stream the kernels that read the old contents
+    // were launched on, so they run behind them)
+    std::unique_ptr<sr::TileTable> fresh;
+    if (!found) {
+        fresh = std::make_unique<sr::TileTable>();
+        fresh->frames_per_tile = frames_per_tile;
+    }
+    sr::TileTable *const tt = found ? found : fresh.get();
+    tt->stale = false;
+    tt->n_work = 0;
+    tt->work_packed = false;
     std::vector<sr::TileDesc> tiles;
     std::vector<int> begin(n_utt + 1, 0);
     for (int u = 0; u < n_utt; u++) {
@@ -1504,6 +1517,6 @@ sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {
     tt->d_tiles.upload(tiles.data(), tiles.size());
     tt->d_utt_tile_begin.upload(begin.data(), begin.size());
     sr::sync_stream();
-    tile_tables.push_back(std::move(tt));
-    return *tile_tables.back();
+    if (fresh) tile_tables.push_back(std::move(fresh));
+    return *tt;
 }

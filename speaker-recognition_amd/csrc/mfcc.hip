@@ -918,7 +918,7 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
     out.data.ensure((size_t)std::max<int64_t>(1, out.n_rows) * out.dim);
     if (!same_shape) {
         out.offsets = out_off;
-        out.tile_tables.clear();
+        out.invalidate_tiles();
         out.d_offsets.upload(out.offsets.data(), out.offsets.size());
         uploaded = true;
     }

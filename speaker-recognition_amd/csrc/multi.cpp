@@ -267,7 +267,7 @@ void run_slot(SRMulti *m, SRMulti::Slot &s, const int16_t *pcm, const int64_t *o
                     b.n_utt = nu;
                     b.offsets = po;
                     b.n_rows = n_samp;
-                    b.tile_tables.clear();
+                    b.invalidate_tiles();
                     b.pcm16.ensure((size_t)std::max<int64_t>(1, n_samp));
                     b.d_offsets.upload(b.offsets.data(), b.offsets.size());
                     sync_stream();

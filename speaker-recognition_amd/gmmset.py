@@ -9,6 +9,7 @@ speaker model sits in one device-resident ``ModelSet`` and an utterance -- or a 
 """
 from __future__ import annotations
 
+import threading
 from collections import OrderedDict
 
 import numpy as np
@@ -81,7 +82,16 @@ class GMMSet(object):
             # device-resident sets cannot exist here; the reference's own speaker-by-speaker loop (gmmset.py:59-64) can --
             # each call is served by this process's helper (csrc/fork_proxy.cpp)
             return [float(g.score_all(x)) for g in self.gmms]
-        totals, _ = self._model_set().score(Batch.from_features([x]))
+        # one utterance at a time is how the reference's drivers call (gmmset.py:62-64, gui.py:179-214): the device batch is kept and
+        # refilled, so such a loop allocates nothing
+        # (a batch per calling thread: the calls below release the GIL)
+        mine = self.__dict__.setdefault("_scratch", {})
+        scratch = mine.get(threading.get_ident())
+        if scratch is None:
+            scratch = mine[threading.get_ident()] = Batch.from_features([x])
+        else:
+            scratch.reset_features(x)
+        totals, _ = self._model_set().score(scratch)
         return totals[0].tolist()
 
     def _label_of_best(self, scores):
@@ -124,6 +134,7 @@ class GMMSetPyGMM(GMMSet):
     # models travel through pickle as their text dumps (gmmset.py:101-105)
     def before_pickle(self):
         self._set = None
+        self.__dict__.pop("_scratch", None)
         self.gmms = [m.dumps() for m in self.gmms]
 
     def after_pickle(self):
@@ -133,4 +144,5 @@ class GMMSetPyGMM(GMMSet):
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_set"] = None
+        state.pop("_scratch", None)
         return state

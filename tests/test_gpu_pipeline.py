@@ -161,6 +161,44 @@ def test_gmmset_rejection_and_pickle(built_lib, tmp_path):
     assert gs2.predict(tests) == ["s0", "s1", "s2"]
 
 
+def test_per_utterance_loop_reuses_its_batch_and_equals_the_batched_pass(built_lib):
+    """The reference's drivers score one utterance per call (gmmset.py:62-64, :95-99).  Here such a loop refills ONE device batch
+    (sr_batch_reset_features; a stale tile table is rebuilt in its own buffers): utterances of different lengths -- growing, shrinking,
+    a tile-boundary length, a single frame, repeated lengths -- and then a different dimension through the same handle must give the
+    bits of the one-pass batch and of a fresh batch per utterance."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.gmmset import GMMSet
+    from speaker_recognition_amd.pygmm import GMM
+    rng = np.random.default_rng(5)
+    raw = [synth.synth_gmm(16, 13, 40 + s) for s in range(5)]
+    gs = GMMSet(gmm_order=16)
+    for s, m in enumerate(raw):
+        gs._append("s%d" % s, GMM.from_arrays(*m))
+    lens = [300, 77, 1000, 32, 33, 1, 300, 300, 512, 5]
+    utts = [synth.draw_frames(raw[i % 5], n, 70 + i).astype(np.float64) for i, n in enumerate(lens)]
+    ms = ModelSet(gs.gmms)
+    want_sums, want_arg = ms.score(Batch.from_features(utts))
+    for rep in range(2):                                  # the second sweep starts from the last (short) shape
+        for i, x in enumerate(utts):
+            got = np.asarray(gs.predict_one_scores(x))
+            fresh, _ = ms.score(Batch.from_features([x]))
+            assert np.array_equal(got, fresh[0]) and np.array_equal(got, want_sums[i]), (rep, i)
+            assert gs.predict_one(x) == "s%d" % want_arg[i]
+    assert len(gs._scratch) == 1
+    # the same handle with another dimension and layout
+    b = gs._scratch[next(iter(gs._scratch))]
+    raw39 = [synth.synth_gmm(8, 39, 90 + s) for s in range(3)]
+    ms39 = ModelSet([GMM.from_arrays(*m) for m in raw39])
+    x39 = synth.draw_frames(raw39[1], 450, 3)
+    b.reset_features(x39)
+    a, _ = ms39.score(b)
+    c, _ = ms39.score(Batch.from_features([x39]))
+    assert b.dim == 39 and b.n_rows == 450 and np.array_equal(a, c)
+    with pytest.raises(Exception):
+        Batch.from_pcm([np.zeros(4000, np.int16)]).reset_features(x39)       # a PCM batch is not refilled with features
+
+
 def test_map_training_vs_reference_dso_golden(built_lib, gmm_golden):
     """train_model_from_ubm on the GPU (legacy symbol, double** rows) against the models the
     reference's own compiled trainer produced for the same UBM and frames (1 and 4 iterations)."""
