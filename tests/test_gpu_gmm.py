@@ -875,7 +875,7 @@ def test_hybrid_form_of_ill_conditioned_sets(built_lib, oracle_built):
     indep = [spoil(synth.synth_gmm(K, D, 4100 + s), (3, 40 + s), s) for s in range(5)]
     ubm = spoil(synth.synth_gmm(K, D, 4200), (5, 33), 77)
     shared = [ubm] + [synth.synth_map_speaker(ubm, 4300 + s) for s in range(14)]
-    for models, expect in ((indep, "split_kernel"), (shared, "h2s")):
+    for models, expect in ((indep, "split_kernel"), (shared, "gmm_score_h2")):      # (h2s / h2p / h2m: whichever shape the batch takes)
         utts = [synth.draw_frames(models[u % len(models)], n, 70 + u, outlier_frac=0.01 if u % 2 else 0.0)
                 for u, n in enumerate([300, 1, 257, 40, 513])]
         X = np.concatenate(utts).astype(np.float64)
