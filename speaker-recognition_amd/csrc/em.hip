@@ -773,8 +773,8 @@ static void pack_em_set(SRModelSet &set, const GMM &gmm) {
     }
 }
 
-// A fit's packed sets are RECYCLED (train_em): a re-packed set keeps its device buffers, so both of its layouts go up here, into
-// the allocations of the iteration before last, behind one wait -- upload_model_set + ensure_bx3_layout on a fresh SRModelSet were
+// A fit's packed sets are RECYCLED (train_em): a re-packed set keeps its device buffers, so its layouts go up into the
+// allocations of the iteration before last -- upload_model_set + ensure_bx3_layout on a fresh SRModelSet were
 // six hipMalloc, two waits and, when the set of the previous iteration died, six hipFree (each one a device synchronisation) per
 // iteration: most of a 16-mixture speaker model's 0.16 ms per iteration.
 // (What else a set caches on the device survives a re-pack unchanged: the group tables are keyed by their content, and the per-model
@@ -783,12 +783,17 @@ static void upload_em_set(SRModelSet &s) {
     ensure_device();
     s.d_params.upload(s.host.params.data(), s.host.params.size());
     s.d_center0.upload(s.host.center.data(), s.host.center.size());
-    s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
-    if (!s.bx3.params.empty()) {       // (what ensure_bx3_layout would do on first use: it sees the buffers filled and returns)
-        s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
-        s.d_bx3_chunks.upload(s.bx3.chunks.data(), s.bx3.chunks.size());
-        s.d_bx3_center.upload(s.bx3.center.data(), s.bx3.center.size());
+    {   // (the chunk table describes the layout, not the parameters: the same from one iteration to the next)
+        const size_t bytes = s.host.chunks.size() * sizeof(ChunkDesc);
+        const char *img = reinterpret_cast<const char *>(s.host.chunks.data());
+        if (!s.d_chunks.p || s.chunks_image.size() != bytes || std::memcmp(s.chunks_image.data(), img, bytes) != 0) {
+            s.d_chunks.upload(s.host.chunks.data(), s.host.chunks.size());
+            s.chunks_image.assign(img, img + bytes);
+        }
     }
+    // the matrix-core layout goes up when a kernel asks for it (ensure_bx3_layout), into the same buffers: a speaker-sized model
+    // (16 mixtures: half of every 32-mixture tile would be padding) stays on the vector engine and never does
+    s.bx3_stale = true;
     sync_stream();
     s.device = ctx().device;
 }

@@ -195,6 +195,8 @@ struct SRModelSet {
     sr::DevBuf<uint16_t> d_bx3_params;
     sr::DevBuf<float> d_bx3_center;
     sr::DevBuf<sr::ChunkDesc> d_bx3_chunks;
+    std::vector<char> chunks_image;  // (em.hip) the bytes d_chunks holds: a re-packed model of the same shape has the same chunk table
+    bool bx3_stale = false;          // a re-packed set (em.hip: a fit recycles its sets): ensure_bx3_layout fills the standing buffers again
     sr::PackedSplit h2;              // two-part fp16 layout (three part products)
     sr::DevBuf<uint16_t> d_h2_params;
     sr::DevBuf<float> d_h2_center, d_h2_scale;

@@ -845,7 +845,8 @@ bool split_bf16_in_range(const SRModelSet &s) {
 }
 
 void ensure_bx3_layout(SRModelSet &s) {
-    if (s.d_bx3_params.p) return;
+    if (s.d_bx3_params.p && !s.bx3_stale) return;
+    s.bx3_stale = false;
     s.d_bx3_params.upload(s.bx3.params.data(), s.bx3.params.size());
     s.d_bx3_chunks.upload(s.bx3.chunks.data(), s.bx3.chunks.size());
     s.d_bx3_center.upload(s.bx3.center.data(), s.bx3.center.size());
