@@ -158,7 +158,9 @@ SRBatch *sr_batch_from_features(const float *X, int64_t n_frames, int dim,
  * samples are on the device. */
 int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples);
 /* New contents AND a new utterance layout in the same handle: device buffers are reused (they only
- * grow), so a serving loop whose batches change shape allocates nothing in steady state. */
+ * grow), so a serving loop whose batches change shape allocates nothing in steady state.  Up to 4 MB of samples travel as
+ * sr_batch_update_pcm's do -- page-locked copy, transfer left in flight, the caller's buffers free on return -- together with
+ * their offsets; the feature stage's and the scoring pass's tables of such a batch are rebuilt the same way (no host wait). */
 int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_offsets, int n_utt);
 /* The same for a feature batch: new frames and a new utterance layout (any dim) in the handle's buffers -- what keeps the
  * reference's per-utterance loop (gmmset.py:62-64, :95-99: one scoring call per utterance) free of allocations. */

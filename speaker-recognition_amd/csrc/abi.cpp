@@ -507,15 +507,46 @@ int sr_batch_reset_features(SRBatch *b, const float *X, int64_t n_frames, int di
     b->n_utt = n_utt;
     b->dim = dim;
     b->n_rows = n_frames;
+    // (device buffers only ever grow.)  A serving-sized refill goes through the batch's page-locked copies and is left in flight: the
+    // caller's matrix is its own again when the call returns, whatever is queued next on the stream runs behind the transfer
+    const size_t n_val = (size_t)n_frames * dim;
+    const bool staged = n_val * sizeof(float) <= ((size_t)4 << 20) && ((size_t)n_utt + 1) * sizeof(int64_t) <= STAGED_TABLE_MAX_BYTES;
     if (!same_layout) {
         b->offsets.assign(frame_offsets, frame_offsets + n_utt + 1);
         b->invalidate_tiles();
-        b->d_offsets.upload(b->offsets.data(), b->offsets.size());
+        if (staged) b->stage_offsets.send(b->d_offsets, b->offsets.data(), b->offsets.size());
+        else b->d_offsets.upload(b->offsets.data(), b->offsets.size());
     }
-    b->data.upload(X, (size_t)n_frames * dim);       // device buffers only ever grow
+    if (staged) {
+        b->stage_rows.send(b->data, X, n_val);
+        return 0;
+    }
+    b->data.upload(X, n_val);
     sync_stream();
     return 0;
     SR_CATCH(-1)
+}
+
+// A serving decision's worth of PCM (<= 4 MB): through the batch's page-locked copy, transfer left in flight (batch.hpp) -- the stream
+// synchronisation sr_batch_update_pcm used to end with was a sixth of a single-utterance decision (round 6).  false: too large, the
+// caller uploads and waits.
+static bool stage_small_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
+    if ((size_t)n_samples * sizeof(int16_t) > ((size_t)4 << 20) || n_samples <= 0) return false;
+    if (!b->stage_done.e) SR_HIP(hipEventCreateWithFlags(&b->stage_done.e, hipEventDisableTiming));
+    else if (hipEventQuery(b->stage_done.e) != hipSuccess) SR_HIP(hipEventSynchronize(b->stage_done.e));
+    b->h_stage.ensure((size_t)n_samples);
+    b->pcm16.ensure((size_t)n_samples);
+    g_devbuf_epoch++;                       // (contents changed: a captured graph that depends on them is re-captured, as upload())
+    // more than 1 MB: in pieces of 256 K samples, a piece's DMA under the host's copy of the next one (64 utterances x 3 s:
+    // 0.936 -> 0.905 ms per call; a second piece costs a small batch its 5 us)
+    const int64_t PIECE = n_samples <= ((int64_t)512 << 10) ? n_samples : ((int64_t)256 << 10);
+    for (int64_t at = 0; at < n_samples; at += PIECE) {
+        const size_t n = (size_t)std::min<int64_t>(PIECE, n_samples - at);
+        std::memcpy(b->h_stage.p + at, pcm + at, n * sizeof(int16_t));
+        SR_HIP(hipMemcpyAsync(b->pcm16.p + at, b->h_stage.p + at, n * sizeof(int16_t), hipMemcpyHostToDevice, ctx().stream));
+    }
+    SR_HIP(hipEventRecord(b->stage_done.e, ctx().stream));
+    return true;
 }
 
 int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
@@ -524,25 +555,7 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     if (b->kind != SRBatch::PCM16) fail("sr_batch_update_pcm needs an int16 PCM batch");
     if (n_samples != b->n_rows) fail("sample count %lld does not match the batch (%lld)", (long long)n_samples, (long long)b->n_rows);
     b->bind_device();
-    if ((size_t)n_samples * sizeof(int16_t) <= ((size_t)4 << 20) && n_samples > 0) {
-        // a serving decision's worth of PCM: through the batch's page-locked copy, transfer left in flight (batch.hpp) -- the
-        // stream synchronisation this call used to end with was a sixth of a single-utterance decision (round 6)
-        if (!b->stage_done.e) SR_HIP(hipEventCreateWithFlags(&b->stage_done.e, hipEventDisableTiming));
-        else if (hipEventQuery(b->stage_done.e) != hipSuccess) SR_HIP(hipEventSynchronize(b->stage_done.e));
-        b->h_stage.ensure((size_t)n_samples);
-        b->pcm16.ensure((size_t)n_samples);
-        g_devbuf_epoch++;                       // (contents changed: a captured graph that depends on them is re-captured, as upload())
-        // more than 1 MB: in pieces of 256 K samples, a piece's DMA under the host's copy of the next one (64 utterances x 3 s:
-        // 0.936 -> 0.905 ms per call; a second piece costs a small batch its 5 us)
-        const int64_t PIECE = n_samples <= ((int64_t)512 << 10) ? n_samples : ((int64_t)256 << 10);
-        for (int64_t at = 0; at < n_samples; at += PIECE) {
-            const size_t n = (size_t)std::min<int64_t>(PIECE, n_samples - at);
-            std::memcpy(b->h_stage.p + at, pcm + at, n * sizeof(int16_t));
-            SR_HIP(hipMemcpyAsync(b->pcm16.p + at, b->h_stage.p + at, n * sizeof(int16_t), hipMemcpyHostToDevice, ctx().stream));
-        }
-        SR_HIP(hipEventRecord(b->stage_done.e, ctx().stream));
-        return 0;
-    }
+    if (stage_small_pcm(b, pcm, n_samples)) return 0;
     b->pcm16.upload(pcm, (size_t)n_samples);
     sync_stream();
     return 0;
@@ -563,7 +576,12 @@ int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_off
     b->offsets.assign(sample_offsets, sample_offsets + n_utt + 1);
     b->n_rows = n;
     b->invalidate_tiles();
-    b->pcm16.upload(pcm, (size_t)n);                 // device buffers only ever grow
+    // (device buffers only ever grow.)  A decision's worth of samples and their offsets: page-locked copies, left in flight
+    if (((size_t)n_utt + 1) * sizeof(int64_t) <= STAGED_TABLE_MAX_BYTES && stage_small_pcm(b, pcm, n)) {
+        b->stage_offsets.send(b->d_offsets, b->offsets.data(), b->offsets.size());
+        return 0;
+    }
+    b->pcm16.upload(pcm, (size_t)n);
     b->d_offsets.upload(b->offsets.data(), b->offsets.size());
     sync_stream();
     return 0;

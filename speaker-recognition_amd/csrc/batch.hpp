@@ -33,6 +33,9 @@ struct TileTable {
     // instead meant two or three hipFree -- each a device synchronisation -- and as many hipMalloc per call of a loop whose
     // utterances differ in length (the reference's predict_one loop, gmmset.py:62-64; sr_batch_reset_pcm; mfcc_extract_batch)
     bool stale = false;
+    // (a rebuilt table travels through these, left in flight: common.hpp)
+    StagedUpload<TileDesc> stage_tiles, stage_work;
+    StagedUpload<int> stage_begin;
 };
 
 void ensure_work_table(TileTable &tt, bool pack_tails);   // gmm_score.hip
@@ -56,6 +59,10 @@ struct SRBatch {
     // `stage_done` says when the staging area may be overwritten by the next update
     sr::PinnedBuf<int16_t> h_stage;
     sr::EventHolder stage_done;
+    // a REFILLED batch's offsets, and a refilled feature batch's rows (sr_batch_reset_pcm / _features, mfcc_extract_batch into a
+    // batch it has filled before): page-locked, in flight (common.hpp: StagedUpload)
+    sr::StagedUpload<int64_t> stage_offsets;
+    sr::StagedUpload<float> stage_rows;
 
     sr::TileTable &tiles_for(int frames_per_tile);
     void invalidate_tiles() {       // after a change of `offsets`

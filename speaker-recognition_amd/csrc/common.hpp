@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstring>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -211,6 +212,31 @@ struct EventHolder {
     void drop() {
         if (e && !gpu_runtime_lost()) (void)hipEventDestroy(e);
         e = nullptr;
+    }
+};
+
+// A small host -> device table of an object that is REUSED from call to call (a serving loop's batch whose utterance changes
+// length, its tile tables, the feature stage's frame offsets): through a page-locked copy owned by the object, the transfer left in
+// flight on the library's stream -- no host wait.  From pageable memory every such table is a blocking staging copy of the
+// runtime's plus, because the source may be rewritten, a stream synchronisation: three of them per decision once the layout
+// changes (0.182 against 0.127 ms for a fixed-length loop, scripts/debug/serving_varlen.py).  `done` guards the page-locked copy
+// against the next refill (normally long complete: the host has seen the pass's results in between).
+// Fresh objects keep the plain upload + wait: a page-locked allocation per new batch would cost more than it saves.
+constexpr size_t STAGED_TABLE_MAX_BYTES = (size_t)256 << 10;
+template <typename T>
+struct StagedUpload {
+    PinnedBuf<T> h;
+    EventHolder done;
+    void send(DevBuf<T> &dst, const T *src, size_t n) {
+        dst.ensure(n);
+        g_devbuf_epoch++;                                  // (contents changed: as DevBuf::upload)
+        if (n == 0) return;
+        if (!done.e) SR_HIP(hipEventCreateWithFlags(&done.e, hipEventDisableTiming));
+        else if (hipEventQuery(done.e) != hipSuccess) SR_HIP(hipEventSynchronize(done.e));
+        h.ensure(n);
+        std::memcpy(h.p, src, n * sizeof(T));
+        SR_HIP(hipMemcpyAsync(dst.p, h.p, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+        SR_HIP(hipEventRecord(done.e, ctx().stream));
     }
 };
 

@@ -1477,6 +1477,10 @@ void ensure_work_table(TileTable &tt, bool pack_tails) {
     std::vector<TileDesc> both(tt.h_tiles);
     both.resize(tt.h_tiles.size() + work.size());
     std::memcpy(both.data() + tt.h_tiles.size(), work.data(), work.size() * sizeof(int4));
+    if (tt.stage_tiles.h.p && both.size() * sizeof(TileDesc) <= STAGED_TABLE_MAX_BYTES) {      // a rebuilt table of a reused batch
+        tt.stage_work.send(tt.d_tiles_work, both.data(), both.size());
+        return;
+    }
     tt.d_tiles_work.upload(both.data(), both.size());
     sync_stream();
 }
@@ -1515,6 +1519,12 @@ sr::TileTable &SRBatch::tiles_for(int frames_per_tile) {
     begin[n_utt] = (int)tiles.size();
     tt->n_tiles = (int)tiles.size();
     tt->h_tiles = tiles;
+    if (found && tiles.size() * sizeof(sr::TileDesc) <= sr::STAGED_TABLE_MAX_BYTES && begin.size() * sizeof(int) <= sr::STAGED_TABLE_MAX_BYTES) {
+        // the table of a batch that is being reused: no host wait (common.hpp: StagedUpload)
+        tt->stage_tiles.send(tt->d_tiles, tiles.data(), tiles.size());
+        tt->stage_begin.send(tt->d_utt_tile_begin, begin.data(), begin.size());
+        return *tt;
+    }
     tt->d_tiles.upload(tiles.data(), tiles.size());
     tt->d_utt_tile_begin.upload(begin.data(), begin.size());
     sr::sync_stream();

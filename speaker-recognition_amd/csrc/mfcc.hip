@@ -871,6 +871,7 @@ struct MfccScratch {
     DevBuf<float> raw;
     DevBuf<int64_t> raw_off;
     std::vector<int64_t> raw_off_host;   // what raw_off currently holds (skip the upload + sync when unchanged)
+    StagedUpload<int64_t> stage_raw_off; // (a workspace lives as long as its device: its table always travels this way when small)
 };
 MfccScratch *mfcc_scratch_new() { return new MfccScratch(); }
 void mfcc_scratch_delete(MfccScratch *s) { delete s; }
@@ -903,10 +904,15 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
     auto &w = *scratch;
     w.raw.ensure((size_t)std::max<int64_t>(1, NF) * m.n_ceps);
     bool uploaded = false;
+    const bool small_tables = raw_off.size() * sizeof(int64_t) <= STAGED_TABLE_MAX_BYTES;
     if (w.raw_off_host != raw_off) {
         w.raw_off_host = raw_off;
-        w.raw_off.upload(w.raw_off_host.data(), w.raw_off_host.size());
-        uploaded = true;
+        if (small_tables) {
+            w.stage_raw_off.send(w.raw_off, w.raw_off_host.data(), w.raw_off_host.size());
+        } else {
+            w.raw_off.upload(w.raw_off_host.data(), w.raw_off_host.size());
+            uploaded = true;
+        }
     }
 
     const int dim_out = m.n_ceps * (nd + 1) + m.n_lpc;
@@ -917,10 +923,15 @@ void mfcc_extract_with(SRMfcc &m, SRBatch &pcm, int nd, int cmvn, SRBatch &out, 
     out.n_rows = out_off[U];
     out.data.ensure((size_t)std::max<int64_t>(1, out.n_rows) * out.dim);
     if (!same_shape) {
+        const bool refilled = !out.offsets.empty() && out.d_offsets.p != nullptr;      // (a batch this stage has filled before)
         out.offsets = out_off;
         out.invalidate_tiles();
-        out.d_offsets.upload(out.offsets.data(), out.offsets.size());
-        uploaded = true;
+        if (refilled && small_tables) {
+            out.stage_offsets.send(out.d_offsets, out.offsets.data(), out.offsets.size());
+        } else {
+            out.d_offsets.upload(out.offsets.data(), out.offsets.size());
+            uploaded = true;
+        }
     }
 
     if (NF > 0) {

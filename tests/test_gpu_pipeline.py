@@ -199,6 +199,35 @@ def test_per_utterance_loop_reuses_its_batch_and_equals_the_batched_pass(built_l
         Batch.from_pcm([np.zeros(4000, np.int16)]).reset_features(x39)       # a PCM batch is not refilled with features
 
 
+def test_serving_loop_with_changing_layouts_equals_fresh_batches(built_lib):
+    """A serving loop whose batch changes its layout from call to call (Batch.reset_pcm: 1-4 utterances of 0.4-1.2 s): samples,
+    offsets, the feature stage's frame offsets and the rebuilt tile tables all travel through page-locked copies left in flight
+    (common.hpp: StagedUpload) -- every decision must carry the bits of a fresh batch, including right after a larger and a
+    smaller layout, an unchanged layout with other samples, and a tile-boundary length."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.core import Batch, MfccExtractor, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    fs = 16000
+    ex = MfccExtractor(fs, win_length_ms=25, win_shift_ms=10)
+    ubm = synth.synth_gmm(64, 39, 99)
+    ms = ModelSet([GMM.from_arrays(*m) for m in [ubm] + [synth.synth_map_speaker(ubm, 500 + s) for s in range(14)]])     # shared sigma
+    ms2 = ModelSet([GMM.from_arrays(*synth.synth_gmm(32, 39, 7 + s)) for s in range(5)])                                   # generic engine
+    clips = [synth.synth_speech(u, 1.3, fs, seed=40 + u) for u in range(4)]
+    rng = np.random.default_rng(3)
+    n34 = (34 - 1) * ex.FRAME_SHIFT + ex.FRAME_LEN            # 34 raw frames -> 32 after the deltas: exactly one tile
+    layouts = [[6400], [19000, 7000], [n34], [12000, 12000, 12000, 12000], [6400], [6400], [n34, n34], [20000]]
+    batch = Batch.from_pcm([clips[0][:8000]])
+    for rep in range(2):
+        for li, lens in enumerate(layouts):
+            sigs = [clips[(u + li + rep) % 4][:n] for u, n in enumerate(lens)]
+            batch.reset_pcm(sigs)
+            for models in (ms, ms2):
+                got = ex.predict_batch(models, batch, nd=2)
+                want = ex.predict_batch(models, Batch.from_pcm(sigs), nd=2)
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (rep, li)
+    assert batch.n_utt == 1 and batch.n_rows == 20000
+
+
 def test_map_training_vs_reference_dso_golden(built_lib, gmm_golden):
     """train_model_from_ubm on the GPU (legacy symbol, double** rows) against the models the
     reference's own compiled trainer produced for the same UBM and frames (1 and 4 iterations)."""
