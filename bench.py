@@ -606,6 +606,26 @@ def block_serving_small(_lib, ex, base, ms, S, K, hbm):
                                     "scoring_kernel_ms": (ms_k + ms_r) / max(1, n_k), "mfcc_kernel_ms": ms_m / max(1, n_k),
                                     "kernel": kname.split(" (")[0], "frac_algorithmic": rf["frac"], "frac_executed_mfma": rf["frac_executed_mfma"],
                                     "algorithmic_tflops": rf["achieved"], "all_finite": bool(np.all(np.isfinite(sums)))}
+    # ... and one utterance per call whose LENGTH changes from call to call (2.5 .. 3.5 s: what a real stream of decisions looks like):
+    # new layout in the same device batch (Batch.reset_pcm), the last decision checked against a fresh batch's
+    clip = np.ascontiguousarray(base[0])
+    rng = np.random.default_rng(1)
+    lens = rng.integers(min(len(clip), int(2.5 * FS)), min(len(clip), int(3.5 * FS)) + 1, 230)
+    batch = Batch.from_pcm([clip[:lens[0]]])
+    lat = []
+    _lib.profile_enable(False)
+    try:
+        for n in lens:
+            t0 = time.perf_counter()
+            batch.reset_pcm([clip[:n]])
+            sums, arg = ex.predict_batch(ms, batch, nd=ND)
+            lat.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        _lib.profile_enable(True)
+    fresh = ex.predict_batch(ms, Batch.from_pcm([clip[:lens[-1]]]), nd=ND)
+    lat = np.array(lat[30:])
+    out["utterances_1_varying_length"] = {"seconds_per_utterance": [2.5, 3.5], "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99))},
+                                          "last_decision_equals_fresh_batch": bool(np.array_equal(fresh[0], sums) and np.array_equal(fresh[1], arg))}
     return out
 
 
