@@ -534,8 +534,8 @@ static bool stage_small_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples) {
     if ((size_t)n_samples * sizeof(int16_t) > ((size_t)4 << 20) || n_samples <= 0) return false;
     if (!b->stage_done.e) SR_HIP(hipEventCreateWithFlags(&b->stage_done.e, hipEventDisableTiming));
     else if (hipEventQuery(b->stage_done.e) != hipSuccess) SR_HIP(hipEventSynchronize(b->stage_done.e));
-    b->h_stage.ensure((size_t)n_samples);
-    b->pcm16.ensure((size_t)n_samples);
+    if ((size_t)n_samples > b->h_stage.n) b->h_stage.ensure((size_t)n_samples + (size_t)n_samples / 4);   // (headroom: as StagedUpload)
+    if ((size_t)n_samples > b->pcm16.n) b->pcm16.ensure((size_t)n_samples + (size_t)n_samples / 4);
     g_devbuf_epoch++;                       // (contents changed: a captured graph that depends on them is re-captured, as upload())
     // more than 1 MB: in pieces of 256 K samples, a piece's DMA under the host's copy of the next one (64 utterances x 3 s:
     // 0.936 -> 0.905 ms per call; a second piece costs a small batch its 5 us)

@@ -228,12 +228,12 @@ struct StagedUpload {
     PinnedBuf<T> h;
     EventHolder done;
     void send(DevBuf<T> &dst, const T *src, size_t n) {
-        dst.ensure(n);
+        if (n > dst.n) dst.ensure(n + n / 4);              // (a quarter of headroom: a loop whose sizes creep up re-allocates a few times, not at every new maximum)
         g_devbuf_epoch++;                                  // (contents changed: as DevBuf::upload)
         if (n == 0) return;
         if (!done.e) SR_HIP(hipEventCreateWithFlags(&done.e, hipEventDisableTiming));
         else if (hipEventQuery(done.e) != hipSuccess) SR_HIP(hipEventSynchronize(done.e));
-        h.ensure(n);
+        if (n > h.n) h.ensure(n + n / 4);
         std::memcpy(h.p, src, n * sizeof(T));
         SR_HIP(hipMemcpyAsync(dst.p, h.p, n * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
         SR_HIP(hipEventRecord(done.e, ctx().stream));
