@@ -197,6 +197,20 @@ def test_per_utterance_loop_reuses_its_batch_and_equals_the_batched_pass(built_l
     assert b.dim == 39 and b.n_rows == 450 and np.array_equal(a, c)
     with pytest.raises(Exception):
         Batch.from_pcm([np.zeros(4000, np.int16)]).reset_features(x39)       # a PCM batch is not refilled with features
+    # several utterances per refill, through the C ABI itself: ragged, an empty one in the middle, then fewer and longer ones, then a
+    # refill too large for the page-locked path (> 4 MB: upload + wait) -- each against a fresh batch of the same layout
+    from speaker_recognition_amd import _lib
+    L = _lib.lib()
+    for lens in ([40, 0, 333, 64], [700, 5], [40, 0, 333, 64], [30000]):
+        mats = [synth.draw_frames(raw39[i % 3], n, 200 + i + len(lens)) for i, n in enumerate(lens)]
+        X = np.ascontiguousarray(np.concatenate(mats))
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        assert L.sr_batch_reset_features(b._h, _lib.as_fp(X), X.shape[0], 39, _lib.as_i64p(off), len(lens)) == 0, _lib.last_error()
+        a, aa = ms39.score(b)
+        c, ca = ms39.score(Batch.from_features(mats))
+        assert b.n_utt == len(lens) and np.array_equal(a, c) and np.array_equal(aa, ca), lens
+    bad = np.array([0, 10, 5], dtype=np.int64)
+    assert L.sr_batch_reset_features(b._h, _lib.as_fp(X), 5, 39, _lib.as_i64p(bad), 2) != 0 and "non-decreasing" in _lib.last_error()
 
 
 def test_serving_loop_with_changing_layouts_equals_fresh_batches(built_lib):
