@@ -163,7 +163,10 @@ int sr_batch_update_pcm(SRBatch *b, const int16_t *pcm, int64_t n_samples);
  * their offsets; the feature stage's and the scoring pass's tables of such a batch are rebuilt the same way (no host wait). */
 int sr_batch_reset_pcm(SRBatch *b, const int16_t *pcm, const int64_t *sample_offsets, int n_utt);
 /* The same for a feature batch: new frames and a new utterance layout (any dim) in the handle's buffers -- what keeps the
- * reference's per-utterance loop (gmmset.py:62-64, :95-99: one scoring call per utterance) free of allocations. */
+ * reference's per-utterance loop (gmmset.py:62-64, :95-99: one scoring call per utterance) free of allocations.  Up to 4 MB of
+ * frames are copied to a page-locked staging area and the call returns with the transfer in flight on the library's stream (X is
+ * the caller's again at once; sr_score_batch_set and whatever else is queued next runs behind it); larger refills return when the
+ * frames are on the device. */
 int sr_batch_reset_features(SRBatch *b, const float *X, int64_t n_frames, int dim,
                             const int64_t *frame_offsets, int n_utt);
 void sr_batch_free(SRBatch *b);
