@@ -141,12 +141,19 @@ struct H2sArgs {
 // Which (model group, frame tiles) a workgroup of the main kernels takes.  Consecutive blockIdx go to consecutive XCDs (8 of
 // them, each with its own L2), and workgroups of different groups stream different blocks' images:
 //   0  group-fastest (rounds 2-3): one workgroup of every group on each XCD in turn;
-//   1  group-major (round 4): a group's workgroups consecutive in launch order, spread over the 8 XCDs.
+//   1  group-major (round 4): a group's workgroups consecutive in launch order, spread over the 8 XCDs;
+//   2  (round 6, the model-split kernel of a serving decision only) group g's workgroups all on XCD g % 8.
 // (Tried: XCD-major -- every XCD a contiguous run of (group, tile) pairs, whole groups where there are enough tiles, so that a
 // block's images come into ONE L2 only.  No better than 0: 64 utterances x 300 frames 0.755 ms against 0.652 for group-major.)
 __device__ __forceinline__ bool h2s_wg_assignment(const H2sArgs &a, int tiles_wg, int &g, int &tile0) {
     const int wg_lo = blockIdx.x & 7, q = blockIdx.x >> 3;
     int t;
+    if (a.group_major == 2) {           // a group's workgroups on ONE XCD (its blocks' images come into one L2, once)
+        g = wg_lo + 8 * (q / a.n_wg);
+        t = q - (q / a.n_wg) * a.n_wg;
+        tile0 = a.tile_base + t * tiles_wg;
+        return g < a.n_groups && tile0 < a.n_units;
+    }
     if (a.group_major) {
         g = q / a.rows8;
         t = (q - g * a.rows8) * 8 + wg_lo;
@@ -1320,7 +1327,14 @@ static int launch_h2s(const H2sLaunch &l) {
         n_launches++;
         a.tile_base = base * TILES_WG;
         const int n = std::min(wg_per_launch, n_wg - base);
-        dim3 grid((unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
+        // A serving decision (gmm_score_h2m_kernel, every workgroup resident at once): a group's workgroups on ONE XCD, so that a
+        // block's images come into one L2, once.  Spread over the XCDs as above, every L2 fetched all 28 MiB of configs[2]'s images
+        // for its share of the ten tiles and the fabric bounded the kernel: 300 frames 0.072 -> 0.057 ms, a decision 0.126 -> 0.105
+        // (600 / 900 frames: 0.094 -> 0.088 / 0.091).  The LDS-staged 4-wave shapes wait for their stages' round trips, not for
+        // bytes (0.110 either way), and larger grids ran slower XCD-major (h2s_wg_assignment).
+        const int per_xcd = ((l.n_groups + 7) / 8) * n;
+        const bool xcd_groups = MS && KLF <= H2M_MAX_KLF && l.n_groups > 1 && n == n_wg && per_xcd <= 2 * (ctx().n_cu / 8);
+        dim3 grid(xcd_groups ? (unsigned)(8 * ((l.n_groups + 7) / 8) * n) : (unsigned)((int64_t)l.n_groups * ((n + 7) / 8) * 8));
         // Launch order.  With ONE group every workgroup sweeps all blocks from block 0 on, in phase with its XCD's others (see the
         // kernel).  With several, workgroups of different groups stream different blocks: group-fastest order (rounds 2-3) put one
         // workgroup of EVERY block on each XCD at a time -- no reuse in its L2, every stage a trip to HBM, the loop bound by that
@@ -1328,7 +1342,7 @@ static int launch_h2s(const H2sLaunch &l) {
         // block's workgroups side by side.
         a.rows8 = (n + 7) / 8;
         a.n_wg = n;
-        a.group_major = l.n_groups > 1;
+        a.group_major = xcd_groups ? 2 : l.n_groups > 1;
         // (the model-split shape: gmm_score_h2m_kernel, fragments straight into registers, where two sets of them fit; the LDS form
         // of round 4 for the longest chains -- D = 46 .. 48 -- whose two sets spill)
         constexpr bool M_DIRECT = MS && KLF <= H2M_MAX_KLF;
