@@ -1446,7 +1446,8 @@ bool fetch_results(SRModelSet &set, SRBatch &feat, int flags, const ScoreResult 
 void score_batch_set(SRModelSet &set, SRBatch &feat, double *sums_out, int *argmax_out,
                      float *frame_ll_out, int flags) {
     // (small result sets land in host memory by themselves: SCORE_HOST_DELIVER, score.hpp)
-    const int deliver = (!frame_ll_out && sums_out && argmax_out && host_deliverable((size_t)feat.n_utt, (size_t)set.host.n_models)) ? SCORE_HOST_DELIVER : 0;
+    // (either result alone too: the legacy ABI's score_all wants one sum, pygmm.cc:98-104, and so does every second EM iteration)
+    const int deliver = (!frame_ll_out && (sums_out || argmax_out) && host_deliverable((size_t)feat.n_utt, (size_t)set.host.n_models)) ? SCORE_HOST_DELIVER : 0;
     const ScoreResult r = score_device(set, feat, frame_ll_out != nullptr, flags | deliver);
     if (fetch_results(set, feat, flags, r, sums_out, argmax_out, frame_ll_out)) return;
     // a frame left the fp16 engine's range: the whole batch again on the fp32-grade engines
