@@ -113,29 +113,17 @@ static std::vector<float> rows_to_f32(double **X, long n, int dim) {
 // The legacy ABI scores ONE model per call, and its callers loop over the speakers with the same
 // utterance (gmmset.py:59-64, :95-99: S calls of score_all(x)): re-uploading x S times would make
 // the drop-in path pay S H2D copies and S tile-table builds.  The last uploaded matrix stays on the
-// device, keyed by shape and a 64-bit FNV-1a hash of its fp32 contents (~0.1 ms per MB on the host); a hit is confirmed
-// by comparing the contents with the host copy kept beside it (a hash alone would score the wrong utterance on a
-// collision).  Matrices above LEGACY_CACHE_MAX_BYTES are not kept (neither copy outlives the call).
+// device, keyed by shape and CONTENTS: a call's matrix is compared with the host copy kept beside the device one (memcmp: 5 us
+// for 1000 x 39 frames on a hit, a few bytes on a miss).  (Through round 5 a 64-bit FNV-1a hash went first: a dependent
+// multiply per 8 bytes, 20 us of a 60 us call, for a comparison that decides by itself.)  Matrices above LEGACY_CACHE_MAX_BYTES
+// are not kept (neither copy outlives the call).
 constexpr size_t LEGACY_CACHE_MAX_BYTES = (size_t)256 << 20;
 struct LegacyFeatureCache {
-    uint64_t hash = 0;
     long n = -1;
     int dim = -1;
     std::vector<float> host;
     std::unique_ptr<SRBatch> batch;
 };
-
-static uint64_t fnv1a(const void *p, size_t bytes) {
-    const unsigned char *b = static_cast<const unsigned char *>(p);
-    uint64_t h = 1469598103934665603ull;
-    for (size_t i = 0; i + 8 <= bytes; i += 8) {
-        uint64_t w;
-        std::memcpy(&w, b + i, 8);                     // (the caller's floats are 4-byte aligned)
-        h = (h ^ w) * 1099511628211ull;
-    }
-    for (size_t i = bytes & ~(size_t)7; i < bytes; i++) h = (h ^ b[i]) * 1099511628211ull;
-    return h;
-}
 
 namespace sr {
 void score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags);
@@ -155,8 +143,7 @@ void sr::score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out,
     if (dim != g->dim) fail("nr_dim %d does not match the model's dim %d", dim, g->dim);
     auto &cache = per_device<LegacyFeatureCache>();
     const size_t bytes = (size_t)n * dim * sizeof(float);
-    const uint64_t h = fnv1a(X, bytes);
-    const bool hit = cache.batch && cache.n == n && cache.dim == dim && cache.hash == h &&
+    const bool hit = cache.batch && cache.n == n && cache.dim == dim &&
                      cache.host.size() * sizeof(float) == bytes && std::memcmp(cache.host.data(), X, bytes) == 0;
     if (!hit) {
         const int64_t off[2] = {0, n};
@@ -164,7 +151,6 @@ void sr::score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out,
         cache.batch = feature_batch(X, n, dim, off, 1);
         cache.n = n;
         cache.dim = dim;
-        cache.hash = h;
         if (bytes <= LEGACY_CACHE_MAX_BYTES) cache.host.assign(X, X + (size_t)n * dim);
         else std::vector<float>().swap(cache.host);
     }
