@@ -126,6 +126,14 @@ GMM *sr_gmm_loads(const char *text);
 int sr_score_frames_f32(GMM *gmm, const float *X, long n, int dim, float *ll_out, double *sum_out,
                         int flags);
 
+/* All of `models` on ONE utterance in one fused pass: sums_out[i] = the sum over the frames of model i's log-likelihood -- what
+ * the reference's per-speaker loop of score_all calls computes (gmmset.py:95-99).  The packed set of the last model list is
+ * kept (keyed by the handles and their parameters' state), so a loop over utterances packs once.  Unlike SRModelSet handles this
+ * entry point also works in a process forked after its parent used the GPU (the reference's Pool drivers,
+ * test-nperson.py:126-146): there it is ONE conversation with the process's helper instead of one per model. */
+int sr_score_models_f32(GMM *const *models, int n_models, const float *X /* [n_frames][dim] */, long n_frames, int dim,
+                        double *sums_out /* [n_models] */, int flags /* SR_CLAMP_COMPAT | ... */);
+
 /* Speaker set: S models packed once, resident in HBM (replaces the per-speaker ABI loop of
  * src/testbench/gmmset.py:59-64,95-99). */
 typedef struct SRModelSet SRModelSet;

@@ -21,7 +21,7 @@ LEGACY_SYMBOLS = ["new_gmm", "load", "dump", "train_model", "train_model_from_ub
 EXT_SYMBOLS = [
     "sr_last_error", "sr_gpu_runtime_lost", "sr_device_count", "sr_set_device", "sr_set_thread_device", "sr_get_device", "sr_device_synchronize",
     "sr_device_name", "sr_device_numa_node", "sr_bind_thread_near_device", "sr_multi_slot_numa_node", "sr_free_gmm", "sr_gmm_from_arrays", "sr_gmm_get_params", "sr_gmm_dumps",
-    "sr_gmm_loads", "sr_score_frames_f32", "sr_modelset_create", "sr_modelset_free",
+    "sr_gmm_loads", "sr_score_frames_f32", "sr_score_models_f32", "sr_modelset_create", "sr_modelset_free",
     "sr_modelset_size", "sr_modelset_info", "sr_modelset_dim", "sr_batch_from_pcm", "sr_batch_from_pcm_f32",
     "sr_batch_from_features", "sr_batch_update_pcm", "sr_batch_reset_pcm", "sr_batch_reset_features", "sr_batch_free", "sr_batch_num_utterances", "sr_batch_num_rows",
     "sr_batch_dim", "sr_batch_offsets", "sr_batch_download", "sr_score_batch_set",
@@ -96,6 +96,7 @@ def lib():
         "sr_gmm_dumps": (i32, [vp, C.c_char_p, C.c_long, C.POINTER(C.c_long)]),
         "sr_gmm_loads": (vp, [C.c_char_p]),
         "sr_score_frames_f32": (i32, [vp, fp, C.c_long, i32, fp, dp, i32]),
+        "sr_score_models_f32": (i32, [C.POINTER(vp), i32, fp, C.c_long, i32, dp, i32]),
         "sr_modelset_create": (vp, [C.POINTER(vp), i32]),
         "sr_modelset_free": (None, [vp]),
         "sr_modelset_size": (i32, [vp]),

@@ -127,7 +127,9 @@ struct LegacyFeatureCache {
 
 namespace sr {
 void score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags);
+void score_models_local(GMM *const *models, int n_models, const float *X, long n, int dim, double *sums_out, int flags);
 }
+static std::unique_ptr<SRBatch> feature_batch(const float *X, int64_t n, int dim, const int64_t *offsets, int n_utt);
 // One model against a contiguous fp32 matrix: here, or -- in a process that lost its GPU runtime to fork() -- in its helper.
 static void score_one(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags) {
     if (gpu_runtime_lost()) return fork_proxy_score(g, X, n, dim, ll_out, sum_out, flags);
@@ -161,6 +163,47 @@ void sr::score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out,
         cache.batch.reset();
         cache.n = -1;
     }
+}
+
+// Several models on ONE utterance in one fused pass (sr_score_models_f32): what gmmset.py:95-99's loop of score_all calls computes.
+// The packed set of the last model list stays on the device, keyed by every model's identity and parameter generation.
+namespace {
+struct ModelsSetCache {
+    std::vector<std::pair<uint64_t, uint64_t>> key;      // (uid, generation) per model
+    std::unique_ptr<SRModelSet> set;
+    std::unique_ptr<SRBatch> batch;                      // refilled per call (device buffers only grow)
+};
+}  // namespace
+void sr::score_models_local(GMM *const *models, int n_models, const float *X, long n, int dim, double *sums_out, int flags) {
+    if (!models || n_models <= 0) fail("empty model list");
+    if (!sums_out) fail("null sums_out");
+    if (n < 0 || dim <= 0) fail("bad frame matrix shape");
+    if (n > 0 && !X) fail("null X");
+    std::vector<std::pair<uint64_t, uint64_t>> key((size_t)n_models);
+    for (int i = 0; i < n_models; i++) {
+        const GMM *g = models[i];
+        if (!g) fail("null GMM handle in model list");
+        if (!g->trained()) fail("GMM has no parameters yet (train or load it first)");
+        if (g->dim != dim) fail("nr_dim %d does not match model %d's dim %d", dim, i, g->dim);
+        key[(size_t)i] = {g->uid, g->generation};
+    }
+    ensure_device();
+    auto &cache = per_device<ModelsSetCache>();
+    if (!cache.set || cache.key != key || cache.set->device != ctx().device) {
+        cache.set.reset();
+        auto s = std::make_unique<SRModelSet>();
+        pack_model_set(*s, std::vector<const GMM *>(models, models + n_models));
+        upload_model_set(*s);
+        cache.set = std::move(s);
+        cache.key = key;
+    }
+    const int64_t off[2] = {0, n};
+    if (!cache.batch) {
+        cache.batch = feature_batch(X, n, dim, off, 1);
+    } else if (sr_batch_reset_features(cache.batch.get(), X, n, dim, off, 1) != 0) {
+        fail("%s", last_error().c_str());
+    }
+    score_batch_set(*cache.set, *cache.batch, sums_out, nullptr, nullptr, flags);
 }
 
 extern "C" {
@@ -697,6 +740,14 @@ int sr_train_f32(GMM *gmm, GMM *ubm_or_null, const float *X, long n, int dim,
     SR_CATCH(-1)
 }
 
+int sr_score_models_f32(GMM *const *models, int n_models, const float *X, long n_frames, int dim, double *sums_out, int flags) {
+    SR_TRY
+    if (gpu_runtime_lost()) fork_proxy_score_models(models, n_models, X, n_frames, dim, sums_out, flags);
+    else score_models_local(models, n_models, X, n_frames, dim, sums_out, flags);
+    return 0;
+    SR_CATCH(-1)
+}
+
 int sr_hbm_copy_gbps(size_t bytes, int iters, double *gbps_out) {
     SR_TRY
     if (!gbps_out || bytes == 0 || iters <= 0) fail("bad arguments to sr_hbm_copy_gbps");
@@ -829,6 +880,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "debug_capture_delay_ms") {
         if (value < 0 || value > 1000) fail("debug_capture_delay_ms must be 0 .. 1000");
         stream_debug_capture_delay_ms().store((int)value);         // test hook (tests/test_gpu_pipeline.py)
+    } else if (k == "debug_helper_max_models") {
+        if (value < 0) fail("debug_helper_max_models must be >= 0 (0: the default)");
+        fork_proxy_set_max_models(value);                           // test hook (tests/test_gpu_fork.py): applies in the helper, where it is forwarded
     } else if (k == "mfcc_generic") {
         mfcc_set_force_generic(value != 0);
     } else if (k == "mfcc_precision") {

@@ -30,6 +30,7 @@
 #include "fork_proxy.hpp"
 #include "gmm_model.hpp"
 
+#include <atomic>
 #include <cerrno>
 #include <cstring>
 #include <string>
@@ -51,11 +52,12 @@ namespace sr {
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param, long seed);   // em.hip
 void reference_rand_state(int32_t *words36, bool set);                                                           // kmeans_init.hip
 void score_one_local(GMM *g, const float *X, long n, int dim, float *ll_out, double *sum_out, int flags);       // abi.cpp
+void score_models_local(GMM *const *models, int n_models, const float *X, long n, int dim, double *sums_out, int flags);   // abi.cpp
 
 namespace {
 
 constexpr uint32_t MAGIC = 0x53524650u;      // "SRFP"
-enum Op : uint32_t { OP_SCORE = 1, OP_TRAIN = 2, OP_OPTION = 3, OP_PING = 4 };
+enum Op : uint32_t { OP_SCORE = 1, OP_TRAIN = 2, OP_OPTION = 3, OP_PING = 4, OP_SCORE_MODELS = 5 };
 
 // ---- framed, blocking I/O on a stream socket ----
 void send_all(int fd, const void *p, size_t n) {
@@ -192,7 +194,13 @@ void get_params(Reader &r, GMM &g) {
 
 // what the helper answers when asked to use a model it has evicted (the conversation stays intact; the caller sends it again)
 constexpr char HELPER_MISS[] = "fork helper miss";
-constexpr size_t HELPER_MAX_MODELS = 64;       // models (host parameters + packed device set) the helper keeps, least recently used out
+// models (host parameters + packed device set) the helper keeps, least recently used out: by count and by bytes of parameters.
+// (Through round 5: 64 models.  The reference's own logged run -- test-nperson.py: 80 speakers, every pool worker scoring each utterance
+// against all of them in order -- cycled through 80 with room for 64: every call missed, sent its model again and had it packed and
+// uploaded again: 0.9 ms per score_all call, 36 s for the run's 4000 utterances on 8 workers.)
+constexpr size_t HELPER_MAX_MODELS = 4096;
+constexpr size_t HELPER_MAX_MODEL_BYTES = (size_t)1 << 30;
+std::atomic<long> g_helper_max_models{0};    // 0: HELPER_MAX_MODELS (test hook: the eviction path with a handful of models)
 
 // ---- the options set so far: a fresh helper starts from the library's defaults, the forked child did not ----
 std::vector<std::pair<std::string, long>> &option_log() {
@@ -333,7 +341,9 @@ void put_model_tracked(Writer &w, Helper &h, const GMM &g, std::vector<std::pair
     const uint64_t hash = model_hash(g);
     const uint64_t key = (uint64_t)(uintptr_t)&g;
     const auto it = h.sent.find(key);
-    const bool have = g.trained() && it != h.sent.end() && it->second == hash;
+    bool have = g.trained() && it != h.sent.end() && it->second == hash;
+    for (const auto &kv : pending)            // the same handle earlier in THIS request (a set may name a model twice): sent once
+        if (kv.first == key && kv.second == hash) have = true;
     put_model(w, g, hash, !have);
     if (g.trained() && !have) pending.emplace_back(key, hash);
 }
@@ -344,6 +354,8 @@ void put_model_tracked(Writer &w, Helper &h, const GMM &g, std::vector<std::pair
 
 // pthread_atfork child handler (common.cpp): only the forking thread exists; whoever held the record's mutex does not
 void fork_proxy_atfork_child() { helper().mu = new std::mutex(); }
+
+void fork_proxy_set_max_models(long n) { g_helper_max_models.store(n); }
 
 void fork_proxy_note_option(const char *key, long value) {
     auto &log = option_log();
@@ -410,6 +422,49 @@ void fork_proxy_score(GMM *g, const float *X, long n, int dim, float *ll_out, do
             continue;
         }
         // an error raised BY the helper leaves the conversation intact; a broken conversation does not
+        if (std::strncmp(e.what(), "fork helper:", 12) == 0) drop_helper(h);
+        throw;
+    }
+}
+
+// All of a speaker set's models on one utterance in ONE conversation and one fused pass in the helper (sr_score_models_f32):
+// the reference's pool workers call predict_one per utterance (test-nperson.py:133-146), which through score_all is a
+// conversation, a launch chain and a reply per SPEAKER -- 80 of them per utterance in its logged run.
+void fork_proxy_score_models(GMM *const *models, int n_models, const float *X, long n, int dim, double *sums_out, int flags) {
+    if (!models || n_models <= 0) fail("empty model list");
+    if (!sums_out) fail("null sums_out");
+    for (int i = 0; i < n_models; i++) {
+        if (!models[i]) fail("null GMM handle in model list");
+        if (!models[i]->trained()) fail("GMM has no parameters yet (train or load it first)");
+        if (models[i]->dim != dim) fail("nr_dim %d does not match model %d's dim %d", dim, i, models[i]->dim);
+    }
+    Helper &h = helper();
+    std::lock_guard<std::mutex> lock(*helper_mutex(h));
+    start_helper(h);
+    for (int attempt = 0;; attempt++)
+    try {
+        std::vector<std::pair<uint64_t, uint64_t>> pending;
+        Writer w;
+        put_header(w, OP_SCORE_MODELS);
+        w.pod<int32_t>(n_models);
+        for (int i = 0; i < n_models; i++) put_model_tracked(w, h, *models[i], pending);
+        w.pod<int64_t>(n);
+        w.pod<int32_t>(dim);
+        w.pod<int32_t>(flags);
+        w.bytes(X, (size_t)n * dim * sizeof(float));
+        w.flush(h.fd);
+        Reader r;
+        r.fill(h.fd);
+        reply_status(r);
+        for (const auto &kv : pending) h.sent[kv.first] = kv.second;
+        std::memcpy(sums_out, r.take((size_t)n_models * sizeof(double)), (size_t)n_models * sizeof(double));
+        return;
+    } catch (const Error &e) {
+        // a model the helper has evicted: the whole list again with its parameters, once
+        if (attempt == 0 && std::strncmp(e.what(), HELPER_MISS, sizeof HELPER_MISS - 1) == 0) {
+            for (int i = 0; i < n_models; i++) h.sent.erase((uint64_t)(uintptr_t)models[i]);
+            continue;
+        }
         if (std::strncmp(e.what(), "fork helper:", 12) == 0) drop_helper(h);
         throw;
     }
@@ -484,6 +539,16 @@ extern "C" int sr_fork_helper_main(int fd) {
             return it->second.g.get();
         }
         Held &slot = keep ? models[key] : scratch;       // a training target is single-use: it never enters the kept set
+        if (keep && state == 1 && slot.g && slot.hash == hash && slot.g->nr_mixtures == K && slot.g->dim == D) {
+            // parameters the helper already holds (sent again after a miss elsewhere in the list, or twice in one request): the
+            // object stays -- an earlier entry of this request may point at it -- and its packed sets with it
+            const size_t k = (size_t)K, kd = k * (size_t)D;
+            r.take(k * sizeof(double));
+            r.take(kd * sizeof(double));
+            r.take(kd * sizeof(double));
+            slot.tick = ++clock;
+            return slot.g.get();
+        }
         slot.tick = ++clock;
         slot.g = std::make_unique<GMM>();
         slot.hash = hash;
@@ -539,6 +604,25 @@ extern "C" int sr_fork_helper_main(int fd) {
                 w.str("");
                 w.pod<double>(sum);
                 if (want_ll) w.bytes(ll.data(), ll.size() * sizeof(float));
+            } else if (op == OP_SCORE_MODELS) {
+                set_default_device(r.pod<int32_t>());
+                const int n_models = r.pod<int32_t>();
+                if (n_models <= 0 || n_models > (1 << 20)) fail("fork helper: bad model count");
+                std::vector<GMM *> ms((size_t)n_models);
+                for (int i = 0; i < n_models; i++) ms[(size_t)i] = take_model(r, true);
+                const long n = (long)r.pod<int64_t>();
+                const int dim = r.pod<int32_t>();
+                const int flags = r.pod<int32_t>();
+                if (n < 0 || dim <= 0) fail("fork helper: bad frame matrix shape");
+                const float *X = reinterpret_cast<const float *>(r.take((size_t)n * dim * sizeof(float)));
+                std::vector<double> sums((size_t)n_models, 0.0);
+                {
+                    std::lock_guard<std::recursive_mutex> lock(api_mutex());
+                    score_models_local(ms.data(), n_models, X, n, dim, sums.data(), flags);
+                }
+                w.pod<int32_t>(0);
+                w.str("");
+                w.bytes(sums.data(), sums.size() * sizeof(double));
             } else if (op == OP_TRAIN) {
                 set_default_device(r.pod<int32_t>());
                 GMM *g = take_model(r, false);
@@ -582,7 +666,14 @@ extern "C" int sr_fork_helper_main(int fd) {
         // training targets are single-use (scratch); the rest is a bounded least-recently-used set, so that a long-lived pool worker
         // enrolling speaker after speaker does not grow this process (and its packed device sets) without bound
         scratch = Held();
-        while (models.size() > HELPER_MAX_MODELS) {
+        auto kept_bytes = [&]() {
+            size_t b = 0;
+            for (const auto &kv : models)
+                if (kv.second.g) b += (kv.second.g->weights.size() + kv.second.g->mean.size() + kv.second.g->sigma.size()) * sizeof(double);
+            return b;
+        };
+        const size_t max_models = g_helper_max_models.load() > 0 ? (size_t)g_helper_max_models.load() : HELPER_MAX_MODELS;
+        while (models.size() > max_models || (models.size() > 1 && kept_bytes() > HELPER_MAX_MODEL_BYTES)) {
             auto oldest = models.begin();
             for (auto it = models.begin(); it != models.end(); ++it)
                 if (it->second.tick < oldest->second.tick) oldest = it;

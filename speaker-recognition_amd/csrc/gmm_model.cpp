@@ -1,12 +1,20 @@
 // gmm_model.cpp -- text model format + parameter packing (host, float64 -> fp32 tables).
 #include "gmm_model.hpp"
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <limits>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+
+namespace sr {
+uint64_t next_gmm_uid() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
+}  // namespace sr
 
 namespace sr {
 

@@ -13,6 +13,10 @@ struct SRModelSet;
 
 // The handle type of the C ABI (`GMM *`).  Reference: class GMM, src/gmm/src/gmm.hh:130-173;
 // per-Gaussian mean/sigma (sigma = STANDARD DEVIATIONS) as gmm.hh:24-46.
+namespace sr {
+uint64_t next_gmm_uid();       // gmm_model.cpp
+}
+
 struct GMM {
     int nr_mixtures = 0;
     int covariance_type = 1;  // COVTYPE_DIAGONAL, gmm.hh:18-22
@@ -24,8 +28,13 @@ struct GMM {
     // each holds its device's lock only); invalidated by training.  (mutable: a cache -- a UBM handed to the MAP trainer as
     // `const` lends its packed set to every speaker's first E-step, em.hip)
     mutable std::shared_ptr<SRModelSet> single[sr::MAX_DEVICES];
+    // identity of the PARAMETERS for caches that hold several models (sr_score_models_f32): `uid` is unique per object for the life
+    // of the process (an address can come back), `generation` moves whenever the parameters change (every writer calls drop_single)
+    uint64_t uid = sr::next_gmm_uid();
+    uint64_t generation = 0;
     void drop_single() {
         for (auto &s : single) s.reset();
+        generation++;
     }
     bool trained() const { return dim > 0 && (int)weights.size() == nr_mixtures; }
 };

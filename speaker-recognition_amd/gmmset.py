@@ -9,6 +9,7 @@ speaker model sits in one device-resident ``ModelSet`` and an utterance -- or a 
 """
 from __future__ import annotations
 
+import ctypes as C
 import threading
 from collections import OrderedDict
 
@@ -81,7 +82,14 @@ class GMMSet(object):
             # a worker forked after the parent used the GPU (the reference's fit-then-Pool drivers, test-nperson.py:126-139):
             # device-resident sets cannot exist here; the reference's own speaker-by-speaker loop (gmmset.py:59-64) can --
             # each call is served by this process's helper (csrc/fork_proxy.cpp)
-            return [float(g.score_all(x)) for g in self.gmms]
+            # -- in ONE conversation and one fused pass in the helper for the whole set (sr_score_models_f32; the per-speaker loop was
+            # a conversation, a launch chain and a reply per speaker: 80 per utterance in the reference's logged run)
+            X = _lib.f32_matrix(x)
+            handles = (C.c_void_p * len(self.gmms))(*[g.gmm for g in self.gmms])
+            sums = np.zeros(len(self.gmms))
+            _lib.check(_lib.lib().sr_score_models_f32(handles, len(self.gmms), _lib.as_fp(X), X.shape[0], X.shape[1],
+                                                      _lib.as_dp(sums), _lib.SR_CLAMP_COMPAT), "sr_score_models_f32")
+            return sums.tolist()
         # one utterance at a time is how the reference's drivers call (gmmset.py:62-64, gui.py:179-214): the device batch is kept and
         # refilled, so such a loop allocates nothing
         # (a batch per calling thread: the calls below release the GIL)

@@ -128,6 +128,36 @@ def test_package_gmmset_and_training_in_forked_workers(built_lib):
     assert _run_pool(_train_task, range(3), workers=3) == ref
 
 
+def test_forked_workers_score_the_whole_set_in_one_conversation(built_lib):
+    """predict_one_scores in a forked worker is ONE conversation with its helper and one fused pass there (sr_score_models_f32) --
+    the reference's logged run calls it per utterance against 80 speakers (test-nperson.py:133-146).  Its sums must be the bits of
+    the parent's fused pass: utterances of different lengths one after the other in the same worker, a set that names a model
+    twice, a model re-trained between two pools (new parameters behind the same handle), and a helper that keeps fewer models than
+    the set has (every call evicts, misses and sends the list again)."""
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.gmmset import GMMSet
+    from speaker_recognition_amd.pygmm import GMM
+    raw = [synth.synth_gmm(8, 13, 50 + s) for s in range(20)]
+    gs = GMMSet(gmm_order=8)
+    for s, m in enumerate(raw):
+        gs._append("s%d" % s, GMM.from_arrays(*m))
+    gs._append("again", gs.gmms[3])                              # the same handle twice
+    utts = [synth.draw_frames(raw[u % 20], n, 400 + u).astype(np.float64) for u, n in enumerate([300, 40, 1000, 33, 300, 300])]
+    want = [[float(v) for v in gs.predict_one_scores(x)] for x in utts]      # parent: in-process fused pass, GPU runtime up
+    _STATE.update(set=gs, utts=utts)
+    assert _run_pool(_scores_task, range(len(utts)), workers=1) == want
+    assert _run_pool(_scores_task, range(len(utts)), workers=3) == want
+    _lib.set_option("debug_helper_max_models", 5)
+    try:
+        assert _run_pool(_scores_task, range(len(utts)), workers=1) == want
+    finally:
+        _lib.set_option("debug_helper_max_models", 0)
+    gs.gmms[7].fit(utts[2][:, :13], None)                        # new parameters behind the same handle
+    want2 = [[float(v) for v in gs.predict_one_scores(x)] for x in utts]
+    assert want2 != want
+    assert _run_pool(_scores_task, range(len(utts)), workers=2) == want2
+
+
 def _fresh_child_scores(conn):
     """a pool created BEFORE the first compute call: the worker initialises its own runtime, no helper involved"""
     try:
@@ -175,8 +205,8 @@ def test_pool_before_first_compute_call_initialises_per_worker():
 
 
 def _many_models_task(_):
-    """one forked worker scores MORE models than its helper keeps (64), then the first ones again: the helper has evicted them,
-    says so, and the library sends them again (csrc/fork_proxy.cpp: HELPER_MAX_MODELS, "fork helper miss")"""
+    """one forked worker scores MORE models than its helper keeps (the test hook lowers the bound to 64), then the first ones again: the
+    helper has evicted them, says so, and the library sends them again (csrc/fork_proxy.cpp: HELPER_MAX_MODELS, "fork helper miss")"""
     models, x = _STATE["many"], _STATE["utts"][0]
     first = [m.score_all(x) for m in models]
     again = [m.score_all(x) for m in models[:8]]
@@ -190,5 +220,13 @@ def test_forked_worker_with_more_models_than_its_helper_keeps(built_lib):
     x = synth.draw_frames(synth.synth_gmm(4, 13, 900), 120, 5).astype(np.float64)
     want = [m.score_all(x) for m in models]                 # parent: GPU runtime up before the fork
     _STATE["many"], _STATE["utts"] = models, [x]
+    from speaker_recognition_amd import _lib
+    _lib.set_option("debug_helper_max_models", 64)          # (logged here, replayed into every helper at its start)
+    try:
+        (first, again), = _run_pool(_many_models_task, [0], workers=1)
+    finally:
+        _lib.set_option("debug_helper_max_models", 0)
+    assert np.allclose(first, want, rtol=0, atol=0) and np.allclose(again, want[:8], rtol=0, atol=0)
+    # ... and with the default bound (the reference's logged run: 80 speakers per worker) nothing is evicted: same values
     (first, again), = _run_pool(_many_models_task, [0], workers=1)
     assert np.allclose(first, want, rtol=0, atol=0) and np.allclose(again, want[:8], rtol=0, atol=0)
