@@ -213,6 +213,40 @@ def test_per_utterance_loop_reuses_its_batch_and_equals_the_batched_pass(built_l
     assert L.sr_batch_reset_features(b._h, _lib.as_fp(X), 5, 39, _lib.as_i64p(bad), 2) != 0 and "non-decreasing" in _lib.last_error()
 
 
+def test_score_models_entry_point_equals_the_packed_set(built_lib):
+    """sr_score_models_f32 in-process (what a fork helper runs for a forked worker's predict_one): GMM handles in, the sums of one fused
+    pass out -- the bits of ModelSet.score on the same models; the packed set is kept across calls and follows a model whose
+    parameters change behind the same handle, a shorter list, and a list that names a handle twice."""
+    import ctypes as C
+    from speaker_recognition_amd import _lib, synth
+    from speaker_recognition_amd.core import Batch, ModelSet
+    from speaker_recognition_amd.pygmm import GMM
+    L = _lib.lib()
+    raw = [synth.synth_gmm(16, 20, 610 + s) for s in range(9)]
+    gm = [GMM.from_arrays(*m) for m in raw]
+
+    def entry(models, x):
+        X = _lib.f32_matrix(x)
+        h = (C.c_void_p * len(models))(*[g.gmm for g in models])
+        out = np.zeros(len(models))
+        assert L.sr_score_models_f32(h, len(models), _lib.as_fp(X), X.shape[0], X.shape[1], _lib.as_dp(out), _lib.SR_CLAMP_COMPAT) == 0, _lib.last_error()
+        return out
+
+    xs = [synth.draw_frames(raw[i % 9], n, 77 + i, outlier_frac=0.01) for i, n in enumerate([500, 31, 500, 1200])]
+    for models in (gm, gm[:4], [gm[2], gm[5], gm[2]], gm):
+        ms = ModelSet(models)
+        for x in xs:
+            want, _ = ms.score(Batch.from_features([x]))
+            assert np.array_equal(entry(models, x), want[0])
+    gm[1].fit(xs[3], None)                                     # new parameters behind the same handle
+    want, _ = ModelSet(gm).score(Batch.from_features([xs[0]]))
+    assert np.array_equal(entry(gm, xs[0]), want[0])
+    wrong = synth.draw_frames(synth.synth_gmm(4, 13, 1), 50, 2)
+    X = _lib.f32_matrix(wrong)
+    h = (C.c_void_p * 2)(gm[0].gmm, gm[1].gmm)
+    assert L.sr_score_models_f32(h, 2, _lib.as_fp(X), 50, 13, _lib.as_dp(np.zeros(2)), 0) != 0 and "dim" in _lib.last_error()
+
+
 def test_serving_loop_with_changing_layouts_equals_fresh_batches(built_lib):
     """A serving loop whose batch changes its layout from call to call (Batch.reset_pcm: 1-4 utterances of 0.4-1.2 s): samples,
     offsets, the feature stage's frame offsets and the rebuilt tile tables all travel through page-locked copies left in flight
