@@ -840,6 +840,17 @@ def block_cfg0(_lib):
     t3 = time.perf_counter()
     dev = {"enroll_features_s": t1 - t0, "train_s": t2 - t1, "predict_s": t3 - t2, "total_s": t3 - t0,
            "correct": int(sum(p == l for p, (l, _) in zip(pred, test))), "of": len(test)}
+    # the same ten fits an iteration per launch (em_stats_engine 3; csrc/em.hip) beside the whole-fit kernel's (csrc/em_small.hip)
+    try:
+        _lib.set_option("em_stats_engine", 3)
+        m3 = ModelInterface(gmm_order=K, feature_kwargs=kw, lpc=False, gmm_kwargs={"seed": 1}, verbose=False)
+        for label, f in enroll:
+            m3.enroll(label, *read_wav(f))
+        t4 = time.perf_counter()
+        m3.train()
+        dev["train_iteration_per_launch_s"] = time.perf_counter() - t4
+    finally:
+        _lib.set_option("em_stats_engine", 0)
     cpu = None
     try:
         out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cfg0_baseline.py"), tmp], capture_output=True, text=True, timeout=400)

@@ -869,8 +869,9 @@ int sr_set_option(const char *key, long value) {
         if (value != 0 && value != 1) fail("reference_side_effects must be 0 or 1");
         set_reference_side_effects((int)value);
     } else if (k == "em_stats_engine") {
-        if (value < 0 || value > 2)
-            fail("em_stats_engine must be 0 (automatic), 1 (vector ALU) or 2 (fp64 matrix cores, responsibilities on the vector ALU)");
+        if (value < 0 || value > 3)
+            fail("em_stats_engine must be 0 (automatic), 1 (vector ALU), 2 (fp64 matrix cores, responsibilities on the vector ALU) or "
+                 "3 (automatic, an iteration per launch: no whole-fit kernel)");
         set_em_stats_engine((int)value);
     } else if (k == "multi_merge_same_device") {
         multi_merge_option().store(value != 0);

@@ -749,6 +749,9 @@ static void dispatch_stats_mfma(int DP, const float *X, int64_t n, int dim, cons
 
 // initialisation: kmeans_init.hip (the reference's own draws, decision for decision)
 void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Parameter &param, long seed);
+// em_small.hip
+bool em_small_eligible(int K, int dim, long n, const Parameter &param);
+bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations);
 void burn_reference_rand(int count);
 
 // The model of one EM / MAP iteration as a set: the vector-ALU layout (the statistics kernels' records) and -- round 4 -- the
@@ -804,7 +807,10 @@ struct EmWorkspace {
     PinnedBuf<double> h_stats;        // where an iteration's sums land on the host
 };
 static int &em_stats_engine_option() {
-    static int v = 0;       // 0 = automatic (fp64 matrix cores where instantiated; responsibilities on the 16-bit ones where the model allows), 1 = the vector-ALU form always, 2 = fp64 matrix cores with the responsibilities on the vector ALU (round 3's)
+    // 0 = automatic (a speaker-sized fit whole in one launch, em_small.hip; else fp64 matrix cores where instantiated, responsibilities
+    // on the 16-bit ones where the model allows), 1 = the vector-ALU form always, 2 = fp64 matrix cores with the responsibilities on the
+    // vector ALU (round 3's), 3 = automatic among the iteration-at-a-time engines (no whole-fit launch)
+    static int v = 0;
     return v;
 }
 void set_em_stats_engine(int v) { em_stats_engine_option() = v; }
@@ -862,6 +868,15 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
     feat.offsets = {0, (int64_t)n};
     feat.data.upload(X, (size_t)n * dim);
     feat.d_offsets.upload(feat.offsets.data(), feat.offsets.size());
+    // a speaker-sized fit: every iteration, the stop rule included, in ONE launch (em_small.hip; last_em_stats_engine() = 4).  Not with
+    // the reference's side effects on (a model file after every second iteration) nor with the per-phase trace (verbosity >= 2).
+    if (em_stats_engine_option() == 0 && !reference_side_effects_option() && em_small_eligible(K, dim, n, param)) {
+        int iterations = 0;
+        if (train_em_small(gmm, ubm, feat.data.p, n, dim, param, relevance, &iterations)) {
+            g_last_stats_engine.store(4);
+            return iterations;
+        }
+    }
     sync_stream();
 
     const int n_tiles = (int)((n + 255) / 256);
@@ -921,7 +936,7 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         const bool use_mfma = stats_mfma_available(DP) && stats_engine != 1;
         // round 4: responsibilities on the 16-bit matrix cores when the model is inside the split-bf16 layout's range -- the
         // engine score_device has just taken for the denominators (em_stats_engine = 2 keeps them on the vector ALU)
-        const bool use_split = use_mfma && stats_engine == 0 && split_bf16_in_range(set) && stats_split_available(DP, dim);
+        const bool use_split = use_mfma && (stats_engine == 0 || stats_engine == 3) && split_bf16_in_range(set) && stats_split_available(DP, dim);
         g_last_stats_engine.store(use_split ? 3 : use_mfma ? 2 : 1);
         if (use_split) {
             ensure_bx3_layout(set);

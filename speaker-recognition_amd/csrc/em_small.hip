@@ -1,0 +1,432 @@
+// em_small.hip -- a WHOLE EM / MAP fit of a speaker-sized model in one launch.
+//
+// Why: a speaker model (gui/interface.py:55-109 enrols 32 mixtures; configs[0] 16 x 13 on 3000 frames) is fitted by up to 200
+// iterations (gmm.cc:600-651) of a few microseconds of arithmetic each.  Iteration at a time (em.hip: pack, upload, score, statistics,
+// sums back to the host, M-step there, every second iteration a pass for the total log-likelihood) an iteration costs ~85 us of launches,
+// small copies and host waits around ~25 us of kernels: 17-21 ms per fit, 96 % of configs[0]'s enrol + predict time.
+// Here the loop of GMMTrainerBaseline::train (gmm.cc:581-653) runs ON the device: one resident grid, a workgroup per 64 frames (kept in
+// its LDS for the whole fit, beside the model), ONE grid-wide barrier per iteration behind which every workgroup adds up everybody's sums
+// itself (two, with the addition shared out, when workgroups x sums is large), the host waits once.  16 x 13 on 2998 frames: 27 us per
+// iteration (96 iteration at a time); what an iteration costs is its trips to the memory side -- a device-scope release, the arrival, the
+// poll, the partial sums: ~12 us with ONE workgroup -- and it grows with the workgroups that meet (scripts/debug/em_small_time.py).
+//
+// Arithmetic: float64 throughout (the reference's own type, gmm.hh:15) -- log densities, responsibilities, the three sums, the M-step.
+//   E-step (gmm.cc:439-498): p_ik = w_k N(x_i; mu_k, sigma_k) taken in the log domain, a term below DBL_MIN = exp(-708.396) is 0 as in
+//     the reference's linear-domain product under -ffast-math (lse.hpp), a frame without a surviving term carries no responsibility
+//     (:482-498: its sum is replaced by 1e-15 and every quotient is 0) and counts ln 1e-15 in the total (safe_log, :34-38).
+//   Sums: N_k, sum g (x - mu_k), sum g (x - mu_k)^2 about the CURRENT mean (the variance then needs no cancelling subtraction of large
+//     numbers; em.hip's M-step restated), each (mixture, dimension) added up over a workgroup's frames in frame order, the workgroups'
+//     partial sums in workgroup order: the same bits on every run.
+//   M-step: N_k = 0 -> 1e-6 (:502-509); weights N_k / n normalised by their sum (:388-394); mean, then the variance about the NEW mean
+//     (:396-437) floored at sqrt(min_covar); MAP (gmmubm.cc:53-74): means only, relevance 16.
+//   Stop rule (:622-650): after every second iteration the total log-likelihood under the updated model -- which is the denominator
+//     pass of the NEXT iteration's E-step, so it costs nothing: the next E-step is computed, its total compared, and on "too small an
+//     increment" that iteration's M-step is not applied.
+// What this kernel leaves to the iteration-at-a-time path (it raises a flag, the host starts over there): a live frame whose largest
+// term lies within 110 nats of the underflow boundary -- where the reference's flushes of PARTIAL products decide (lse.hpp,
+// gmm_flush.hip) -- and anything that is not finite.
+#include "score.hpp"
+#include "wave_ops.hpp"
+
+#include "../../include/pygmm_hip.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <vector>
+
+namespace sr {
+
+namespace {
+
+constexpr int EMF_FRAMES = 64;                    // frames per workgroup step (one per lane of each of the four waves)
+constexpr int EMF_THREADS = 256;
+constexpr int EMF_MAX_K = 32, EMF_MAX_D = 40;
+// the iteration's price grows with the workgroups that meet at its barriers (12 us at one, 27 at 47, 46 at 128, 16 x 13); from ~10 k
+// frames on an iteration per launch costs the same (20 000 x 32 x 40: 30 ms either way)
+constexpr long EMF_MAX_FRAMES = 8192;
+constexpr int EMF_MAX_ROLES = (EMF_MAX_K * (EMF_MAX_D + 1) + EMF_THREADS - 1) / EMF_THREADS;      // (mixture, dimension | N) pairs per thread
+constexpr double EMF_MINLOG = -708.396418532264;  // ln DBL_MIN (fastexp.cc:93,105)
+constexpr double EMF_BAND = -598.0;               // a live frame below this goes to the path that restates the partial-product flushes
+constexpr double EMF_LN_1E_15 = -34.538776394910684;
+constexpr double EMF_SQRT_2_PI = 2.5066282746310002;
+
+struct EmSmallArgs {
+    const float *X;            // [n][dim]
+    int n, dim, K;
+    int nr_iter;
+    int map;                   // means only (gmmubm.cc:53-74)
+    double threshold, min_sigma, relevance;
+    const double *init;        // [K] weights, [K*D] means, [K*D] sigmas, (map) [K*D] the UBM's means
+    double *partials;          // [grid][E]
+    double *totals;            // [E]
+    double *out;               // [K] weights, [K*D] means, [K*D] sigmas
+    double *ll_hist;           // [nr_iter]: total log-likelihood after iteration i (odd i only; NaN elsewhere)
+    int *result;               // [0] iterations carried out, [1] flag (1: left to the other path)
+    unsigned *barrier;         // grid barrier counter (0 at launch)
+};
+
+// every workgroup of the (resident) grid arrives; `round` = 1, 2, ... over the barriers of the launch.  Every thread releases its own
+// stores at device scope before the workgroup's barrier and acquires behind it (the device's eight L2s are not coherent with each
+// other for plain accesses); what crosses workgroups is then read with plain loads.  Measured (scripts/debug/em_small_time.py, 16 x 13
+// on 47 workgroups / 32 x 40 on 256): two full fences and acquiring polls 49 / 647 us per iteration; release + acquire fences and relaxed
+// polls with a longer sleep 38 / 222 (the pollers' traffic on the one address was most of it).  Arrivals dealt to eight group counters on
+// lines of their own: 27.0 -> 26.1 / 89 -> 80, not kept.
+__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned round) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (released by the fence above)
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * gridDim.x) __builtin_amdgcn_s_sleep(8);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// sum over the grid's workgroups of entry e: partials[e][0 .. G), in workgroup order, 32 loads in flight at a time (one after
+// the other they cost a trip to the memory side each: 47 of them were most of an iteration).  Plain loads: behind the barrier's acquire.
+__device__ __forceinline__ double sum_partials(const double *row, int G) {
+    double t = 0.0;
+    for (int w0 = 0; w0 < G; w0 += 32) {
+        double v[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) v[j] = w0 + j < G ? row[w0 + j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) t += v[j];
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(EMF_THREADS)
+void em_small_fit_kernel(const EmSmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double emf_lds[];
+    const int K = a.K, D = a.dim, n = a.n;
+    const int REC = 2 * D + 1;                     // a mixture's sums: [D] first moments, [D] second moments, N
+    const int E = K * REC + 2;                     // + total log-likelihood, + flag count
+    double *s_w = emf_lds;                         // [K]
+    double *s_c = s_w + K;                         // [K]   ln w - sum_d ln(sqrt(2 pi) sigma_d)
+    double *s_nk = s_c + K;                        // [K]
+    double *s_mu = s_nk + K;                       // [K][D]
+    double *s_h = s_mu + K * D;                    // [K][D] 1 / (2 sigma^2)
+    double *s_sg = s_h + K * D;                    // [K][D]
+    double *s_g = s_sg + K * D;                    // [K][64]  log densities -> exponentials -> responsibilities
+    double *s_pm = s_g + K * EMF_FRAMES;           // [4][64]  the four waves' maxima, then their sums
+    double *s_ll = s_pm + 4 * EMF_FRAMES;          // [64]
+    double *s_tot = s_ll + EMF_FRAMES;             // [E]      the grid's sums of an iteration
+    float *s_x = reinterpret_cast<float *>(s_tot + E);              // [64][D + 1]
+    const int XS = D + 1;
+
+    const int tid = threadIdx.x, f = tid & 63, g = tid >> 6;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const int n_chunks = (n + EMF_FRAMES - 1) / EMF_FRAMES;
+    const int R = K * (D + 1);                     // roles of the sums: (k, d < D) both moments, (k, D) N_k
+
+    for (int i = tid; i < K; i += EMF_THREADS) s_w[i] = a.init[i];
+    for (int i = tid; i < K * D; i += EMF_THREADS) {
+        s_mu[i] = a.init[K + i];
+        s_sg[i] = a.init[K + K * D + i];
+    }
+    __syncthreads();
+    auto derive = [&]() {                           // (a barrier in front of it; s_g is free between two E-steps)
+        for (int i = tid; i < K * D; i += EMF_THREADS) {
+            s_h[i] = 0.5 / (s_sg[i] * s_sg[i]);
+            s_g[i] = log(EMF_SQRT_2_PI * s_sg[i]);  // (one logarithm per thread: a mixture's D of them in a row were most of an M-step)
+        }
+        __syncthreads();
+        for (int k = tid; k < K; k += EMF_THREADS) {
+            double c = s_w[k] > 0.0 ? log(s_w[k]) : -__builtin_inf();
+            for (int d = 0; d < D; d++) c -= s_g[k * D + d];
+            s_c[k] = c;
+        }
+    };
+    derive();
+    __syncthreads();
+
+    const bool redundant = (long)G * E <= 48 * 1024;
+    const bool one_chunk = n_chunks <= G;
+    unsigned arrivals = 0;
+    double last_ll = -DBL_MAX;
+    int done = a.nr_iter, flagged = 0;
+    for (int it = 0;; it++) {
+        const bool ll_only = it == a.nr_iter;      // the total after the LAST iteration, when that one is an odd one (gmm.cc:622)
+        if (ll_only && ((a.nr_iter - 1) & 1) == 0) break;
+
+        // ---- E-step over this workgroup's frames ----
+        double m1[EMF_MAX_ROLES], m2[EMF_MAX_ROLES];
+#pragma unroll
+        for (int j = 0; j < EMF_MAX_ROLES; j++) m1[j] = m2[j] = 0.0;
+        double ll_part = 0.0;
+        int bad = 0;
+        for (int c = wg; c < n_chunks; c += G) {
+            const int f0 = c * EMF_FRAMES;
+            __syncthreads();                        // the chunk before is done with s_x / s_g
+            if (!(one_chunk && it > 0)) {           // (a workgroup with ONE chunk keeps it in LDS for the whole fit)
+                for (int i = tid; i < EMF_FRAMES * D; i += EMF_THREADS) {
+                    const int fr = i / D, d = i - fr * D;
+                    s_x[fr * XS + d] = f0 + fr < n ? a.X[(size_t)(f0 + fr) * D + d] : 0.f;
+                }
+                __syncthreads();
+            }
+            const bool valid = f0 + f < n;
+            // log densities of this wave's mixtures (k = g, g + 4, ...) for frame f
+            double pmax = -__builtin_inf();
+            for (int k = g; k < K; k += 4) {
+                double lp = s_c[k];
+                const double *mu = s_mu + k * D, *h = s_h + k * D;
+                for (int d = 0; d < D; d++) {
+                    const double t = (double)s_x[f * XS + d] - mu[d];
+                    lp = fma(-(t * t), h[d], lp);
+                }
+                s_g[k * EMF_FRAMES + f] = lp;
+                if (lp >= EMF_MINLOG) pmax = fmax(pmax, lp);
+                if (valid && !(lp == lp)) bad = 1;                 // NaN (a non-finite input or parameter)
+            }
+            s_pm[g * EMF_FRAMES + f] = pmax;
+            __syncthreads();
+            const double m = fmax(fmax(s_pm[f], s_pm[EMF_FRAMES + f]), fmax(s_pm[2 * EMF_FRAMES + f], s_pm[3 * EMF_FRAMES + f]));
+            const bool live = m >= EMF_MINLOG;                     // some term survives (gmm.cc:482-498)
+            __syncthreads();                                       // (s_pm is rewritten)
+            double psum = 0.0;
+            for (int k = g; k < K; k += 4) {
+                const double lp = s_g[k * EMF_FRAMES + f];
+                const double e = live && lp >= EMF_MINLOG ? exp(lp - m) : 0.0;
+                s_g[k * EMF_FRAMES + f] = e;
+                psum += e;
+            }
+            s_pm[g * EMF_FRAMES + f] = psum;
+            __syncthreads();
+            const double s = ((s_pm[f] + s_pm[EMF_FRAMES + f]) + s_pm[2 * EMF_FRAMES + f]) + s_pm[3 * EMF_FRAMES + f];
+            const double r = live && valid ? 1.0 / s : 0.0;
+            for (int k = g; k < K; k += 4) s_g[k * EMF_FRAMES + f] *= r;
+            if (g == 0) {
+                s_ll[f] = valid ? (live ? m + log(s) : EMF_LN_1E_15) : 0.0;
+                if (valid && live && m < EMF_BAND) bad = 1;
+            }
+            __syncthreads();
+            if (g == 0) ll_part += wave_sum_f64(s_ll[f]);          // (fixed order, wave_ops.hpp; every lane of wave 0 holds it)
+            if (!ll_only) {
+#pragma unroll
+                for (int j = 0; j < EMF_MAX_ROLES; j++) {
+                    const int role = tid + j * EMF_THREADS;
+                    if (role < R) {
+                        const int k = role / (D + 1), d = role - k * (D + 1);
+                        const double *gam = s_g + k * EMF_FRAMES;
+                        // four running sums per moment (frames i = q mod 4), added up in a fixed order: a chain of 16 instead of 64
+                        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
+                        if (d < D) {
+                            const double mu = s_mu[k * D + d];
+                            for (int i = 0; i < EMF_FRAMES; i += 4) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    const double dv = (double)s_x[(i + q) * XS + d] - mu;
+                                    const double gd = gam[i + q] * dv;
+                                    p1[q] += gd;
+                                    p2[q] = fma(gd, dv, p2[q]);
+                                }
+                            }
+                        } else {
+                            for (int i = 0; i < EMF_FRAMES; i += 4) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) p1[q] += gam[i + q];
+                            }
+                        }
+                        const double a1 = m1[j] + ((p1[0] + p1[1]) + (p1[2] + p1[3])), a2 = m2[j] + ((p2[0] + p2[1]) + (p2[2] + p2[3]));
+                        m1[j] = a1;
+                        m2[j] = a2;
+                    }
+                }
+            }
+        }
+        // ---- this workgroup's sums out ([entry][workgroup]: a reader's lanes take consecutive entries' rows), everybody's in ----
+        {
+            double *mine = a.partials + wg;
+#pragma unroll
+            for (int j = 0; j < EMF_MAX_ROLES; j++) {
+                const int role = tid + j * EMF_THREADS;
+                if (role < R) {
+                    const int k = role / (D + 1), d = role - k * (D + 1);
+                    if (d < D) {
+                        mine[(size_t)(k * REC + d) * G] = m1[j];
+                        mine[(size_t)(k * REC + D + d) * G] = m2[j];
+                    } else {
+                        mine[(size_t)(k * REC + 2 * D) * G] = m1[j];
+                    }
+                }
+            }
+            if (tid == 0) mine[(size_t)(K * REC) * G] = ll_part;
+            const int any_bad = __syncthreads_or(bad);
+            if (tid == 0) mine[(size_t)(K * REC + 1) * G] = any_bad ? 1.0 : 0.0;
+        }
+        grid_barrier(a.barrier, ++arrivals);
+        if (redundant) {
+            // few workgroups x few entries: every workgroup adds up everything itself (G x E loads, one trip's latency) -- one
+            // grid barrier per iteration
+            for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = sum_partials(a.partials + (size_t)e * G, G);
+        } else {
+            for (int e = wg * EMF_THREADS + tid; e < E; e += G * EMF_THREADS) a.totals[e] = sum_partials(a.partials + (size_t)e * G, G);
+            grid_barrier(a.barrier, ++arrivals);
+            for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = a.totals[e];
+        }
+        __syncthreads();
+
+        if (s_tot[K * REC + 1] > 0.0) {
+            flagged = 1;
+            break;
+        }
+        // the total under the model as iteration it - 1 left it: the reference takes it after odd iterations (gmm.cc:622-650)
+        if (it >= 1 && ((it - 1) & 1)) {
+            const double ll = s_tot[K * REC];
+            if (wg == 0 && tid == 0) a.ll_hist[it - 1] = ll;
+            const double ll_diff = ll - last_ll;
+            if (fabs(ll_diff) / fabs(ll) < a.threshold && ll_diff < a.threshold) {
+                done = it;
+                break;
+            }
+            last_ll = ll;
+        }
+        if (ll_only) break;
+
+        // ---- M-step (em.hip's host M-step restated; every workgroup forms the same model) ----
+        for (int k = tid; k < K; k += EMF_THREADS) {
+            double v = s_tot[k * REC + 2 * D];
+            if (v == 0.0) v = 1e-6;                                 // min_n_k, gmm.cc:502-509
+            s_nk[k] = v;
+        }
+        __syncthreads();
+        if (!a.map) {                                               // update_weights, gmm.cc:388-394 (the quotients side by side, their sum in order)
+            for (int k = tid; k < K; k += EMF_THREADS) s_w[k] = s_nk[k] / (double)n;
+            __syncthreads();
+            double wsum = 0.0;
+            for (int k = 0; k < K; k++) wsum += s_w[k];
+            __syncthreads();
+            for (int k = tid; k < K; k += EMF_THREADS) s_w[k] /= wsum;
+        }
+        for (int i = tid; i < K * D; i += EMF_THREADS) {
+            const int k = i / D, d = i - k * D;
+            const double sd = s_tot[k * REC + d], sdd = s_tot[k * REC + D + d];
+            const double nk = s_nk[k], mu_old = s_mu[i];
+            const double shift = sd / nk;                           // E_k[x] - mu_old
+            if (a.map) {                                            // update_means, gmmubm.cc:53-74
+                const double alpha = nk / (nk + a.relevance);
+                s_mu[i] = alpha * (mu_old + shift) + (1 - alpha) * a.init[K + 2 * K * D + i];
+            } else {                                                // gmm.cc:396-437
+                s_mu[i] = mu_old + shift;
+                double var = sdd / nk - shift * shift;              // sum g (x - mu_new)^2 = sdd - N shift^2
+                if (var < 0) var = 0;
+                s_sg[i] = fmax(a.min_sigma, sqrt(var));
+            }
+        }
+        __syncthreads();
+        derive();
+        // (the barrier at the head of the next E-step's first chunk publishes s_h / s_c)
+    }
+
+    if (wg == 0) {
+        __syncthreads();
+        for (int i = tid; i < K; i += EMF_THREADS) a.out[i] = s_w[i];
+        for (int i = tid; i < K * D; i += EMF_THREADS) {
+            a.out[K + i] = s_mu[i];
+            a.out[K + K * D + i] = s_sg[i];
+        }
+        if (tid == 0) {
+            a.result[0] = done;
+            a.result[1] = flagged;
+        }
+    }
+}
+
+struct EmSmallWorkspace {
+    DevBuf<double> init, partials, totals, out;
+    DevBuf<int> result;            // [0..1] the kernel's answer, [32] the barrier's counter (a line of its own)
+    PinnedBuf<double> h_out;       // the model and the totals' history, one copy
+    PinnedBuf<int> h_result;
+};
+
+}  // namespace
+
+size_t em_small_lds_bytes(int K, int D) {
+    return (size_t)(3 * K + 3 * K * D + K * EMF_FRAMES + 5 * EMF_FRAMES + K * (2 * D + 1) + 2) * sizeof(double) + (size_t)EMF_FRAMES * (D + 1) * sizeof(float);
+}
+
+bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
+    return K >= 1 && K <= EMF_MAX_K && dim >= 1 && dim <= EMF_MAX_D && n >= 1 &&
+           n <= EMF_MAX_FRAMES && param.nr_iteration >= 1 && param.verbosity < 2;
+}
+
+// The fit of `gmm` (its parameters are the start) on the n resident frames dX.  true: done -- gmm holds the result, *iterations the
+// count train_em returns; false: the kernel met what it leaves to the iteration-at-a-time path (gmm untouched).
+bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations) {
+    const int K = gmm.nr_mixtures, KD = K * dim;
+    auto &w = per_device<EmSmallWorkspace>();
+    const int n_chunks = (int)((n + EMF_FRAMES - 1) / EMF_FRAMES);
+    const int grid = std::min(n_chunks, ctx().n_cu);
+    const int E = K * (2 * dim + 1) + 2;
+    const int nit = param.nr_iteration;
+
+    std::vector<double> init((size_t)K + 2 * (size_t)KD + (ubm ? KD : 0));
+    for (int k = 0; k < K; k++) init[k] = gmm.weights[k];
+    for (int i = 0; i < KD; i++) {
+        init[K + i] = gmm.mean[i];
+        init[K + KD + i] = gmm.sigma[i];
+        if (ubm) init[K + 2 * KD + i] = ubm->mean[i];
+    }
+    w.init.upload(init.data(), init.size());
+    w.partials.ensure((size_t)grid * E);
+    w.totals.ensure((size_t)E);
+    w.out.ensure((size_t)K + 2 * (size_t)KD + (size_t)nit);
+    w.result.ensure(64);
+    w.h_out.ensure((size_t)K + 2 * (size_t)KD + (size_t)nit);
+    w.h_result.ensure(4);
+    SR_HIP(hipMemsetAsync(w.result.p, 0, 64 * sizeof(int), ctx().stream));
+    // (NaN: "no total taken after this iteration")
+    SR_HIP(hipMemsetAsync(w.out.p + K + 2 * KD, 0xff, (size_t)nit * sizeof(double), ctx().stream));
+
+    EmSmallArgs a;
+    a.X = dX;
+    a.n = (int)n;
+    a.dim = dim;
+    a.K = K;
+    a.nr_iter = nit;
+    a.map = ubm ? 1 : 0;
+    a.threshold = param.threshold;
+    a.min_sigma = std::sqrt(param.min_covar);
+    a.relevance = relevance;
+    a.init = w.init.p;
+    a.partials = w.partials.p;
+    a.totals = w.totals.p;
+    a.out = w.out.p;
+    a.ll_hist = w.out.p + K + 2 * KD;
+    a.result = w.result.p;
+    a.barrier = reinterpret_cast<unsigned *>(w.result.p + 32);
+    void *args[] = {&a};
+    const size_t lds = em_small_lds_bytes(K, dim);
+    if (lds > 64 * 1024)
+        SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&em_small_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const hipError_t launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&em_small_fit_kernel), dim3((unsigned)grid),
+                                                           dim3(EMF_THREADS), args, (unsigned)lds, ctx().stream);
+    if (launched != hipSuccess) {            // (a device or runtime without cooperative launches: the other path serves; sr_last_em_stats_engine tells)
+        (void)hipGetLastError();
+        return false;
+    }
+    w.out.download(w.h_out.p, (size_t)K + 2 * (size_t)KD + (size_t)nit);
+    w.result.download(w.h_result.p, 2);
+    sync_stream();
+    if (w.h_result.p[1]) return false;
+    const int done = w.h_result.p[0];
+    for (int k = 0; k < K; k++) gmm.weights[k] = w.h_out.p[k];
+    for (int i = 0; i < KD; i++) {
+        gmm.mean[i] = w.h_out.p[K + i];
+        gmm.sigma[i] = w.h_out.p[K + KD + i];
+    }
+    gmm.drop_single();
+    if (param.verbosity >= 1) {
+        const double *hist = w.h_out.p + K + 2 * KD;
+        for (int i = 1; i < done && i < nit; i += 2)
+            if (hist[i] == hist[i]) printf("iter %d: ll %lf\n", i, hist[i]);
+    }
+    *iterations = done;
+    return true;
+}
+
+}  // namespace sr

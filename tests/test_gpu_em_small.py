@@ -1,0 +1,117 @@
+"""A speaker-sized EM / MAP fit WHOLE in one launch (csrc/em_small.hip; sr_last_em_stats_engine() == 4): the loop of
+GMMTrainerBaseline::train (src/gmm/src/gmm.cc:581-653) -- E-step :439-498, M-step :388-437 / gmmubm.cc:53-74, stop rule
+:622-650 -- on the device in float64.  Checked against the float64 oracle iterated (oracle/gmm_oracle.c, pinned to the
+reference trainer's goldens), against the iteration-at-a-time path (csrc/em.hip, em_stats_engine 3) incl. the iteration
+the stop rule ends on, and for the frames it must hand over.  The reference trainer's own goldens run through this kernel
+in tests/test_gpu_pipeline.py (test_em_training_vs_reference_trainer_golden, test_train_from_scratch_vs_reference_trainer_golden)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(rng, n, K, D, spread=2.0, shift=0.0):
+    cent = shift + rng.normal(0, spread, (K, D))
+    return (cent[rng.integers(0, K, n)] + rng.normal(0, 0.7, (n, D))).astype(np.float32), cent
+
+
+def _fit(eng, X, K, iters, threshold, km=0, seed=7, ubm=None, start=None):
+    from speaker_recognition_amd import _lib
+    from speaker_recognition_amd.pygmm import GMM
+    _lib.set_option("em_stats_engine", eng)
+    try:
+        if start is not None:
+            g = GMM.from_arrays(*start)
+            g.nr_iteration, g.init_with_kmeans, g.threshold = iters, -1, threshold       # -1: warm start (extension)
+        else:
+            g = GMM(K, nr_iteration=iters, threshold=threshold, init_with_kmeans=km, seed=seed)
+        it = g.fit(X, ubm=ubm) if ubm is not None else g.fit(X)
+        return it, g.params(), _lib.last_em_stats_engine()
+    finally:
+        _lib.set_option("em_stats_engine", 0)
+
+
+def test_whole_fit_vs_oracle_iterated(built_lib, oracle_built):
+    """N iterations with the stop rule off (threshold 0) against the oracle's iteration applied N times, EM and MAP: float64 on
+    both sides -- models of 1..32 mixtures, 3..40 dims, frame counts around the 64-frame chunks up to the kernel's limit
+    (8192 frames: 128 workgroups, the sums shared out behind a second barrier)."""
+    go = oracle_built
+    rng = np.random.default_rng(31)
+    r6 = np.vectorize(lambda v: float("%g" % v))
+    for n, K, D, N in ((3000, 16, 13, 7), (900, 32, 39, 4), (150, 3, 40, 6), (4097, 9, 26, 5), (64, 1, 3, 3), (65, 2, 5, 2), (8192, 32, 34, 3), (8129, 4, 5, 4)):
+        X, cent = _data(rng, n, K, D, shift=3.0)
+        start = go.GMMParams(np.full(K, 1.0 / K), r6(cent + 0.2 * rng.standard_normal(cent.shape)), np.full((K, D), 0.9))
+        want = start
+        for _ in range(N):
+            want = go.em_iteration(want, X.astype(np.float64))
+        it, p, eng = _fit(0, X, K, N, 0.0, start=(start.weights, start.mean, start.sigma))
+        assert it == N and eng == 4, (n, K, D, it, eng)
+        err = (np.max(np.abs(p[0] - want.weights)), np.max(np.abs(p[1] - want.mean)), np.max(np.abs(p[2] - want.sigma) / want.sigma))
+        assert err[0] < 1e-7 and err[1] < 1e-6 and err[2] < 1e-6, (n, K, D, err)
+        m = min(n, 300)
+        want = start
+        for _ in range(N):
+            want = go.em_iteration(want, X[:m].astype(np.float64), map_relevance=16.0, ubm=start)
+        from speaker_recognition_amd.pygmm import GMM
+        ubm = GMM.from_arrays(start.weights, start.mean, start.sigma)
+        it, p, eng = _fit(0, X[:m], K, N, 0.0, ubm=ubm)
+        assert it == N and eng == 4
+        assert np.array_equal(p[0], start.weights) and np.array_equal(p[2], start.sigma)        # means only, gmmubm.cc:29-38
+        assert np.max(np.abs(p[1] - want.mean)) < 1e-6, (n, K, D, np.max(np.abs(p[1] - want.mean)))
+
+
+def test_whole_fit_vs_iteration_at_a_time_with_the_stop_rule(built_lib):
+    """Both paths from the same initialisation (random frames / k-means||, the reference's own random numbers) under the
+    reference's default stop rule (threshold 0.01, checked after every second iteration, gmm.cc:622-650): the same iteration
+    ends both, the models agree inside the training gates; verbosity 1 prints the totals the rule saw."""
+    rng = np.random.default_rng(5)
+    for n, K, D, km in ((2998, 16, 13, 0), (2998, 16, 13, 1), (1250, 32, 34, 1), (5000, 8, 20, 0), (64, 4, 3, 0), (333, 5, 39, 0)):
+        X, _ = _data(rng, n, K, D)
+        it3, p3, e3 = _fit(3, X, K, 200, 0.01, km)
+        it0, p0, e0 = _fit(0, X, K, 200, 0.01, km)
+        assert e0 == 4 and e3 in (1, 2, 3), (e0, e3)
+        assert it0 == it3, (n, K, D, km, it0, it3)
+        err = (np.max(np.abs(p0[0] - p3[0])), np.max(np.abs(p0[1] - p3[1])), np.max(np.abs(p0[2] - p3[2]) / p3[2]))
+        assert err[0] < 2e-5 and err[1] < 2e-4 and err[2] < 1e-3, (n, K, D, km, err)
+    # an odd and an even iteration limit below the stop rule's iteration (the total after the LAST iteration is taken when that one is odd)
+    X, _ = _data(rng, 2000, 8, 13)
+    for iters in (1, 2, 3, 4):
+        it3, p3, _ = _fit(3, X, 8, iters, 0.0)
+        it0, p0, e0 = _fit(0, X, 8, iters, 0.0)
+        assert e0 == 4 and it0 == it3 == iters
+        assert np.max(np.abs(p0[1] - p3[1])) < 2e-4
+
+
+def test_whole_fit_frames_without_responsibility_and_the_flush_band(built_lib):
+    """A frame far from every mixture has no surviving term: no responsibility, ln 1e-15 in the total (gmm.cc:482-498, :34-38)
+    -- the kernel's own rule, against the other path.  A live frame within 110 nats of the underflow boundary is where the
+    reference's flushes of PARTIAL products decide (gmm_flush.hip): the kernel raises its flag and the fit runs iteration at
+    a time -- same bits as asking for that path."""
+    rng = np.random.default_rng(9)
+    X, cent = _data(rng, 500, 8, 13)
+    X[::50] += 1000.0
+    start = (np.full(8, 1.0 / 8), cent, np.full((8, 13), 0.9))
+    it3, p3, e3 = _fit(3, X, 8, 4, 0.0, start=start)
+    it0, p0, e0 = _fit(0, X, 8, 4, 0.0, start=start)
+    assert e0 == 4 and it0 == it3 == 4
+    assert np.max(np.abs(p0[0] - p3[0])) < 2e-5 and np.max(np.abs(p0[1] - p3[1])) < 2e-4 and np.max(np.abs(p0[2] - p3[2]) / p3[2]) < 1e-3
+    X, cent = _data(rng, 500, 1, 13)
+    X[::50] = (cent[0] + 9.1).astype(np.float32)          # 13 x (9.1 / 0.9)^2 / 2 = 664 nats down
+    start = (np.ones(1), cent, np.full((1, 13), 0.9))
+    it3, p3, e3 = _fit(3, X, 1, 1, 0.0, start=start)
+    it0, p0, e0 = _fit(0, X, 1, 1, 0.0, start=start)
+    assert e0 != 4 and e0 == e3
+    assert all(np.array_equal(a, b) for a, b in zip(p0, p3))
+
+
+def test_whole_fit_same_bits_on_every_run_and_limits(built_lib):
+    rng = np.random.default_rng(13)
+    X, _ = _data(rng, 2998, 16, 13)
+    a = _fit(0, X, 16, 200, 0.01, 1, seed=3)
+    b = _fit(0, X, 16, 200, 0.01, 1, seed=3)
+    assert a[2] == b[2] == 4 and a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+    # beyond the kernel's shapes the iteration-at-a-time path serves: 33 mixtures, 41 dims, 8193 frames
+    for n, K, D in ((3000, 33, 13), (3000, 8, 41), (8193, 4, 5)):
+        X, _ = _data(rng, n, K, D)
+        it, _, eng = _fit(0, X, K, 2, 0.0)
+        assert it == 2 and eng in (1, 2, 3), (n, K, D, eng)
