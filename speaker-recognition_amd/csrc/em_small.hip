@@ -4,11 +4,12 @@
 // iterations (gmm.cc:600-651) of a few microseconds of arithmetic each.  Iteration at a time (em.hip: pack, upload, score, statistics,
 // sums back to the host, M-step there, every second iteration a pass for the total log-likelihood) an iteration costs ~85 us of launches,
 // small copies and host waits around ~25 us of kernels: 17-21 ms per fit, 96 % of configs[0]'s enrol + predict time.
-// Here the loop of GMMTrainerBaseline::train (gmm.cc:581-653) runs ON the device: one resident grid, a workgroup per 64 frames (kept in
-// its LDS for the whole fit, beside the model), ONE grid-wide barrier per iteration behind which every workgroup adds up everybody's sums
-// itself (two, with the addition shared out, when workgroups x sums is large), the host waits once.  16 x 13 on 2998 frames: 27 us per
-// iteration (96 iteration at a time); what an iteration costs is its trips to the memory side -- a device-scope release, the arrival, the
-// poll, the partial sums: ~12 us with ONE workgroup -- and it grows with the workgroups that meet (scripts/debug/em_small_time.py).
+// Here the loop of GMMTrainerBaseline::train (gmm.cc:581-653) runs ON the device: one resident grid, a workgroup of 1024 threads per 64
+// or 128 frames (kept in its LDS for the whole fit, beside the model), ONE grid-wide barrier per iteration behind which every workgroup
+// adds up everybody's sums itself (two, with the addition shared out, when workgroups x sums is large), the host waits once.  16 x 13 on
+// 2998 frames: 19.6 us per iteration (96 iteration at a time), a 200-iteration fit 4.05 ms (17.8); what an iteration costs is its trips
+// to the memory side -- a device-scope release, the arrival, the poll, the partial sums: ~11 us with ONE workgroup -- and ~0.3 us per
+// workgroup that meets at the barrier (scripts/debug/em_small_time.py, profiles/r06_em_small.txt).
 //
 // Arithmetic: float64 throughout (the reference's own type, gmm.hh:15) -- log densities, responsibilities, the three sums, the M-step.
 //   E-step (gmm.cc:439-498): p_ik = w_k N(x_i; mu_k, sigma_k) taken in the log domain, a term below DBL_MIN = exp(-708.396) is 0 as in
@@ -40,13 +41,11 @@ namespace sr {
 
 namespace {
 
-constexpr int EMF_FRAMES = 64;                    // frames per workgroup step (one per lane of each of the four waves)
-constexpr int EMF_THREADS = 256;
+constexpr int EMF_THREADS = 1024;                 // a workgroup: 64 or 128 frames x 16 or 8 mixture groups
 constexpr int EMF_MAX_K = 32, EMF_MAX_D = 40;
 // the iteration's price grows with the workgroups that meet at its barriers (12 us at one, 27 at 47, 46 at 128, 16 x 13); from ~10 k
 // frames on an iteration per launch costs the same (20 000 x 32 x 40: 30 ms either way)
 constexpr long EMF_MAX_FRAMES = 8192;
-constexpr int EMF_MAX_ROLES = (EMF_MAX_K * (EMF_MAX_D + 1) + EMF_THREADS - 1) / EMF_THREADS;      // (mixture, dimension | N) pairs per thread
 constexpr double EMF_MINLOG = -708.396418532264;  // ln DBL_MIN (fastexp.cc:93,105)
 constexpr double EMF_BAND = -598.0;               // a live frame below this goes to the path that restates the partial-product flushes
 constexpr double EMF_LN_1E_15 = -34.538776394910684;
@@ -55,6 +54,7 @@ constexpr double EMF_SQRT_2_PI = 2.5066282746310002;
 struct EmSmallArgs {
     const float *X;            // [n][dim]
     int n, dim, K;
+    int fr, seg;               // frames per workgroup (64 / 128), segments of a role's sweep (a power of two, fr / seg a multiple of 4)
     int nr_iter;
     int map;                   // means only (gmmubm.cc:53-74)
     double threshold, min_sigma, relevance;
@@ -72,28 +72,32 @@ struct EmSmallArgs {
 // other for plain accesses); what crosses workgroups is then read with plain loads.  Measured (scripts/debug/em_small_time.py, 16 x 13
 // on 47 workgroups / 32 x 40 on 256): two full fences and acquiring polls 49 / 647 us per iteration; release + acquire fences and relaxed
 // polls with a longer sleep 38 / 222 (the pollers' traffic on the one address was most of it).  Arrivals dealt to eight group counters on
-// lines of their own: 27.0 -> 26.1 / 89 -> 80, not kept.
+// lines of their own: 27.0 -> 26.1 / 89 -> 80, not kept.  The device-scope fences by ONE thread (below): 24.7 -> 21.5 with 16 waves.
 __device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned round) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // every wave's stores are in the L2 (a workgroup-scope release waits for them) before the workgroup's barrier; ONE thread then
+    // writes the L2's dirty lines back, arrives, polls and invalidates (the device-scope fences cost per wave that executes them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (released by the fence above)
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * gridDim.x) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// sum over the grid's workgroups of entry e: partials[e][0 .. G), in workgroup order, 32 loads in flight at a time (one after
+// sum over the grid's workgroups of entry e: partials[e][0 .. G), in workgroup order, 16 loads in flight at a time (one after
 // the other they cost a trip to the memory side each: 47 of them were most of an iteration).  Plain loads: behind the barrier's acquire.
 __device__ __forceinline__ double sum_partials(const double *row, int G) {
     double t = 0.0;
-    for (int w0 = 0; w0 < G; w0 += 32) {
-        double v[32];
+    for (int w0 = 0; w0 < G; w0 += 16) {
+        double v[16];
 #pragma unroll
-        for (int j = 0; j < 32; j++) v[j] = w0 + j < G ? row[w0 + j] : 0.0;
+        for (int j = 0; j < 16; j++) v[j] = w0 + j < G ? row[w0 + j] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 32; j++) t += v[j];
+        for (int j = 0; j < 16; j++) t += v[j];
     }
     return t;
 }
@@ -102,30 +106,38 @@ __global__ __launch_bounds__(EMF_THREADS)
 void em_small_fit_kernel(const EmSmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double emf_lds[];
     const int K = a.K, D = a.dim, n = a.n;
+    const int FR = a.fr, NG = EMF_THREADS / FR;    // frames of this workgroup; thread = (frame f, mixture group g of NG)
+    const int S = a.seg;                           // segments a (mixture, dimension) pair's sweep over the frames is cut into
     const int REC = 2 * D + 1;                     // a mixture's sums: [D] first moments, [D] second moments, N
     const int E = K * REC + 2;                     // + total log-likelihood, + flag count
+    const int R = K * (D + 1);                     // roles of the sums: (k, d < D) both moments, (k, D) N_k
     double *s_w = emf_lds;                         // [K]
     double *s_c = s_w + K;                         // [K]   ln w - sum_d ln(sqrt(2 pi) sigma_d)
     double *s_nk = s_c + K;                        // [K]
     double *s_mu = s_nk + K;                       // [K][D]
     double *s_h = s_mu + K * D;                    // [K][D] 1 / (2 sigma^2)
     double *s_sg = s_h + K * D;                    // [K][D]
-    double *s_g = s_sg + K * D;                    // [K][64]  log densities -> exponentials -> responsibilities
-    double *s_pm = s_g + K * EMF_FRAMES;           // [4][64]  the four waves' maxima, then their sums
-    double *s_ll = s_pm + 4 * EMF_FRAMES;          // [64]
-    double *s_tot = s_ll + EMF_FRAMES;             // [E]      the grid's sums of an iteration
-    float *s_x = reinterpret_cast<float *>(s_tot + E);              // [64][D + 1]
+    double *s_g = s_sg + K * D;                    // [K][FR]  log densities -> exponentials -> responsibilities
+    double *s_pm = s_g + K * FR;                   // [NG][FR] the groups' maxima, then their sums
+    double *s_ll = s_pm + EMF_THREADS;             // [FR]
+    double *s_tot = s_ll + FR;                     // [E]      the grid's sums of an iteration
+    double *s_seg = s_tot + E;                     // [R][S][2] the segments' sums of a role
+    float *s_x = reinterpret_cast<float *>(s_seg + 2 * R * S);      // [FR][D + 1]
     const int XS = D + 1;
 
-    const int tid = threadIdx.x, f = tid & 63, g = tid >> 6;
+    const int tid = threadIdx.x, f = tid & (FR - 1), g = tid / FR, lane = tid & 63;
     const int G = gridDim.x, wg = blockIdx.x;
-    const int n_chunks = (n + EMF_FRAMES - 1) / EMF_FRAMES;
-    const int R = K * (D + 1);                     // roles of the sums: (k, d < D) both moments, (k, D) N_k
+    const int f0 = wg * FR;                        // (one chunk per workgroup: it stays in LDS for the whole fit)
+    const bool valid = f0 + f < n;
 
     for (int i = tid; i < K; i += EMF_THREADS) s_w[i] = a.init[i];
     for (int i = tid; i < K * D; i += EMF_THREADS) {
         s_mu[i] = a.init[K + i];
         s_sg[i] = a.init[K + K * D + i];
+    }
+    for (int i = tid; i < FR * D; i += EMF_THREADS) {
+        const int fr = i / D, d = i - fr * D;
+        s_x[fr * XS + d] = f0 + fr < n ? a.X[(size_t)(f0 + fr) * D + d] : 0.f;
     }
     __syncthreads();
     auto derive = [&]() {                           // (a barrier in front of it; s_g is free between two E-steps)
@@ -144,7 +156,6 @@ void em_small_fit_kernel(const EmSmallArgs a) {
     __syncthreads();
 
     const bool redundant = (long)G * E <= 48 * 1024;
-    const bool one_chunk = n_chunks <= G;
     unsigned arrivals = 0;
     double last_ll = -DBL_MAX;
     int done = a.nr_iter, flagged = 0;
@@ -153,107 +164,99 @@ void em_small_fit_kernel(const EmSmallArgs a) {
         if (ll_only && ((a.nr_iter - 1) & 1) == 0) break;
 
         // ---- E-step over this workgroup's frames ----
-        double m1[EMF_MAX_ROLES], m2[EMF_MAX_ROLES];
-#pragma unroll
-        for (int j = 0; j < EMF_MAX_ROLES; j++) m1[j] = m2[j] = 0.0;
         double ll_part = 0.0;
         int bad = 0;
-        for (int c = wg; c < n_chunks; c += G) {
-            const int f0 = c * EMF_FRAMES;
-            __syncthreads();                        // the chunk before is done with s_x / s_g
-            if (!(one_chunk && it > 0)) {           // (a workgroup with ONE chunk keeps it in LDS for the whole fit)
-                for (int i = tid; i < EMF_FRAMES * D; i += EMF_THREADS) {
-                    const int fr = i / D, d = i - fr * D;
-                    s_x[fr * XS + d] = f0 + fr < n ? a.X[(size_t)(f0 + fr) * D + d] : 0.f;
-                }
-                __syncthreads();
-            }
-            const bool valid = f0 + f < n;
-            // log densities of this wave's mixtures (k = g, g + 4, ...) for frame f
+        {
+            // log densities of this group's mixtures (k = g, g + NG, ...) for frame f
             double pmax = -__builtin_inf();
-            for (int k = g; k < K; k += 4) {
+            for (int k = g; k < K; k += NG) {
                 double lp = s_c[k];
                 const double *mu = s_mu + k * D, *h = s_h + k * D;
                 for (int d = 0; d < D; d++) {
                     const double t = (double)s_x[f * XS + d] - mu[d];
                     lp = fma(-(t * t), h[d], lp);
                 }
-                s_g[k * EMF_FRAMES + f] = lp;
+                s_g[k * FR + f] = lp;
                 if (lp >= EMF_MINLOG) pmax = fmax(pmax, lp);
                 if (valid && !(lp == lp)) bad = 1;                 // NaN (a non-finite input or parameter)
             }
-            s_pm[g * EMF_FRAMES + f] = pmax;
+            s_pm[g * FR + f] = pmax;
             __syncthreads();
-            const double m = fmax(fmax(s_pm[f], s_pm[EMF_FRAMES + f]), fmax(s_pm[2 * EMF_FRAMES + f], s_pm[3 * EMF_FRAMES + f]));
+            double m = s_pm[f];
+            for (int gg = 1; gg < NG; gg++) m = fmax(m, s_pm[gg * FR + f]);
             const bool live = m >= EMF_MINLOG;                     // some term survives (gmm.cc:482-498)
             __syncthreads();                                       // (s_pm is rewritten)
             double psum = 0.0;
-            for (int k = g; k < K; k += 4) {
-                const double lp = s_g[k * EMF_FRAMES + f];
+            for (int k = g; k < K; k += NG) {
+                const double lp = s_g[k * FR + f];
                 const double e = live && lp >= EMF_MINLOG ? exp(lp - m) : 0.0;
-                s_g[k * EMF_FRAMES + f] = e;
+                s_g[k * FR + f] = e;
                 psum += e;
             }
-            s_pm[g * EMF_FRAMES + f] = psum;
+            s_pm[g * FR + f] = psum;
             __syncthreads();
-            const double s = ((s_pm[f] + s_pm[EMF_FRAMES + f]) + s_pm[2 * EMF_FRAMES + f]) + s_pm[3 * EMF_FRAMES + f];
+            double s = s_pm[f];
+            for (int gg = 1; gg < NG; gg++) s += s_pm[gg * FR + f];                // (the groups in order)
             const double r = live && valid ? 1.0 / s : 0.0;
-            for (int k = g; k < K; k += 4) s_g[k * EMF_FRAMES + f] *= r;
+            for (int k = g; k < K; k += NG) s_g[k * FR + f] *= r;
             if (g == 0) {
                 s_ll[f] = valid ? (live ? m + log(s) : EMF_LN_1E_15) : 0.0;
                 if (valid && live && m < EMF_BAND) bad = 1;
             }
             __syncthreads();
-            if (g == 0) ll_part += wave_sum_f64(s_ll[f]);          // (fixed order, wave_ops.hpp; every lane of wave 0 holds it)
+            if (tid < 64)                                           // wave 0: the frames' values 64 at a time (fixed order, wave_ops.hpp)
+                for (int q = 0; q < FR; q += 64) ll_part += wave_sum_f64(s_ll[q + lane]);
             if (!ll_only) {
+                // a role's sweep over the frames, cut into S segments on S threads (16 x 13 = 224 roles leave most of 1024 threads
+                // idle otherwise); within a segment four running sums per moment (frames i = q mod 4): short chains, a fixed order
+                const int L = FR / S;
+                for (int item = tid; item < R * S; item += EMF_THREADS) {
+                    const int role = item % R, seg = item / R;
+                    const int k = role / (D + 1), d = role - k * (D + 1);
+                    const double *gam = s_g + k * FR + seg * L;
+                    double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
+                    if (d < D) {
+                        const double mu = s_mu[k * D + d];
+                        const float *xs = s_x + (seg * L) * XS + d;
+                        for (int i = 0; i < L; i += 4) {
 #pragma unroll
-                for (int j = 0; j < EMF_MAX_ROLES; j++) {
-                    const int role = tid + j * EMF_THREADS;
-                    if (role < R) {
-                        const int k = role / (D + 1), d = role - k * (D + 1);
-                        const double *gam = s_g + k * EMF_FRAMES;
-                        // four running sums per moment (frames i = q mod 4), added up in a fixed order: a chain of 16 instead of 64
-                        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
-                        if (d < D) {
-                            const double mu = s_mu[k * D + d];
-                            for (int i = 0; i < EMF_FRAMES; i += 4) {
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const double dv = (double)s_x[(i + q) * XS + d] - mu;
-                                    const double gd = gam[i + q] * dv;
-                                    p1[q] += gd;
-                                    p2[q] = fma(gd, dv, p2[q]);
-                                }
-                            }
-                        } else {
-                            for (int i = 0; i < EMF_FRAMES; i += 4) {
-#pragma unroll
-                                for (int q = 0; q < 4; q++) p1[q] += gam[i + q];
+                            for (int q = 0; q < 4; q++) {
+                                const double dv = (double)xs[(i + q) * XS] - mu;
+                                const double gd = gam[i + q] * dv;
+                                p1[q] += gd;
+                                p2[q] = fma(gd, dv, p2[q]);
                             }
                         }
-                        const double a1 = m1[j] + ((p1[0] + p1[1]) + (p1[2] + p1[3])), a2 = m2[j] + ((p2[0] + p2[1]) + (p2[2] + p2[3]));
-                        m1[j] = a1;
-                        m2[j] = a2;
+                    } else {
+                        for (int i = 0; i < L; i += 4) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) p1[q] += gam[i + q];
+                        }
                     }
+                    s_seg[(role * S + seg) * 2] = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+                    s_seg[(role * S + seg) * 2 + 1] = (p2[0] + p2[1]) + (p2[2] + p2[3]);
                 }
             }
         }
-        // ---- this workgroup's sums out ([entry][workgroup]: a reader's lanes take consecutive entries' rows), everybody's in ----
+        __syncthreads();
+        // ---- this workgroup's sums out ([entry][workgroup]: a reader's loads take one entry's row), everybody's in ----
         {
             double *mine = a.partials + wg;
-#pragma unroll
-            for (int j = 0; j < EMF_MAX_ROLES; j++) {
-                const int role = tid + j * EMF_THREADS;
-                if (role < R) {
+            if (!ll_only)
+                for (int role = tid; role < R; role += EMF_THREADS) {
                     const int k = role / (D + 1), d = role - k * (D + 1);
+                    double m1 = 0.0, m2 = 0.0;
+                    for (int seg = 0; seg < S; seg++) {                             // (the segments in order)
+                        m1 += s_seg[(role * S + seg) * 2];
+                        m2 += s_seg[(role * S + seg) * 2 + 1];
+                    }
                     if (d < D) {
-                        mine[(size_t)(k * REC + d) * G] = m1[j];
-                        mine[(size_t)(k * REC + D + d) * G] = m2[j];
+                        mine[(size_t)(k * REC + d) * G] = m1;
+                        mine[(size_t)(k * REC + D + d) * G] = m2;
                     } else {
-                        mine[(size_t)(k * REC + 2 * D) * G] = m1[j];
+                        mine[(size_t)(k * REC + 2 * D) * G] = m1;
                     }
                 }
-            }
             if (tid == 0) mine[(size_t)(K * REC) * G] = ll_part;
             const int any_bad = __syncthreads_or(bad);
             if (tid == 0) mine[(size_t)(K * REC + 1) * G] = any_bad ? 1.0 : 0.0;
@@ -319,7 +322,7 @@ void em_small_fit_kernel(const EmSmallArgs a) {
         }
         __syncthreads();
         derive();
-        // (the barrier at the head of the next E-step's first chunk publishes s_h / s_c)
+        __syncthreads();                                            // s_h / s_c for the next E-step; derive() is done with s_g
     }
 
     if (wg == 0) {
@@ -345,13 +348,32 @@ struct EmSmallWorkspace {
 
 }  // namespace
 
-size_t em_small_lds_bytes(int K, int D) {
-    return (size_t)(3 * K + 3 * K * D + K * EMF_FRAMES + 5 * EMF_FRAMES + K * (2 * D + 1) + 2) * sizeof(double) + (size_t)EMF_FRAMES * (D + 1) * sizeof(float);
+// frames per workgroup, segments of a role's sweep, LDS bytes.  The fewer workgroups meet at the barrier the cheaper the iteration
+// (~0.3 us each) and the longer a workgroup's own arithmetic: 16 x 13 on 2998 frames 26.8 us per iteration at 64 frames per workgroup,
+// 19.5 at 128, 21.5 at 256 -- 128 where the LDS fits and 64 frames would not do with as few workgroups.
+struct EmSmallShape {
+    int fr, seg, grid;
+    size_t lds;
+};
+static EmSmallShape em_small_shape(int K, int D, long n) {
+    EmSmallShape best{0, 1, 0, 0};
+    const int R = K * (D + 1);
+    for (int fr : {128, 64}) {
+        if (fr > 64 && (n + fr / 2 - 1) / (fr / 2) == (n + fr - 1) / fr) continue;      // (half the frames: as many workgroups)
+        int seg = 1;
+        while (seg * 2 <= fr / 64 && R * seg * 2 <= EMF_THREADS) seg *= 2;
+        const size_t lds = (size_t)(3 * K + 3 * K * D + K * fr + EMF_THREADS + fr + K * (2 * D + 1) + 2 + 2 * R * seg) * sizeof(double) +
+                           (size_t)fr * (D + 1) * sizeof(float);
+        if (lds > 150 * 1024) continue;
+        best = {fr, seg, (int)((n + fr - 1) / fr), lds};
+        break;
+    }
+    return best;
 }
 
 bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
     return K >= 1 && K <= EMF_MAX_K && dim >= 1 && dim <= EMF_MAX_D && n >= 1 &&
-           n <= EMF_MAX_FRAMES && param.nr_iteration >= 1 && param.verbosity < 2;
+           n <= EMF_MAX_FRAMES && em_small_shape(K, dim, n).grid >= 1 && em_small_shape(K, dim, n).grid <= ctx().n_cu && param.nr_iteration >= 1 && param.verbosity < 2;
 }
 
 // The fit of `gmm` (its parameters are the start) on the n resident frames dX.  true: done -- gmm holds the result, *iterations the
@@ -359,8 +381,8 @@ bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
 bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations) {
     const int K = gmm.nr_mixtures, KD = K * dim;
     auto &w = per_device<EmSmallWorkspace>();
-    const int n_chunks = (int)((n + EMF_FRAMES - 1) / EMF_FRAMES);
-    const int grid = std::min(n_chunks, ctx().n_cu);
+    const EmSmallShape shape = em_small_shape(K, dim, n);
+    const int grid = shape.grid;
     const int E = K * (2 * dim + 1) + 2;
     const int nit = param.nr_iteration;
 
@@ -387,6 +409,8 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     a.n = (int)n;
     a.dim = dim;
     a.K = K;
+    a.fr = shape.fr;
+    a.seg = shape.seg;
     a.nr_iter = nit;
     a.map = ubm ? 1 : 0;
     a.threshold = param.threshold;
@@ -400,7 +424,7 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     a.result = w.result.p;
     a.barrier = reinterpret_cast<unsigned *>(w.result.p + 32);
     void *args[] = {&a};
-    const size_t lds = em_small_lds_bytes(K, dim);
+    const size_t lds = shape.lds;
     if (lds > 64 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&em_small_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const hipError_t launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&em_small_fit_kernel), dim3((unsigned)grid),

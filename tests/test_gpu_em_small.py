@@ -115,3 +115,36 @@ def test_whole_fit_same_bits_on_every_run_and_limits(built_lib):
         X, _ = _data(rng, n, K, D)
         it, _, eng = _fit(0, X, K, 2, 0.0)
         assert it == 2 and eng in (1, 2, 3), (n, K, D, eng)
+
+
+def test_whole_fit_progress_lines_and_the_legacy_symbol(built_lib, tmp_path):
+    """verbosity 1 prints `iter i: ll x` after every second iteration (gmm.cc:641): the whole-fit kernel keeps the totals its
+    stop rule saw and the host prints them afterwards -- the same iterations, the same totals to 1e-6 relative, as an
+    iteration per launch prints while it runs.  Through the legacy symbol train_model (double**, pygmm.hh:33) in a fresh
+    process, as the reference's binding calls it."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(17)
+    X, _ = _data(rng, 1500, 8, 13)
+    xp = str(tmp_path / "X.npy")
+    np.save(xp, X)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "from speaker_recognition_amd import _lib\n"
+            "from speaker_recognition_amd.pygmm import GMM\n"
+            "_lib.set_option('em_stats_engine', int(sys.argv[2]))\n"
+            "g = GMM(8, nr_iteration=40, verbosity=1, seed=5)\n"
+            "it = g.fit(np.load(sys.argv[1]))\n"
+            "sys.stdout.flush(); print('done', it, _lib.last_em_stats_engine())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for eng in (0, 3):
+        r = subprocess.run([sys.executable, "-c", code, xp, str(eng)], capture_output=True, text=True, check=True, timeout=300)
+        lines = r.stdout.splitlines()
+        out[eng] = ([(int(l.split()[1].rstrip(":")), float(l.split()[3])) for l in lines if l.startswith("iter ")],
+                    [l for l in lines if l.startswith("done")][0].split())
+    assert out[0][1][2] == "4" and out[3][1][2] in ("1", "2", "3")
+    assert out[0][1][1] == out[3][1][1]                                     # iterations carried out
+    assert len(out[0][0]) == len(out[3][0]) >= 1 and [i for i, _ in out[0][0]] == [i for i, _ in out[3][0]]
+    assert all(i % 2 == 1 for i, _ in out[0][0])
+    for (_, a), (_, b) in zip(out[0][0], out[3][0]):
+        assert abs(a - b) <= 1e-6 * abs(b), (a, b)
