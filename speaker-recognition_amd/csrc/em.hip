@@ -752,6 +752,9 @@ void init_gmm_like_reference(GMM &g, const float *X, long n, int dim, const Para
 // em_small.hip
 bool em_small_eligible(int K, int dim, long n, const Parameter &param);
 bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations);
+// em_f64.hip
+bool em_f64_eligible(int K, int dim, long n, const Parameter &param);
+bool train_em_f64(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations);
 void burn_reference_rand(int count);
 
 // The model of one EM / MAP iteration as a set: the vector-ALU layout (the statistics kernels' records) and -- round 4 -- the
@@ -874,6 +877,14 @@ int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Pa
         int iterations = 0;
         if (train_em_small(gmm, ubm, feat.data.p, n, dim, param, relevance, &iterations)) {
             g_last_stats_engine.store(4);
+            return iterations;
+        }
+    } else if (em_stats_engine_option() == 0 && !reference_side_effects_option() && em_f64_eligible(K, dim, n, param)) {
+        // short data, a model of any size (a speaker's MAP enrolment from a large UBM): float64 iterations on the device, nothing
+        // packed, nothing redone on the host (em_f64.hip; last_em_stats_engine() = 5)
+        int iterations = 0;
+        if (train_em_f64(gmm, ubm, feat.data.p, n, dim, param, relevance, &iterations)) {
+            g_last_stats_engine.store(5);
             return iterations;
         }
     }
