@@ -318,7 +318,8 @@ int sr_mfma_streamed_probe(double ms_target, double *tflops, double *mhz);
 const char *sr_last_score_kernel(void);
 /* Which statistics kernel the last EM / MAP iteration of this process ran: 0 none yet, 1 vector ALU, 2 fp64 matrix cores,
  * 3 fp64 matrix cores with the responsibilities on the 16-bit matrix cores (round 4; csrc/em.hip), 4 the whole fit in one launch
- * (speaker-sized models: <= 32 mixtures x <= 40 dims, <= 8192 frames; csrc/em_small.hip).  Tests and benches. */
+ * (speaker-sized models: <= 32 mixtures x <= 40 dims, <= 8192 frames; csrc/em_small.hip), 5 float64 iterations on the device (short
+ * data, <= 8192 frames x <= 64 dims, a model of any size: MAP enrolment from a large UBM; csrc/em_f64.hip).  Tests and benches. */
 int sr_last_em_stats_engine(void);
 /* The first `count` values of the random stream train_model / load draw from when no seed is given: glibc's rand()
  * from its default seed, restated inside the library (the reference draws its initialisation from libc rand():

@@ -810,9 +810,9 @@ struct EmWorkspace {
     PinnedBuf<double> h_stats;        // where an iteration's sums land on the host
 };
 static int &em_stats_engine_option() {
-    // 0 = automatic (a speaker-sized fit whole in one launch, em_small.hip; else fp64 matrix cores where instantiated, responsibilities
+    // 0 = automatic (a speaker-sized fit whole in one launch, em_small.hip; short data through em_f64.hip; else fp64 matrix cores where instantiated, responsibilities
     // on the 16-bit ones where the model allows), 1 = the vector-ALU form always, 2 = fp64 matrix cores with the responsibilities on the
-    // vector ALU (round 3's), 3 = automatic among the iteration-at-a-time engines (no whole-fit launch)
+    // vector ALU (round 3's), 3 = automatic among the iteration-at-a-time engines (no whole-fit launch, no float64 iteration engine)
     static int v = 0;
     return v;
 }
