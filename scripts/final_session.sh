@@ -16,6 +16,8 @@ REHEARSE_TIMEOUT=900 timeout 1000 bash scripts/rehearse_n8.sh torchrun < /dev/nu
   echo "== scripts/debug/point256_wall.py"; timeout 120 python scripts/debug/point256_wall.py < /dev/null 2>&1 | tail -2
   echo "== scripts/debug/cfg0_train_trace.py"; timeout 120 python scripts/debug/cfg0_train_trace.py < /dev/null 2>&1 | grep -E "fit|asarray"
   echo "== scripts/debug/map_default_trace.py 512 / 2048"; for k in 512 2048; do timeout 120 python scripts/debug/map_default_trace.py $k < /dev/null 2>&1 | grep "^MAP"; done
+  echo "== scripts/debug/em_small_time.py"; timeout 120 python scripts/debug/em_small_time.py < /dev/null 2>&1 | tail -4
+  echo "== scripts/debug/em_f64_check.py"; timeout 300 python scripts/debug/em_f64_check.py < /dev/null 2>&1 | grep -E "^MAP K|^EM n|findings"
   echo "== scripts/time_wide_rows.py"; timeout 300 python scripts/time_wide_rows.py < /dev/null 2>&1 | tail -6
 } > $O/${R}_session_notes_raw.txt 2>&1
 cut -c1-400 $O/${R}_session_notes_raw.txt
