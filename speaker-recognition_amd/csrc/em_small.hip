@@ -59,7 +59,7 @@ struct EmSmallArgs {
     int map;                   // means only (gmmubm.cc:53-74)
     double threshold, min_sigma, relevance;
     const double *init;        // [K] weights, [K*D] means, [K*D] sigmas, (map) [K*D] the UBM's means
-    double *partials;          // [grid][E]
+    double *partials;          // [E][grid]  (an entry's row: the workgroups side by side)
     double *totals;            // [E]
     double *out;               // [K] weights, [K*D] means, [K*D] sigmas
     double *ll_hist;           // [nr_iter]: total log-likelihood after iteration i (odd i only; NaN elsewhere)
