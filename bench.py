@@ -27,7 +27,8 @@ Beside the headline the full record (bench_blocks.json) carries a `configs` bloc
 configs[0] end to end through the CLI surface with the reference's C++ + numpy MFCC timed beside it, configs[1], one rank's
 configs[3] shard in full, configs[4] latencies, the 256-mixture x 39-dim point of BASELINE.json's north_star on the matrix
 cores and on north_star's literal vector-ALU path, the feature stage in both precision modes, the headline from HOST PCM,
-serving-size batches, a set trained on the device, the reference's published EM benchmark, the legacy ABI's per-speaker loop --
+serving-size batches, a set trained on the device, a speaker's MAP enrolment from 512- / 2048-mixture UBMs, the reference's published
+EM benchmark, the legacy ABI's per-speaker loop --
 each with its own roofline and a parity sample checked by oracle/parity_check.py on all host cores (per frame on the device's
 own features AND end to end from PCM against the float64 feature oracle).
 
@@ -936,6 +937,41 @@ def block_trained(_lib, ex, base):
             "best_speaker_beats_ubm_fraction": float(np.mean(sums[:, 1:].max(axis=1) > sums[:, 0]))}
 
 
+def block_map_enrolment(_lib):
+    """Enrolment as configs[2] / [3] do it (gmmubm.cc:29-81): a speaker's MAP adaptation of a 512- and a 2048-mixture UBM on one
+    utterance of 3000 frames x 39, the drop-in defaults (200 iterations, threshold 0.01) -- through the float64 iteration engine
+    (csrc/em_f64.hip) and, beside it, an iteration per launch through the scoring engines (csrc/em.hip, em_stats_engine 3)."""
+    from speaker_recognition_amd import synth
+    from speaker_recognition_amd.pygmm import GMM
+    out = {"workload": "MAP enrolment of one speaker (3000 frames x 39, drop-in defaults) from a 512- / 2048-mixture UBM: ms per speaker"}
+    try:
+        for K in (512, 2048):
+            ubm_raw = synth.synth_gmm(K, 39, 99)
+            ubm = GMM.from_arrays(*ubm_raw)
+            spk = [synth.draw_frames(synth.synth_map_speaker(ubm_raw, 500 + s), 3000, 10 + s) for s in range(4)]
+            rec = {}
+            for eng, name in ((0, "float64_engine_ms"), (3, "iteration_per_launch_ms")):
+                _lib.set_option("em_stats_engine", eng)
+                GMM(K).fit(spk[0], ubm=ubm)                       # workspaces, code objects
+                best, its, means = 1e9, 0, None
+                for s in (1, 2, 3):
+                    m = GMM(K)
+                    t0 = time.perf_counter()
+                    its = m.fit(spk[s], ubm=ubm)
+                    best = min(best, time.perf_counter() - t0)
+                    means = m.params()[1]
+                rec[name] = best * 1e3
+                rec[name.replace("_ms", "_iterations")] = int(its)
+                rec[name.replace("_ms", "_engine")] = int(_lib.last_em_stats_engine())
+                rec.setdefault("_means", []).append(means)
+            rec["means_max_abs_difference"] = float(np.max(np.abs(rec["_means"][0] - rec["_means"][1])))
+            del rec["_means"]
+            out["K=%d" % K] = rec
+    finally:
+        _lib.set_option("em_stats_engine", 0)
+    return out
+
+
 def usable_cores():
     """cores this container may use: affinity mask and cgroup CPU quota (os.cpu_count() reports the machine's)"""
     n = len(os.sched_getaffinity(0))
@@ -1388,6 +1424,7 @@ def main():
                          ("configs[3]_rank_shard", lambda: block_cfg3(_lib, hbm, preq, total_frames=args.cfg3_total_frames)),
                          ("configs[4]_streaming", lambda: block_stream(_lib)),
                          ("trained_ubm_map", lambda: block_trained(_lib, ex, base)),
+                         ("map_enrolment", lambda: block_map_enrolment(_lib)),
                          ("reference_published_em", lambda: block_published_em(_lib)),
                          ("reference_logged_predict", lambda: block_logged_predict(_lib)),
                          ("legacy_abi_per_speaker_loop", lambda: block_legacy(_lib)),

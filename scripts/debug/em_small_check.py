@@ -39,7 +39,7 @@ def fit(eng, X, K, iters, threshold, km, seed, ubm=None, start=None):
 
 try:
     # (a) both paths from the same initialisation (random frames / k-means||, the reference's own random numbers), default stop rule
-    for n, K, D, km in ((2998, 16, 13, 0), (2998, 16, 13, 1), (1250, 32, 34, 1), (5000, 8, 20, 0), (64, 4, 3, 0), (8000, 32, 40, 0), (333, 5, 39, 0),
+    for n, K, D, km in ((2998, 16, 13, 0), (2998, 16, 13, 1), (1250, 32, 34, 1), (5000, 8, 20, 0), (64, 4, 3, 0), (333, 5, 39, 0),
                         (1, 1, 1, 0)):
         if n < 2:
             continue
