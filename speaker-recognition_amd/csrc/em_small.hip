@@ -4,7 +4,7 @@
 // iterations (gmm.cc:600-651) of a few microseconds of arithmetic each.  Iteration at a time (em.hip: pack, upload, score, statistics,
 // sums back to the host, M-step there, every second iteration a pass for the total log-likelihood) an iteration costs ~85 us of launches,
 // small copies and host waits around ~25 us of kernels: 17-21 ms per fit, 96 % of configs[0]'s enrol + predict time.
-// Here the loop of GMMTrainerBaseline::train (gmm.cc:581-653) runs ON the device: one resident grid, a workgroup of 1024 threads per 64
+// Here the loop of GMMTrainerBaseline::train (gmm.cc:581-653) runs ON the device: one grid that is resident as a whole, a workgroup of 1024 threads per 64
 // or 128 frames (kept in its LDS for the whole fit, beside the model), ONE grid-wide barrier per iteration behind which every workgroup
 // adds up everybody's sums itself (two, with the addition shared out, when workgroups x sums is large), the host waits once.  16 x 13 on
 // 2998 frames: 19.6 us per iteration (96 iteration at a time), a 200-iteration fit 4.05 ms (17.8); what an iteration costs is its trips
@@ -34,6 +34,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -46,6 +47,7 @@ constexpr int EMF_MAX_K = 32, EMF_MAX_D = 40;
 // the iteration's price grows with the workgroups that meet at its barriers (12 us at one, 27 at 47, 46 at 128, 16 x 13); from ~10 k
 // frames on an iteration per launch costs the same (20 000 x 32 x 40: 30 ms either way)
 constexpr long EMF_MAX_FRAMES = 8192;
+constexpr unsigned EMF_POLL_LIMIT = 250000;       // polls of ~1.2 us (a sleep and a device-scope load) before a workgroup gives the grid up
 constexpr double EMF_MINLOG = -708.396418532264;  // ln DBL_MIN (fastexp.cc:93,105)
 constexpr double EMF_BAND = -598.0;               // a live frame below this goes to the path that restates the partial-product flushes
 constexpr double EMF_LN_1E_15 = -34.538776394910684;
@@ -57,14 +59,15 @@ struct EmSmallArgs {
     int fr, seg;               // frames per workgroup (64 / 128), segments of a role's sweep (a power of two, fr / seg a multiple of 4)
     int nr_iter;
     int map;                   // means only (gmmubm.cc:53-74)
+    int test_absent;           // test hook (SR_EMF_TEST_ABSENT): see the barrier
     double threshold, min_sigma, relevance;
     const double *init;        // [K] weights, [K*D] means, [K*D] sigmas, (map) [K*D] the UBM's means
     double *partials;          // [E][grid]  (an entry's row: the workgroups side by side)
     double *totals;            // [E]
     double *out;               // [K] weights, [K*D] means, [K*D] sigmas
     double *ll_hist;           // [nr_iter]: total log-likelihood after iteration i (odd i only; NaN elsewhere)
-    int *result;               // [0] iterations carried out, [1] flag (1: left to the other path)
-    unsigned *barrier;         // grid barrier counter (0 at launch)
+    int *result;               // [0] iterations carried out, [1] flag (1: frames left to the other path, 2: the grid gave up at a barrier)
+    unsigned *barrier;         // grid barrier counter, [32] the abort word (0 at launch)
 };
 
 // every workgroup of the (resident) grid arrives; `round` = 1, 2, ... over the barriers of the launch.  Every thread releases its own
@@ -73,19 +76,42 @@ struct EmSmallArgs {
 // on 47 workgroups / 32 x 40 on 256): two full fences and acquiring polls 49 / 647 us per iteration; release + acquire fences and relaxed
 // polls with a longer sleep 38 / 222 (the pollers' traffic on the one address was most of it).  Arrivals dealt to eight group counters on
 // lines of their own: 27.0 -> 26.1 / 89 -> 80, not kept.  The device-scope fences by ONE thread (below): 24.7 -> 21.5 with 16 waves.
-__device__ __forceinline__ void grid_barrier(unsigned *counter, unsigned round) {
+// Returns false when the grid has to give up: the launch is an ordinary one (a cooperative launch -- the runtime's promise that every
+// workgroup is on the chip at once -- makes rocprofv3 crash in the traced process's exit(); measured, 1 October), the grid is at most one
+// workgroup per two CUs, and what a promise would rule out -- three or more processes each holding part of the chip with part of such
+// a grid, every one waiting for workgroups that cannot start -- ends here instead: a workgroup that has polled for ~0.3 s raises the
+// abort word (counter[32]), everybody who polls sees it within 64 polls, the kernel returns, the host takes the other path.
+__device__ __forceinline__ bool grid_barrier(unsigned *counter, unsigned round, bool arrive = true) {
+    __shared__ int s_ok;
     // every wave's stores are in the L2 (a workgroup-scope release waits for them) before the workgroup's barrier; ONE thread then
     // writes the L2's dirty lines back, arrives, polls and invalidates (the device-scope fences cost per wave that executes them)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (released by the fence above)
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * gridDim.x) __builtin_amdgcn_s_sleep(8);
+        if (arrive) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (released by the fence above)
+        unsigned polls = 0;
+        int ok = 1;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round * gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++polls & 63u) == 0u) {
+                if (__hip_atomic_load(counter + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    ok = 0;
+                    break;
+                }
+                if (polls > EMF_POLL_LIMIT) {
+                    __hip_atomic_store(counter + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return s_ok != 0;
 }
 
 // sum over the grid's workgroups of entry e: partials[e][0 .. G), in workgroup order, 16 loads in flight at a time (one after
@@ -261,14 +287,22 @@ void em_small_fit_kernel(const EmSmallArgs a) {
             const int any_bad = __syncthreads_or(bad);
             if (tid == 0) mine[(size_t)(K * REC + 1) * G] = any_bad ? 1.0 : 0.0;
         }
-        grid_barrier(a.barrier, ++arrivals);
+        // (test hook: workgroup 1 stays away from the third barrier -- what a workgroup that cannot start looks like to the others)
+        ++arrivals;
+        if (!grid_barrier(a.barrier, arrivals, !(a.test_absent && wg == 1 && arrivals == 3))) {
+            flagged = 2;
+            break;
+        }
         if (redundant) {
             // few workgroups x few entries: every workgroup adds up everything itself (G x E loads, one trip's latency) -- one
             // grid barrier per iteration
             for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = sum_partials(a.partials + (size_t)e * G, G);
         } else {
             for (int e = wg * EMF_THREADS + tid; e < E; e += G * EMF_THREADS) a.totals[e] = sum_partials(a.partials + (size_t)e * G, G);
-            grid_barrier(a.barrier, ++arrivals);
+            if (!grid_barrier(a.barrier, ++arrivals)) {
+                flagged = 2;
+                break;
+            }
             for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = a.totals[e];
         }
         __syncthreads();
@@ -341,7 +375,7 @@ void em_small_fit_kernel(const EmSmallArgs a) {
 
 struct EmSmallWorkspace {
     DevBuf<double> init, partials, totals, out;
-    DevBuf<int> result;            // [0..1] the kernel's answer, [32] the barrier's counter (a line of its own)
+    DevBuf<int> result;            // [0..1] the kernel's answer, [32] the barrier's counter, [64] its abort word (a line each)
     PinnedBuf<double> h_out;       // the model and the totals' history, one copy
     PinnedBuf<int> h_result;
 };
@@ -373,7 +407,7 @@ static EmSmallShape em_small_shape(int K, int D, long n) {
 
 bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
     return K >= 1 && K <= EMF_MAX_K && dim >= 1 && dim <= EMF_MAX_D && n >= 1 &&
-           n <= EMF_MAX_FRAMES && em_small_shape(K, dim, n).grid >= 1 && em_small_shape(K, dim, n).grid <= ctx().n_cu && param.nr_iteration >= 1 && param.verbosity < 2;
+           n <= EMF_MAX_FRAMES && em_small_shape(K, dim, n).grid >= 1 && em_small_shape(K, dim, n).grid <= ctx().n_cu / 2 && param.nr_iteration >= 1 && param.verbosity < 2;
 }
 
 // The fit of `gmm` (its parameters are the start) on the n resident frames dX.  true: done -- gmm holds the result, *iterations the
@@ -397,10 +431,10 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     w.partials.ensure((size_t)grid * E);
     w.totals.ensure((size_t)E);
     w.out.ensure((size_t)K + 2 * (size_t)KD + (size_t)nit);
-    w.result.ensure(64);
+    w.result.ensure(96);
     w.h_out.ensure((size_t)K + 2 * (size_t)KD + (size_t)nit);
     w.h_result.ensure(4);
-    SR_HIP(hipMemsetAsync(w.result.p, 0, 64 * sizeof(int), ctx().stream));
+    SR_HIP(hipMemsetAsync(w.result.p, 0, 96 * sizeof(int), ctx().stream));
     // (NaN: "no total taken after this iteration")
     SR_HIP(hipMemsetAsync(w.out.p + K + 2 * KD, 0xff, (size_t)nit * sizeof(double), ctx().stream));
 
@@ -413,6 +447,7 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     a.seg = shape.seg;
     a.nr_iter = nit;
     a.map = ubm ? 1 : 0;
+    a.test_absent = getenv("SR_EMF_TEST_ABSENT") != nullptr;
     a.threshold = param.threshold;
     a.min_sigma = std::sqrt(param.min_covar);
     a.relevance = relevance;
@@ -423,16 +458,13 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     a.ll_hist = w.out.p + K + 2 * KD;
     a.result = w.result.p;
     a.barrier = reinterpret_cast<unsigned *>(w.result.p + 32);
-    void *args[] = {&a};
     const size_t lds = shape.lds;
     if (lds > 64 * 1024)
         SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&em_small_fit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const hipError_t launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&em_small_fit_kernel), dim3((unsigned)grid),
-                                                           dim3(EMF_THREADS), args, (unsigned)lds, ctx().stream);
-    if (launched != hipSuccess) {            // (a device or runtime without cooperative launches: the other path serves; sr_last_em_stats_engine tells)
-        (void)hipGetLastError();
-        return false;
-    }
+    // an ordinary launch of <= n_cu / 2 workgroups, one per CU: they are all on the chip at once unless other processes hold most of it --
+    // and then the barrier's poll limit ends the wait (grid_barrier)
+    hipLaunchKernelGGL(em_small_fit_kernel, dim3((unsigned)grid), dim3(EMF_THREADS), lds, ctx().stream, a);
+    SR_HIP(hipGetLastError());
     w.out.download(w.h_out.p, (size_t)K + 2 * (size_t)KD + (size_t)nit);
     w.result.download(w.h_result.p, 2);
     sync_stream();
