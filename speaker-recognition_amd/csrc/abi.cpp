@@ -23,6 +23,7 @@ void reference_rand_sample(int *out, int count);
 int train_em(GMM &gmm, const GMM *ubm, const float *X, long n, int dim, const Parameter &param,
              long seed);
 void set_em_stats_engine(int v);
+void set_em_small_test_absent(int v);   // em_small.hip
 int last_em_stats_engine();
 void set_reference_side_effects(int v);
 void set_kmeans_assign_engine(int v);
@@ -881,6 +882,9 @@ int sr_set_option(const char *key, long value) {
     } else if (k == "debug_capture_delay_ms") {
         if (value < 0 || value > 1000) fail("debug_capture_delay_ms must be 0 .. 1000");
         stream_debug_capture_delay_ms().store((int)value);         // test hook (tests/test_gpu_pipeline.py)
+    } else if (k == "debug_em_small_absent_workgroup") {
+        if (value != 0 && value != 1) fail("debug_em_small_absent_workgroup must be 0 or 1");
+        set_em_small_test_absent((int)value);                       // test hook (tests/test_gpu_em_small.py): a workgroup of the whole-fit kernel stays away from a barrier
     } else if (k == "debug_helper_max_models") {
         if (value < 0) fail("debug_helper_max_models must be >= 0 (0: the default)");
         fork_proxy_set_max_models(value);                           // test hook (tests/test_gpu_fork.py): applies in the helper, where it is forwarded

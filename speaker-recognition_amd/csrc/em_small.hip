@@ -33,8 +33,8 @@
 
 #include <cfloat>
 #include <cmath>
+#include <atomic>
 #include <cstdio>
-#include <cstdlib>
 #include <limits>
 #include <vector>
 
@@ -59,7 +59,7 @@ struct EmSmallArgs {
     int fr, seg;               // frames per workgroup (64 / 128), segments of a role's sweep (a power of two, fr / seg a multiple of 4)
     int nr_iter;
     int map;                   // means only (gmmubm.cc:53-74)
-    int test_absent;           // test hook (SR_EMF_TEST_ABSENT): see the barrier
+    int test_absent;           // test hook (option debug_em_small_absent_workgroup): see the barrier
     double threshold, min_sigma, relevance;
     const double *init;        // [K] weights, [K*D] means, [K*D] sigmas, (map) [K*D] the UBM's means
     double *partials;          // [E][grid]  (an entry's row: the workgroups side by side)
@@ -373,6 +373,11 @@ void em_small_fit_kernel(const EmSmallArgs a) {
     }
 }
 
+std::atomic<int> &em_small_test_absent() {
+    static std::atomic<int> v{0};
+    return v;
+}
+
 struct EmSmallWorkspace {
     DevBuf<double> init, partials, totals, out;
     DevBuf<int> result;            // [0..1] the kernel's answer, [32] the barrier's counter, [64] its abort word (a line each)
@@ -404,6 +409,8 @@ static EmSmallShape em_small_shape(int K, int D, long n) {
     }
     return best;
 }
+
+void set_em_small_test_absent(int v) { em_small_test_absent().store(v); }
 
 bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
     return K >= 1 && K <= EMF_MAX_K && dim >= 1 && dim <= EMF_MAX_D && n >= 1 &&
@@ -447,7 +454,7 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
     a.seg = shape.seg;
     a.nr_iter = nit;
     a.map = ubm ? 1 : 0;
-    a.test_absent = getenv("SR_EMF_TEST_ABSENT") != nullptr;
+    a.test_absent = em_small_test_absent().load();
     a.threshold = param.threshold;
     a.min_sigma = std::sqrt(param.min_covar);
     a.relevance = relevance;

@@ -150,31 +150,23 @@ def test_whole_fit_progress_lines_and_the_legacy_symbol(built_lib, tmp_path):
         assert abs(a - b) <= 1e-6 * abs(b), (a, b)
 
 
-def test_whole_fit_gives_up_when_a_workgroup_never_arrives(built_lib, tmp_path):
+def test_whole_fit_gives_up_when_a_workgroup_never_arrives(built_lib):
     """The whole-fit kernel is an ordinary launch whose workgroups meet at a grid-wide barrier; should part of the grid never
     start (other processes holding the chip), the workgroups that wait give the grid up after ~0.3 s of polling and the fit
-    runs an iteration per launch instead.  Test hook SR_EMF_TEST_ABSENT: workgroup 1 stays away from the third barrier."""
-    import os
-    import subprocess
-    import sys
+    runs an iteration per launch instead.  Test hook (option debug_em_small_absent_workgroup): workgroup 1 stays away from
+    the third barrier."""
+    from speaker_recognition_amd import _lib
     rng = np.random.default_rng(19)
     X, _ = _data(rng, 1500, 8, 13)
-    xp = str(tmp_path / "X.npy")
-    np.save(xp, X)
-    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
-            "from speaker_recognition_amd import _lib\n"
-            "from speaker_recognition_amd.pygmm import GMM\n"
-            "_lib.set_option('em_stats_engine', int(sys.argv[2]))\n"
-            "g = GMM(8, nr_iteration=6, threshold=0.0, seed=5)\n"
-            "it = g.fit(np.load(sys.argv[1]))\n"
-            "np.save(sys.argv[3], np.concatenate([p.ravel() for p in g.params()]))\n"
-            "print('done', it, _lib.last_em_stats_engine())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for tag, eng, env in (("absent", 0, {"SR_EMF_TEST_ABSENT": "1"}), ("per_launch", 3, {}), ("whole", 0, {})):
-        out = str(tmp_path / (tag + ".npy"))
-        r = subprocess.run([sys.executable, "-c", code, xp, str(eng), out], capture_output=True, text=True, check=True, timeout=300,
-                           env=dict(os.environ, **env))
-        res[tag] = ([l for l in r.stdout.splitlines() if l.startswith("done")][0].split(), np.load(out))
-    assert res["whole"][0][2] == "4" and res["absent"][0][2] != "4" and res["absent"][0][2] == res["per_launch"][0][2]
-    assert res["absent"][0][1] == res["per_launch"][0][1] == "6"
-    assert np.array_equal(res["absent"][1], res["per_launch"][1])           # the other path from the start: its bits
+    whole = _fit(0, X, 8, 6, 0.0, seed=5)
+    per_launch = _fit(3, X, 8, 6, 0.0, seed=5)
+    _lib.set_option("debug_em_small_absent_workgroup", 1)
+    try:
+        absent = _fit(0, X, 8, 6, 0.0, seed=5)
+    finally:
+        _lib.set_option("debug_em_small_absent_workgroup", 0)
+    assert whole[2] == 4 and absent[2] != 4 and absent[2] == per_launch[2]
+    assert absent[0] == per_launch[0] == whole[0] == 6
+    assert all(np.array_equal(a, b) for a, b in zip(absent[1], per_launch[1]))          # the other path from the start: its bits
+    again = _fit(0, X, 8, 6, 0.0, seed=5)                                                # (the next fit is a whole one again)
+    assert again[2] == 4 and all(np.array_equal(a, b) for a, b in zip(again[1], whole[1]))
