@@ -7,7 +7,9 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=${1:-r06}; O=gpurun_out; mkdir -p $O
 export STAGE_TIMEOUT=1500
 bash scripts/gpu_session.sh ${R}f device test smoke "bench=--steps 20 --warmup 5" prof pmc
-bash scripts/gpu_session.sh ${R}g "prof=--steps 3 --warmup 1 --no-cpu-baseline --no-traffic"
+# (the whole bench under the profiler: its statistics are written ~70 s in; the traced process then may not exit -- fork helpers in the
+# profiler's signal handler -- so this stage gets its own, short limit)
+STAGE_TIMEOUT=420 bash scripts/gpu_session.sh ${R}g "prof=--steps 3 --warmup 1 --no-cpu-baseline --no-traffic"
 REHEARSE_TIMEOUT=900 timeout 1000 bash scripts/rehearse_n8.sh torchrun < /dev/null 2>&1 | tail -8 | cut -c1-1700
 {
   echo "== scripts/ab_h2s_small.py"; timeout 300 python scripts/ab_h2s_small.py < /dev/null 2>&1 | tail -12
