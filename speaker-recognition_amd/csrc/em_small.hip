@@ -32,9 +32,14 @@
 #include "../../include/pygmm_hip.h"
 
 #include <cfloat>
+#include <cerrno>
 #include <cmath>
 #include <atomic>
 #include <cstdio>
+#include <fcntl.h>
+#include <string>
+#include <sys/file.h>
+#include <unistd.h>
 #include <limits>
 #include <vector>
 
@@ -47,7 +52,7 @@ constexpr int EMF_MAX_K = 32, EMF_MAX_D = 40;
 // the iteration's price grows with the workgroups that meet at its barriers (12 us at one, 27 at 47, 46 at 128, 16 x 13); from ~10 k
 // frames on an iteration per launch costs the same (20 000 x 32 x 40: 30 ms either way)
 constexpr long EMF_MAX_FRAMES = 8192;
-constexpr unsigned EMF_POLL_LIMIT = 250000;       // polls of ~1.2 us (a sleep and a device-scope load) before a workgroup gives the grid up
+constexpr unsigned EMF_POLL_LIMIT = 60000;        // polls of ~1.5 us (a sleep and a device-scope load), ~0.1 s, before a workgroup gives the grid up
 constexpr double EMF_MINLOG = -708.396418532264;  // ln DBL_MIN (fastexp.cc:93,105)
 constexpr double EMF_BAND = -598.0;               // a live frame below this goes to the path that restates the partial-product flushes
 constexpr double EMF_LN_1E_15 = -34.538776394910684;
@@ -62,7 +67,7 @@ struct EmSmallArgs {
     int test_absent;           // test hook (option debug_em_small_absent_workgroup): see the barrier
     double threshold, min_sigma, relevance;
     const double *init;        // [K] weights, [K*D] means, [K*D] sigmas, (map) [K*D] the UBM's means
-    double *partials;          // [E][grid]  (an entry's row: the workgroups side by side)
+    double *partials;          // [2][E][grid]  (by the iteration's parity; an entry's row: the workgroups side by side)
     double *totals;            // [E]
     double *out;               // [K] weights, [K*D] means, [K*D] sigmas
     double *ll_hist;           // [nr_iter]: total log-likelihood after iteration i (odd i only; NaN elsewhere)
@@ -79,7 +84,7 @@ struct EmSmallArgs {
 // Returns false when the grid has to give up: the launch is an ordinary one (a cooperative launch -- the runtime's promise that every
 // workgroup is on the chip at once -- makes rocprofv3 crash in the traced process's exit(); measured, 1 October), the grid is at most one
 // workgroup per two CUs, and what a promise would rule out -- three or more processes each holding part of the chip with part of such
-// a grid, every one waiting for workgroups that cannot start -- ends here instead: a workgroup that has polled for ~0.3 s raises the
+// a grid, every one waiting for workgroups that cannot start -- ends here instead (and DeviceFitLock below keeps whole-fit grids from meeting each other at all): a workgroup that has polled for ~0.1 s raises the
 // abort word (counter[32]), everybody who polls sees it within 64 polls, the kernel returns, the host takes the other path.
 __device__ __forceinline__ bool grid_barrier(unsigned *counter, unsigned round, bool arrive = true) {
     __shared__ int s_ok;
@@ -267,7 +272,9 @@ void em_small_fit_kernel(const EmSmallArgs a) {
         __syncthreads();
         // ---- this workgroup's sums out ([entry][workgroup]: a reader's loads take one entry's row), everybody's in ----
         {
-            double *mine = a.partials + wg;
+            // (two sets of partial sums, by the iteration's parity: with ONE barrier per iteration a workgroup that is still adding up
+            // iteration t's sums -- descheduled for another process's kernel, say -- must not see a faster one's sums of t + 1)
+            double *mine = a.partials + (size_t)(it & 1) * E * G + wg;
             if (!ll_only)
                 for (int role = tid; role < R; role += EMF_THREADS) {
                     const int k = role / (D + 1), d = role - k * (D + 1);
@@ -296,9 +303,10 @@ void em_small_fit_kernel(const EmSmallArgs a) {
         if (redundant) {
             // few workgroups x few entries: every workgroup adds up everything itself (G x E loads, one trip's latency) -- one
             // grid barrier per iteration
-            for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = sum_partials(a.partials + (size_t)e * G, G);
+            for (int e = tid; e < E; e += EMF_THREADS) s_tot[e] = sum_partials(a.partials + (size_t)(it & 1) * E * G + (size_t)e * G, G);
         } else {
-            for (int e = wg * EMF_THREADS + tid; e < E; e += G * EMF_THREADS) a.totals[e] = sum_partials(a.partials + (size_t)e * G, G);
+            for (int e = wg * EMF_THREADS + tid; e < E; e += G * EMF_THREADS)
+                a.totals[e] = sum_partials(a.partials + (size_t)(it & 1) * E * G + (size_t)e * G, G);
             if (!grid_barrier(a.barrier, ++arrivals)) {
                 flagged = 2;
                 break;
@@ -373,6 +381,40 @@ void em_small_fit_kernel(const EmSmallArgs a) {
     }
 }
 
+// ONE whole-fit grid on a device at a time, across processes.  Its workgroups meet at a barrier, so a grid is only safe while all of it
+// fits the chip beside whatever else runs -- and a workgroup of 16 waves x 128 registers fills a CU: eleven processes enrolling at once
+// (264 workgroups for 256 CUs) could leave every grid waiting for workgroups that cannot start, each round ending only at the poll limit
+// with every other kernel of those processes queued behind the spinning ones.  An advisory lock on a per-device file (released by the
+// kernel should the holder die) serialises the launches: a fit holds the chip for its few milliseconds
+// (scripts/debug/em_small_stress.py).  No lock to be had: no whole-fit launch.
+struct DeviceFitLock {
+    int fd = -1;
+    bool held = false;
+    explicit DeviceFitLock(int device) {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        for (char *c = bus; *c; c++)
+            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        const std::string path = "/dev/shm/sr_whole_fit_" + std::to_string((unsigned)getuid()) + "_" + bus + ".lock";
+        fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (fd < 0) return;
+        int rc;
+        do rc = flock(fd, LOCK_EX); while (rc != 0 && errno == EINTR);
+        held = rc == 0;
+    }
+    ~DeviceFitLock() {
+        if (fd >= 0) {
+            if (held) (void)flock(fd, LOCK_UN);
+            (void)close(fd);
+        }
+    }
+    DeviceFitLock(const DeviceFitLock &) = delete;
+    DeviceFitLock &operator=(const DeviceFitLock &) = delete;
+};
+
 std::atomic<int> &em_small_test_absent() {
     static std::atomic<int> v{0};
     return v;
@@ -421,6 +463,10 @@ bool em_small_eligible(int K, int dim, long n, const Parameter &param) {
 // count train_em returns; false: the kernel met what it leaves to the iteration-at-a-time path (gmm untouched).
 bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, const Parameter &param, double relevance, int *iterations) {
     const int K = gmm.nr_mixtures, KD = K * dim;
+    int device = 0;
+    SR_HIP(hipGetDevice(&device));
+    DeviceFitLock fit_lock(device);               // (held until this function has the kernel's answer)
+    if (!fit_lock.held) return false;
     auto &w = per_device<EmSmallWorkspace>();
     const EmSmallShape shape = em_small_shape(K, dim, n);
     const int grid = shape.grid;
@@ -435,7 +481,7 @@ bool train_em_small(GMM &gmm, const GMM *ubm, const float *dX, long n, int dim, 
         if (ubm) init[K + 2 * KD + i] = ubm->mean[i];
     }
     w.init.upload(init.data(), init.size());
-    w.partials.ensure((size_t)grid * E);
+    w.partials.ensure((size_t)2 * grid * E);
     w.totals.ensure((size_t)E);
     w.out.ensure((size_t)K + 2 * (size_t)KD + (size_t)nit);
     w.result.ensure(96);

@@ -170,3 +170,22 @@ def test_whole_fit_gives_up_when_a_workgroup_never_arrives(built_lib):
     assert all(np.array_equal(a, b) for a, b in zip(absent[1], per_launch[1]))          # the other path from the start: its bits
     again = _fit(0, X, 8, 6, 0.0, seed=5)                                                # (the next fit is a whole one again)
     assert again[2] == 4 and all(np.array_equal(a, b) for a, b in zip(again[1], whole[1]))
+
+
+def test_whole_fits_from_several_processes_at_once(built_lib):
+    """Four processes enrol on the one device at the same time (scripts/debug/em_small_stress.py): every fit comes back whole,
+    with the bits of the process's first one.  What this pins: a workgroup that another process's kernel keeps off the chip in
+    the middle of adding up iteration t's partial sums must not see a faster workgroup's sums of t + 1 (two sets of partials,
+    by the iteration's parity -- with one set, 3 of 4 processes got different models from fit to fit), and whole-fit grids of
+    different processes do not meet on the chip (a per-device advisory lock)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "debug", "em_small_stress.py"), "4", "10"],
+                       capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if "whole fits" in l]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    m = re.search(r"whole fits (\d+) of (\d+), fits whose bits differ from the process's first (\d+)", line[-1])
+    assert m and m.group(1) == m.group(2) == "40" and m.group(3) == "0", line[-1]
