@@ -391,25 +391,34 @@ struct DeviceFitLock {
     int fd = -1;
     bool held = false;
     explicit DeviceFitLock(int device) {
-        char bus[64] = {0};
-        if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
-            (void)hipGetLastError();
-            return;
+        // the file stays open for the life of the process (asking the runtime for the bus id and opening the file cost 2 ms per
+        // fit); a forked child opens its own -- a lock belongs to the open file, which a child would share with its parent
+        static pid_t owner = 0;
+        static int fds[MAX_DEVICES];
+        if (owner != getpid()) {
+            owner = getpid();
+            for (int &f : fds) f = -1;
         }
-        for (char *c = bus; *c; c++)
-            if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-        const std::string path = "/dev/shm/sr_whole_fit_" + std::to_string((unsigned)getuid()) + "_" + bus + ".lock";
-        fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        if (device < 0 || device >= MAX_DEVICES) return;
+        if (fds[device] < 0) {
+            char bus[64] = {0};
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
+            for (char *c = bus; *c; c++)
+                if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            const std::string path = "/dev/shm/sr_whole_fit_" + std::to_string((unsigned)getuid()) + "_" + bus + ".lock";
+            fds[device] = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        }
+        fd = fds[device];
         if (fd < 0) return;
         int rc;
         do rc = flock(fd, LOCK_EX); while (rc != 0 && errno == EINTR);
         held = rc == 0;
     }
     ~DeviceFitLock() {
-        if (fd >= 0) {
-            if (held) (void)flock(fd, LOCK_UN);
-            (void)close(fd);
-        }
+        if (held) (void)flock(fd, LOCK_UN);
     }
     DeviceFitLock(const DeviceFitLock &) = delete;
     DeviceFitLock &operator=(const DeviceFitLock &) = delete;
