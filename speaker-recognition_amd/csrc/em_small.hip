@@ -409,7 +409,7 @@ struct DeviceFitLock {
             for (char *c = bus; *c; c++)
                 if (*c == ':' || *c == '.' || *c == '/') *c = '_';
             const std::string path = "/dev/shm/sr_whole_fit_" + std::to_string((unsigned)getuid()) + "_" + bus + ".lock";
-            fds[device] = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+            fds[device] = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
         }
         fd = fds[device];
         if (fd < 0) return;
