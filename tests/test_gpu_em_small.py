@@ -152,7 +152,7 @@ def test_whole_fit_progress_lines_and_the_legacy_symbol(built_lib, tmp_path):
 
 def test_whole_fit_gives_up_when_a_workgroup_never_arrives(built_lib):
     """The whole-fit kernel is an ordinary launch whose workgroups meet at a grid-wide barrier; should part of the grid never
-    start (other processes holding the chip), the workgroups that wait give the grid up after ~0.3 s of polling and the fit
+    start (other processes holding the chip), the workgroups that wait give the grid up after ~0.1 s of polling and the fit
     runs an iteration per launch instead.  Test hook (option debug_em_small_absent_workgroup): workgroup 1 stays away from
     the third barrier."""
     from speaker_recognition_amd import _lib
